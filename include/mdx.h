@@ -1,0 +1,275 @@
+/*
+ * mdx.h — C-ABI of libmdx.so, the MI355X (gfx950) kernel library behind
+ * magicdrive_amd's drop-in for MagicDrive's per-step denoiser.
+ *
+ * Boundary: the reference has no FFI of its own — its hot path is
+ * Python calling torch ATen / xformers.  The lowest replaceable interface is
+ *   - xformers.ops.memory_efficient_attention(q, k, v, attn_bias, p, scale, op)
+ *       third_party/xformers/xformers/ops/fmha/__init__.py:115-196, called from
+ *       third_party/diffusers/src/diffusers/models/attention_processor.py:1165-1171
+ *   - ATen conv2d / addmm / native_group_norm / native_layer_norm / gelu / silu as
+ *       invoked by third_party/diffusers/src/diffusers/models/{resnet.py:590-640,
+ *       attention.py:259-280, transformer_2d.py:276-315, embeddings.py:24-64}
+ *   - the scheduler update third_party/diffusers/src/diffusers/schedulers/
+ *       scheduling_ddim.py:325-445 and CFG combine magicdrive/pipeline/
+ *       pipeline_bev_controlnet.py:426-431.
+ * Every entry point below replaces one of those call sites (cited per function).
+ *
+ * Conventions
+ *   - plain C: pointers, 64-bit integers and doubles only; no torch types.  Every
+ *     descriptor field is 8 bytes wide so a ctypes.Structure mirrors it 1:1.
+ *   - all device pointers are caller-owned HBM; nothing is allocated or freed here
+ *     except graph handles; no implicit synchronisation: work is enqueued on the
+ *     hipStream_t passed as `stream` (void*), so calls are hipGraph-capturable.
+ *   - activations are channels-last: a feature map is [B][H][W][C] == a token
+ *     matrix [B*H*W][C]; "ld*" are row (pixel/token) strides in ELEMENTS.
+ *   - bf16 = upper 16 bits of IEEE fp32, round-to-nearest-even on store; all
+ *     accumulation, softmax, normalisation statistics and scheduler math in fp32.
+ *   - return 0 on success, negative MDX_E* otherwise; never throws.
+ *     mdx_last_error() returns a thread-local message for the last failure.
+ */
+#ifndef MDX_H_
+#define MDX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDX_OK 0
+#define MDX_EINVAL (-1)      /* bad descriptor (shape/alignment/unsupported size) */
+#define MDX_ELAUNCH (-2)     /* hip launch / runtime error */
+#define MDX_EUNSUPPORTED (-3)
+
+#define MDX_ABI_VERSION 1
+
+/* ---- epilogue flags shared by GEMM / conv ------------------------------- */
+#define MDX_EPI_NONE 0
+#define MDX_EPI_GEGLU 1      /* W rows interleaved [32 value | 32 gate]; C has N/2 cols:
+                                C = value * gelu_erf(gate)   (attention.py:259-280) */
+#define MDX_EPI_SILU 2       /* C = silu(acc + bias)  (map_embedder.py:66-76, bbox_embedder.py:145-152) */
+
+/*
+ * mdx_gemm_bf16 — C[M,N] = epi(A[M,K] · W[N,K]^T + bias[N] + temb[row(m),N]) + R[M,N]
+ * Replaces ATen addmm/mm for every nn.Linear on the path and every 1x1 conv
+ * (attention_processor.py:141-157 to_q/k/v/out, attention.py:200-216 FeedForward,
+ * transformer_2d.py:155-165 proj_in/out, blocks.py:81-83 connector,
+ * unet_addon_rawbox.py:221-272 zero-convs).
+ * batch > 1: independent problems, pointer p advances by s*[batch index] elements
+ * (used to emit V^T = W_v · X_b^T per view with sA = 0).
+ * temb: optional fp32 table; row added to output row m is
+ *        temb[sel*temb_sel_stride + (m / rows_per_b)*temb_b_stride + n]
+ * where sel = *sel_ptr (device int32, 0 if null) — lets a captured graph pick the
+ * current step's row of a table precomputed for all DDIM steps.
+ * splitk: 0 = let the library choose (it splits K for small-M/huge-K shapes so the launch fills
+ * 256 CUs), 1 = never, >1 = forced.  Splitting needs ws: fp32 [splitk][M][N] scratch of ws_bytes.
+ * Requirements: K % 8 == 0, lda/ldw % 8 == 0, 16-byte aligned A/W; ldc,ldr % 4 == 0.
+ */
+typedef struct MdxGemmDesc {
+    const void* A; const void* W; void* C; const void* R;
+    const float* bias; const float* temb; const int32_t* sel_ptr; float* ws;
+    int64_t M, N, K;
+    int64_t lda, ldw, ldc, ldr;
+    int64_t batch, sA, sW, sC, sR;
+    int64_t temb_sel_stride, temb_b_stride, rows_per_b;
+    int64_t epilogue, splitk;
+    int64_t c_is_f32;           /* 1: C (and R) are fp32 instead of bf16 */
+    int64_t ws_bytes;           /* size of ws; split-K is reduced (or disabled) to fit */
+} MdxGemmDesc;
+int mdx_gemm_bf16(const MdxGemmDesc* d, void* stream);
+
+/*
+ * mdx_conv2d_bf16 — channels-last implicit-GEMM convolution on MFMA:
+ *   Y[b,oy,ox,co] = epi( Σ_{ky,kx,ci} X[b, oy*sh-ph+ky, ox*sw-pw+kx, ci] · Wt[co][ky][kx][ci]
+ *                        + bias[co] + temb[b,co] ) + R[b,oy,ox,co]
+ * Replaces ATen conv2d in ResnetBlock2D.conv1/conv2 (resnet.py:590-640, temb add :617-618,
+ * residual add :638), Downsample2D (resnet.py:198-222), Upsample2D.conv (resnet.py:165-170),
+ * the BEV map encoder (map_embedder.py:66-76).  Weights are pre-packed [Cout][kh][kw][Cin].
+ * ldx/ldy/ldr: pixel strides in elements (a tensor may be a channel slice of a wider one).
+ * Cin % 8 == 0 required (smaller Cin goes through mdx_conv2d_direct).
+ */
+typedef struct MdxConvDesc {
+    const void* X; const void* Wt; void* Y; const void* R;
+    const float* bias; const float* temb; const int32_t* sel_ptr; float* ws;
+    int64_t B, Hi, Wi, Cin, Ho, Wo, Cout;
+    int64_t kh, kw, sh, sw, ph, pw;
+    int64_t ldx, ldy, ldr;
+    int64_t temb_sel_stride, temb_b_stride;
+    int64_t epilogue, splitk;
+    int64_t ws_bytes, reserved1;
+} MdxConvDesc;
+int mdx_conv2d_bf16(const MdxConvDesc* d, void* stream);
+
+/*
+ * mdx_conv2d_direct — small-channel / odd-K convolution or linear on the vector ALU
+ * (fp32 accumulate): conv_in (Cin=4, unet_2d_condition.py:262-265), conv_out (Cout=4, :497-500),
+ * cam2token (K=189, unet_addon_rawbox.py:106), bbox_proj (K=216, bbox_embedder.py:72).
+ * x_is_f32 / y_is_f32 select fp32 I/O (latents and eps stay fp32).
+ */
+typedef struct MdxConvDirectDesc {
+    const void* X; const void* Wt; void* Y; const void* R;
+    const float* bias; const float* temb; const int32_t* sel_ptr; void* reserved_p;
+    int64_t B, Hi, Wi, Cin, Ho, Wo, Cout;
+    int64_t kh, kw, sh, sw, ph, pw;
+    int64_t ldx, ldy, ldr;
+    int64_t temb_sel_stride, temb_b_stride;
+    int64_t epilogue, x_is_f32, y_is_f32, reserved0;
+} MdxConvDirectDesc;
+int mdx_conv2d_direct(const MdxConvDirectDesc* d, void* stream);
+
+/*
+ * mdx_attention_bf16 — fused softmax(Q K^T * scale) V, flash style (no T×T matrix in HBM).
+ * Replaces xformers.ops.memory_efficient_attention (fmha/__init__.py:115-196; CUTLASS kernel
+ * kernel_forward.h) / F.scaled_dot_product_attention (attention_processor.py:1193-1272) for
+ * attn1 (self), attn2 (text+camera+box context) and attn4 (cross-view, blocks.py:106-222).
+ *   Q : [B][Tq][..]  element (b,t,h,j) at Q + b*sQ + t*ldq + h*d + j
+ *   K : [Bkv][Tk][..] same addressing with sK, ldk
+ *   Vt: [Bkv][H*d][ldv]  V transposed — element (b,h,j,t) at Vt + b*sV + (h*d+j)*ldv + t
+ *   O : [B][Tq][H*d] with sO, ldo
+ * nsrc ∈ {1,2}: for query batch b the key/value batches are kvmap[b*nsrc + s] (identity if
+ * kvmap == NULL); with nsrc == 2 the two softmax-normalised outputs are SUMMED — exactly
+ * blocks.py:213-217 (left + right neighbour; the doubled out-bias is the caller's business).
+ * d % 8 == 0, d <= 160; ldq,ldk,ldv,sQ,sK,sV % 8 == 0; ldo % 4 == 0.
+ */
+typedef struct MdxAttnDesc {
+    const void* Q; const void* K; const void* Vt; void* O;
+    const int32_t* kvmap; void* reserved_p;
+    int64_t B, H, Tq, Tk, d, nsrc;
+    int64_t ldq, sQ, ldk, sK, ldv, sV, ldo, sO;
+    double scale;
+    int64_t reserved0;
+} MdxAttnDesc;
+int mdx_attention_bf16(const MdxAttnDesc* d, void* stream);
+
+/*
+ * mdx_groupnorm_bf16 — GroupNorm(+SiLU) over channels-last [B][HW][C]
+ * (ATen native_group_norm + silu: resnet.py:596-598, 626-630; transformer_2d.py:278;
+ *  unet_2d_condition_multiview.py:519-521).  stats in fp32, two-pass variance.
+ */
+typedef struct MdxGroupNormDesc {
+    const void* X; void* Y; const float* gamma; const float* beta;
+    int64_t B, HW, C, G, ldx, ldy;
+    double eps;
+    int64_t silu;
+} MdxGroupNormDesc;
+int mdx_groupnorm_bf16(const MdxGroupNormDesc* d, void* stream);
+
+/* mdx_layernorm_bf16 — LayerNorm over the last dim of [M][C] (attention.py:85,104,120; blocks.py:67-71). */
+typedef struct MdxLayerNormDesc {
+    const void* X; void* Y; const float* gamma; const float* beta;
+    int64_t M, C, ldx, ldy;
+    double eps;
+    int64_t reserved0;
+} MdxLayerNormDesc;
+int mdx_layernorm_bf16(const MdxLayerNormDesc* d, void* stream);
+
+/* ---- small element-wise kernels ---------------------------------------- */
+#define MDX_EW_ADD 1          /* Y[m, :C] += X[m, :C]            (unet_2d_condition_multiview.py:464-488) */
+#define MDX_EW_COPY 2         /* Y[m, :C]  = X[m, :C]  (concat halves: unet_2d_blocks.py:1990, 2090) */
+#define MDX_EW_UPSAMPLE 3     /* nearest resize [B,Hi,Wi,C] -> [B,Ho,Wo,C] (resnet.py:154-163) */
+#define MDX_EW_NCHW_TO_NHWC 4 /* X fp32/bf16 NCHW -> Y NHWC */
+#define MDX_EW_NHWC_TO_NCHW 5
+#define MDX_EW_SILU 6
+#define MDX_EW_SCALE 7        /* Y = X * alpha */
+typedef struct MdxEwDesc {
+    const void* X; void* Y; const int32_t* ymap; const int32_t* xmap;
+    int64_t kind, M, C, ldx, ldy;
+    int64_t B, Hi, Wi, Ho, Wo;
+    int64_t x_is_f32, y_is_f32;
+    double alpha;
+} MdxEwDesc;
+int mdx_elementwise(const MdxEwDesc* d, void* stream);
+
+/*
+ * mdx_fourier_embed — NeRF embedding [x, sin(2^k x), cos(2^k x)]_{k<F} of 3-vectors
+ * (magicdrive/networks/embedder.py:15-40) for camera columns (unet_addon_rawbox.py:288-305) and
+ * box corners with the masked null blend pos*m + null*(1-m) (bbox_embedder.py:165-176).
+ *   X fp32 [n][P][3]  ->  Y bf16 [n][P*(3+6F)] ; mask (uint8 [n]) and null (fp32 [P*(3+6F)]) optional.
+ */
+typedef struct MdxFourierDesc {
+    const float* X; void* Y; const uint8_t* mask; const float* null_feat;
+    int64_t n, P, F, ldy;
+} MdxFourierDesc;
+int mdx_fourier_embed(const MdxFourierDesc* d, void* stream);
+
+/*
+ * mdx_gather_rows — Y[i,:] = m[i] ? T[idx[i],:] : null[:]  (class-token lookup with null blend,
+ * bbox_embedder.py:179-180; idx may be -1 where mask is 0).
+ */
+typedef struct MdxGatherDesc {
+    const void* T; void* Y; const int64_t* idx; const uint8_t* mask; const void* null_row; void* reserved_p;
+    int64_t n, C, ldt, ldy, n_rows, reserved0;
+} MdxGatherDesc;
+int mdx_gather_rows(const MdxGatherDesc* d, void* stream);
+
+/*
+ * mdx_timestep_embedding — sinusoidal timestep features, fp32 math
+ * (diffusers/models/embeddings.py:24-64 with flip_sin_to_cos, downscale_freq_shift):
+ *   Y[i, :] = [cos(t_i * f_j) | sin(t_i * f_j)]  (flip) , f_j = exp(-ln(max_period) * j / (half - shift))
+ */
+typedef struct MdxTimeEmbDesc {
+    const float* t; float* Y;   /* Y fp32 [n][ldy] */
+    int64_t n, dim, flip_sin_to_cos, ldy;
+    double freq_shift, max_period;
+} MdxTimeEmbDesc;
+int mdx_timestep_embedding(const MdxTimeEmbDesc* d, void* stream);
+
+/*
+ * mdx_cfg_ddim_step — fused classifier-free-guidance combine + DDIM update, fp32:
+ *   eps = eps_u + g (eps_c - eps_u)                      pipeline_bev_controlnet.py:426-431
+ *   x0  = (x - sqrt(1-a_t) eps) / sqrt(a_t) ; x <- sqrt(a_prev) x0 + sqrt(1-a_prev) eps
+ *                                                        scheduling_ddim.py:379-425 (eta = 0)
+ * coef: fp32 [n_steps][4] = {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)}; row = *step_ptr.
+ * eps holds [uncond | cond] halves of n elements each when cfg != 0.  After the update the
+ * kernel increments *step_ptr (single thread) so a replayed graph walks the table, and also
+ * refreshes the bf16/fp32 model-input copy(ies) `x_in` (n elements, duplicated for CFG).
+ */
+typedef struct MdxDdimDesc {
+    float* x; const float* eps; const float* coef; int32_t* step_ptr; float* x_in; void* reserved_p;
+    int64_t n, cfg;
+    double guidance;
+    int64_t reserved0;
+} MdxDdimDesc;
+int mdx_cfg_ddim_step(const MdxDdimDesc* d, void* stream);
+
+/* ---- program = array of ops, executed in order on one stream ------------ */
+#define MDX_OP_GEMM 1
+#define MDX_OP_CONV 2
+#define MDX_OP_CONV_DIRECT 3
+#define MDX_OP_ATTN 4
+#define MDX_OP_GROUPNORM 5
+#define MDX_OP_LAYERNORM 6
+#define MDX_OP_EW 7
+#define MDX_OP_FOURIER 8
+#define MDX_OP_GATHER 9
+#define MDX_OP_TIMEEMB 10
+#define MDX_OP_DDIM 11
+
+#define MDX_OP_BYTES 512
+typedef struct MdxOp {
+    int64_t opcode;
+    int64_t reserved;
+    unsigned char desc[MDX_OP_BYTES - 16];   /* one of the Mdx*Desc above, zero padded */
+} MdxOp;
+
+/* Run ops[0..n) in order on `stream`.  Stops at the first failing op (returns its code;
+ * mdx_last_error() names the op index). */
+int mdx_program_run(const MdxOp* ops, int64_t n, void* stream);
+
+/* Capture ops[0..n) into a hipGraph (stream capture on an internal stream) and instantiate it.
+ * The pointers inside the ops are baked into the graph; per-replay variation comes only from
+ * device memory (sel_ptr / step_ptr tables). */
+int mdx_graph_create(const MdxOp* ops, int64_t n, void** graph_out);
+int mdx_graph_launch(void* graph, void* stream);
+int mdx_graph_destroy(void* graph);
+
+int mdx_abi_version(void);
+const char* mdx_last_error(void);
+/* Device facts for bench/roofline bookkeeping: out[0]=CU count, out[1]=clock kHz, out[2]=HBM bytes. */
+int mdx_device_info(int64_t* out3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDX_H_ */

@@ -1,0 +1,166 @@
+"""ctypes binding of libmdx.so (the C-ABI declared in include/mdx.h).
+
+The product path has NO fallback: if the shared library is missing or does not export the
+ABI this module raises at import of the symbol table (`lib()`), and every op wrapper raises
+`MdxError` on a non-zero return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdx.so")
+
+ABI_VERSION = 1
+
+# opcodes (mdx.h)
+OP_GEMM, OP_CONV, OP_CONV_DIRECT, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM = 1, 2, 3, 4, 5, 6
+OP_EW, OP_FOURIER, OP_GATHER, OP_TIMEEMB, OP_DDIM = 7, 8, 9, 10, 11
+OP_BYTES = 512
+
+EPI_NONE, EPI_GEGLU, EPI_SILU = 0, 1, 2
+EW_ADD, EW_COPY, EW_UPSAMPLE, EW_NCHW_TO_NHWC, EW_NHWC_TO_NCHW, EW_SILU, EW_SCALE = 1, 2, 3, 4, 5, 6, 7
+
+P, I, D = C.c_void_p, C.c_int64, C.c_double
+
+
+def _struct(name: str, fields: List[Tuple[str, object]]):
+    return type(name, (C.Structure,), {"_fields_": fields})
+
+
+def _f(kind, names: str):
+    return [(n, kind) for n in names.split()]
+
+
+MdxGemmDesc = _struct("MdxGemmDesc", _f(P, "A W C R bias temb sel_ptr ws") + _f(I, "M N K lda ldw ldc ldr batch sA sW sC sR "
+                      "temb_sel_stride temb_b_stride rows_per_b epilogue splitk c_is_f32 ws_bytes"))
+MdxConvDesc = _struct("MdxConvDesc", _f(P, "X Wt Y R bias temb sel_ptr ws") + _f(I, "B Hi Wi Cin Ho Wo Cout kh kw sh sw ph pw "
+                      "ldx ldy ldr temb_sel_stride temb_b_stride epilogue splitk ws_bytes reserved1"))
+MdxConvDirectDesc = _struct("MdxConvDirectDesc", _f(P, "X Wt Y R bias temb sel_ptr reserved_p") + _f(I, "B Hi Wi Cin Ho Wo Cout kh kw sh sw ph pw "
+                            "ldx ldy ldr temb_sel_stride temb_b_stride epilogue x_is_f32 y_is_f32 reserved0"))
+MdxAttnDesc = _struct("MdxAttnDesc", _f(P, "Q K Vt O kvmap reserved_p") + _f(I, "B H Tq Tk d nsrc ldq sQ ldk sK ldv sV ldo sO")
+                      + _f(D, "scale") + _f(I, "reserved0"))
+MdxGroupNormDesc = _struct("MdxGroupNormDesc", _f(P, "X Y gamma beta") + _f(I, "B HW C G ldx ldy") + _f(D, "eps") + _f(I, "silu"))
+MdxLayerNormDesc = _struct("MdxLayerNormDesc", _f(P, "X Y gamma beta") + _f(I, "M C ldx ldy") + _f(D, "eps") + _f(I, "reserved0"))
+MdxEwDesc = _struct("MdxEwDesc", _f(P, "X Y ymap xmap") + _f(I, "kind M C ldx ldy B Hi Wi Ho Wo x_is_f32 y_is_f32") + _f(D, "alpha"))
+MdxFourierDesc = _struct("MdxFourierDesc", _f(P, "X Y mask null_feat") + _f(I, "n P F ldy"))
+MdxGatherDesc = _struct("MdxGatherDesc", _f(P, "T Y idx mask null_row reserved_p") + _f(I, "n C ldt ldy n_rows reserved0"))
+MdxTimeEmbDesc = _struct("MdxTimeEmbDesc", _f(P, "t Y") + _f(I, "n dim flip_sin_to_cos ldy") + _f(D, "freq_shift max_period"))
+MdxDdimDesc = _struct("MdxDdimDesc", _f(P, "x eps coef step_ptr x_in reserved_p") + _f(I, "n cfg") + _f(D, "guidance") + _f(I, "reserved0"))
+
+DESC_OF_OP = {
+    OP_GEMM: MdxGemmDesc, OP_CONV: MdxConvDesc, OP_CONV_DIRECT: MdxConvDirectDesc, OP_ATTN: MdxAttnDesc,
+    OP_GROUPNORM: MdxGroupNormDesc, OP_LAYERNORM: MdxLayerNormDesc, OP_EW: MdxEwDesc, OP_FOURIER: MdxFourierDesc,
+    OP_GATHER: MdxGatherDesc, OP_TIMEEMB: MdxTimeEmbDesc, OP_DDIM: MdxDdimDesc,
+}
+ENTRY_OF_OP = {
+    OP_GEMM: "mdx_gemm_bf16", OP_CONV: "mdx_conv2d_bf16", OP_CONV_DIRECT: "mdx_conv2d_direct", OP_ATTN: "mdx_attention_bf16",
+    OP_GROUPNORM: "mdx_groupnorm_bf16", OP_LAYERNORM: "mdx_layernorm_bf16", OP_EW: "mdx_elementwise",
+    OP_FOURIER: "mdx_fourier_embed", OP_GATHER: "mdx_gather_rows", OP_TIMEEMB: "mdx_timestep_embedding", OP_DDIM: "mdx_cfg_ddim_step",
+}
+# every symbol include/mdx.h declares
+EXPORTS = sorted(set(ENTRY_OF_OP.values()) | {
+    "mdx_program_run", "mdx_graph_create", "mdx_graph_launch", "mdx_graph_destroy",
+    "mdx_abi_version", "mdx_last_error", "mdx_device_info"})
+
+
+class MdxOp(C.Structure):
+    _fields_ = [("opcode", I), ("reserved", I), ("desc", C.c_ubyte * (OP_BYTES - 16))]
+
+
+assert C.sizeof(MdxOp) == OP_BYTES
+for _d in DESC_OF_OP.values():
+    assert C.sizeof(_d) <= OP_BYTES - 16 and C.sizeof(_d) % 8 == 0
+
+
+class MdxError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+
+def lib() -> C.CDLL:
+    """Load libmdx.so (once).  Raises if it is missing or exports the wrong ABI — never falls back."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise MdxError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C magicdrive_amd/csrc`. magicdrive_amd has no CPU / PyTorch fallback.")
+    l = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(l, name):
+            raise MdxError(f"libmdx.so does not export {name}")
+    for name in ENTRY_OF_OP.values():
+        fn = getattr(l, name)
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p]
+    l.mdx_program_run.restype = C.c_int
+    l.mdx_program_run.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    l.mdx_graph_create.restype = C.c_int
+    l.mdx_graph_create.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+    l.mdx_graph_launch.restype = C.c_int
+    l.mdx_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
+    l.mdx_graph_destroy.restype = C.c_int
+    l.mdx_graph_destroy.argtypes = [C.c_void_p]
+    l.mdx_abi_version.restype = C.c_int
+    l.mdx_last_error.restype = C.c_char_p
+    l.mdx_device_info.restype = C.c_int
+    l.mdx_device_info.argtypes = [C.POINTER(C.c_int64)]
+    if l.mdx_abi_version() != ABI_VERSION:
+        raise MdxError(f"libmdx.so ABI {l.mdx_abi_version()} != expected {ABI_VERSION}")
+    _LIB = l
+    return l
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().mdx_last_error()
+        raise MdxError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def call_op(opcode: int, desc: C.Structure, stream: int) -> None:
+    """Run a single op descriptor on `stream` (a raw hipStream_t value)."""
+    fn = getattr(lib(), ENTRY_OF_OP[opcode])
+    check(fn(C.byref(desc), C.c_void_p(stream)), ENTRY_OF_OP[opcode])
+
+
+class Program:
+    """A flat array of MdxOp built from (opcode, descriptor) pairs; runnable eagerly or as a hipGraph."""
+
+    def __init__(self, ops: List[Tuple[int, C.Structure]]):
+        self.n = len(ops)
+        self.buf = (MdxOp * max(self.n, 1))()
+        for i, (code, desc) in enumerate(ops):
+            self.buf[i].opcode = code
+            C.memmove(C.addressof(self.buf[i]) + 16, C.byref(desc), C.sizeof(desc))
+        self._graph = C.c_void_p(None)
+
+    def run(self, stream: int) -> None:
+        check(lib().mdx_program_run(C.byref(self.buf), self.n, C.c_void_p(stream)), "mdx_program_run")
+
+    def capture(self) -> None:
+        if not self._graph:
+            check(lib().mdx_graph_create(C.byref(self.buf), self.n, C.byref(self._graph)), "mdx_graph_create")
+
+    def launch(self, stream: int) -> None:
+        if not self._graph:
+            self.capture()
+        check(lib().mdx_graph_launch(self._graph, C.c_void_p(stream)), "mdx_graph_launch")
+
+    def __del__(self):
+        try:
+            if self._graph and _LIB is not None:
+                _LIB.mdx_graph_destroy(self._graph)
+        except Exception:
+            pass
+
+
+def device_info() -> Dict[str, int]:
+    out = (C.c_int64 * 3)()
+    check(lib().mdx_device_info(out), "mdx_device_info")
+    return {"cus": out[0], "clock_khz": out[1], "hbm_bytes": out[2]}

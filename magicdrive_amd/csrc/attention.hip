@@ -1,0 +1,278 @@
+// attention.hip — fused flash-style attention forward for gfx950 (wave64, MFMA 32x32x16 bf16).
+//
+// Replaces xformers' CUTLASS fMHA (third_party/xformers/xformers/csrc/attention/cuda/fmha/
+// kernel_forward.h) as called by XFormersAttnProcessor (diffusers/models/attention_processor.py:
+// 1165-1171) for attn1 / attn2 / attn4 of every transformer block, incl. the MagicDrive
+// cross-view attention (magicdrive/networks/blocks.py:106-222).
+//
+// Shape regime here: 8 heads, head dim d in {40, 80, 160}, Tq in {1400, 350, 91, 28}, Tk = Tq
+// (self / cross-view) or 78+L (context).  Nothing is a multiple of 64, so everything is masked.
+//
+// Design (one workgroup = NW waves = NW*32 query rows of one (batch, head)):
+//   * Q fragments live in registers for the whole kernel (d/16 x 4 VGPRs).
+//   * K tile [64 kv][d] and V^T tile [d][64 kv] are staged into LDS with 16-byte loads.
+//     V arrives already transposed from the projection GEMM (it is emitted as W_v · X^T), so the
+//     PV product needs no transposing LDS reads: a lane fetches its 8 kv values with two
+//     ds_read_b64.  LDS strides (d+8 resp. 64+4 elements) make both fragment reads conflict-free.
+//   * S^T = K · Q^T (operands swapped) so each lane owns ONE query column: the online-softmax
+//     max / sum / rescale are lane-local (one cross-half shuffle per tile), and the P^T
+//     registers are directly the B operand of O^T += V^T · P^T — no LDS round trip for P.
+//     The kv order inside a 16-wide MFMA k-step is permuted (kv = 4h + j, 8 + 4h + j) to match
+//     the accumulator layout; V^T is read with the same permutation, so the sum is unchanged.
+//   * softmax in fp32 with exp2 and a folded log2(e)*scale; running max initialised to -inf.
+//   * nsrc == 2 (cross-view): the kv loop runs once per neighbour with its own softmax state and
+//     the two normalised outputs are summed in registers (blocks.py:213-217).
+#include "common.h"
+#include "launch.h"
+
+namespace mdx {
+
+struct AttnParams {
+    const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
+    const int* kvmap;
+    int B, H, Tq, Tk, d, nsrc;
+    long ldq, sQ, ldk, sK, ldv, sV, ldo, sO;
+    float scale_log2;  // scale * log2(e)
+};
+
+constexpr int KVT = 64;          // kv tile
+constexpr int VSTR = KVT + 4;    // V^T LDS row stride (136 B): ds_read_b64 conflict-free
+
+template <int D16, int NW, bool TWO>
+__global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
+    constexpr int DT = (D16 + 1) / 2;   // 32-row d tiles of O^T
+    constexpr int DP = D16 * 16;        // padded head dim for QK^T
+    constexpr int KSTR = DP + 8;        // K LDS row stride (elements)
+    constexpr int NT = NW * 64;
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[KVT * KSTR];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[DT * 32 * VSTR];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const int h = blockIdx.y;
+    const int b = blockIdx.z;
+    const int d = p.d;
+    const int q = blockIdx.x * (NW * 32) + wave * 32 + col;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane -> query column, 8 consecutive dims ----
+    Frag8 qf[D16];
+    {
+        const bf16_t* qp = p.Q + (long)b * p.sQ + (long)(q < p.Tq ? q : 0) * p.ldq + (long)h * d;
+#pragma unroll
+        for (int ks = 0; ks < D16; ++ks) {
+            int dd = ks * 16 + half * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q < p.Tq && dd < d) v = *(const uint4*)(qp + dd);
+            qf[ks].u = v;
+        }
+    }
+
+    f32x16_t oacc[DT];
+    f32x16_t osum[TWO ? DT : 1];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    if (TWO) {
+#pragma unroll
+        for (int i = 0; i < (TWO ? DT : 1); ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) osum[i][r] = 0.f;
+    }
+
+    for (int s = 0; s < p.nsrc; ++s) {
+        const int bkv = p.kvmap ? p.kvmap[b * p.nsrc + s] : b;
+        const bf16_t* kbase = p.K + (long)bkv * p.sK + (long)h * d;
+        const bf16_t* vbase = p.Vt + (long)bkv * p.sV + (long)h * d * p.ldv;
+        float m_run = -INFINITY;
+        float l_run = 0.f;
+
+        for (int j0 = 0; j0 < p.Tk; j0 += KVT) {
+            // ---- stage K tile: KVT rows x DP cols, 16-byte chunks ----
+            for (int c = tid; c < KVT * (DP / 8); c += NT) {
+                int row = c / (DP / 8);
+                int cc = c - row * (DP / 8);
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (j0 + row < p.Tk && cc * 8 < d) v = *(const uint4*)(kbase + (long)(j0 + row) * p.ldk + cc * 8);
+                *(uint4*)(Ks + row * KSTR + cc * 8) = v;
+            }
+            // ---- stage V^T tile: DT*32 rows (head dims) x KVT kv, 16-byte chunks along kv ----
+            for (int c = tid; c < DT * 32 * (KVT / 8); c += NT) {
+                int row = c >> 3;
+                int cc = c & 7;
+                Frag8 v;
+                v.u = make_uint4(0, 0, 0, 0);
+                int kv0 = j0 + cc * 8;
+                if (row < d && kv0 < p.Tk) {
+                    v.u = *(const uint4*)(vbase + (long)row * p.ldv + kv0);
+                    if (kv0 + 8 > p.Tk) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (kv0 + e >= p.Tk) v.h[e] = 0;
+                    }
+                }
+                uint2* dst = (uint2*)(Vs + row * VSTR + cc * 8);
+                dst[0] = v.d2[0];
+                dst[1] = v.d2[1];
+            }
+            __syncthreads();
+
+            // ---- S^T[kv][q] for two 32-kv sub-tiles ----
+            f32x16_t sacc[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[sub][r] = 0.f;
+                const bf16_t* kr = Ks + (sub * 32 + col) * KSTR + half * 8;
+#pragma unroll
+                for (int ks = 0; ks < D16; ++ks) {
+                    Frag8 kf;
+                    kf.u = *(const uint4*)(kr + ks * 16);
+                    sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v, qf[ks].v, sacc[sub], 0, 0, 0);
+                }
+            }
+            // ---- online softmax (this lane: one query, 32 of the 64 kv) ----
+            float mx = -INFINITY;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int kv = j0 + sub * 32 + mfma32_row(r, lane);
+                    float sv = kv < p.Tk ? sacc[sub][r] * p.scale_log2 : -INFINITY;
+                    sacc[sub][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);       // finite: every tile has >= 1 valid kv
+            const float alpha = exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
+            m_run = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float pv = exp2f(sacc[sub][r] - m_new);
+                    sacc[sub][r] = pv;
+                    psum += pv;
+                }
+            l_run = l_run * alpha + psum;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+
+            // ---- O^T[dd][q] += V^T[dd][kv] * P^T[kv][q] ----
+#pragma unroll
+            for (int kstep = 0; kstep < 4; ++kstep) {
+                const int sub = kstep >> 1, kk = kstep & 1;
+                Frag8 pf;
+                pf.u.x = pack2bf(sacc[sub][kk * 8 + 0], sacc[sub][kk * 8 + 1]);
+                pf.u.y = pack2bf(sacc[sub][kk * 8 + 2], sacc[sub][kk * 8 + 3]);
+                pf.u.z = pack2bf(sacc[sub][kk * 8 + 4], sacc[sub][kk * 8 + 5]);
+                pf.u.w = pack2bf(sacc[sub][kk * 8 + 6], sacc[sub][kk * 8 + 7]);
+                const bf16_t* vr = Vs + col * VSTR + kstep * 16 + 4 * half;
+#pragma unroll
+                for (int i = 0; i < DT; ++i) {
+                    Frag8 vf;
+                    vf.d2[0] = *(const uint2*)(vr + i * 32 * VSTR);
+                    vf.d2[1] = *(const uint2*)(vr + i * 32 * VSTR + 8);
+                    oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, oacc[i], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- finish this source ----
+        float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        float inv = 1.0f / l_tot;
+        if (TWO) {
+#pragma unroll
+            for (int i = 0; i < (TWO ? DT : 1); ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    osum[i][r] += oacc[i][r] * inv;
+                    oacc[i][r] = 0.f;
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= inv;
+        }
+    }
+
+    // ---- store O[q][h*d + dd]: lane has 4 consecutive dd per register group ----
+    if (q < p.Tq) {
+        bf16_t* op = p.O + (long)b * p.sO + (long)q * p.ldo + (long)h * d;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int dd = i * 32 + 8 * g + 4 * half;
+                if (dd < d) {
+                    const f32x16_t& src = TWO ? osum[TWO ? i : 0] : oacc[i];
+                    uint2 ov;
+                    ov.x = pack2bf(src[4 * g], src[4 * g + 1]);
+                    ov.y = pack2bf(src[4 * g + 2], src[4 * g + 3]);
+                    *(uint2*)(op + dd) = ov;
+                }
+            }
+    }
+}
+
+template <int D16, int NW>
+static int launch_attn(const AttnParams& p, hipStream_t st) {
+    dim3 grid((p.Tq + NW * 32 - 1) / (NW * 32), p.H, p.B);
+    if (p.nsrc == 2)
+        hipLaunchKernelGGL((attn_kernel<D16, NW, true>), grid, dim3(NW * 64), 0, st, p);
+    else
+        hipLaunchKernelGGL((attn_kernel<D16, NW, false>), grid, dim3(NW * 64), 0, st, p);
+    return check_launch("attn_kernel");
+}
+
+template <int D16>
+static int launch_attn_nw(const AttnParams& p, hipStream_t st) {
+    // 4 waves (128 queries) per workgroup when there are enough rows to fill 256 CUs, else
+    // smaller workgroups so short sequences (91, 28 tokens) still spread over the chip.
+    long blocks4 = (long)((p.Tq + 127) / 128) * p.H * p.B;
+    if (p.Tq >= 256 && blocks4 >= 256) return launch_attn<D16, 4>(p, st);
+    if (p.Tq >= 64) return launch_attn<D16, 2>(p, st);
+    return launch_attn<D16, 1>(p, st);
+}
+
+}  // namespace mdx
+
+using namespace mdx;
+
+extern "C" int mdx_attention_bf16(const MdxAttnDesc* a, void* stream) {
+    if (!a || !a->Q || !a->K || !a->Vt || !a->O) return set_error(MDX_EINVAL, "mdx_attention_bf16: null operand");
+    if (a->d % 8 || a->d <= 0 || a->d > 160) return set_error(MDX_EINVAL, "head dim %ld unsupported (d %% 8 == 0, d <= 160)", (long)a->d);
+    if (a->nsrc != 1 && a->nsrc != 2) return set_error(MDX_EINVAL, "nsrc must be 1 or 2");
+    if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->sQ % 8) || (a->sK % 8) || (a->sV % 8) || (a->ldo % 4) || (a->sO % 4))
+        return set_error(MDX_EINVAL, "attention strides must be multiples of 8 (Q,K,Vt) / 4 (O)");
+    if (((uintptr_t)a->Q & 15) || ((uintptr_t)a->K & 15) || ((uintptr_t)a->Vt & 15) || ((uintptr_t)a->O & 7))
+        return set_error(MDX_EINVAL, "attention operands must be 16-byte aligned");
+    if (a->Tq <= 0 || a->Tk <= 0 || a->B <= 0 || a->H <= 0) return MDX_OK;
+    if (a->ldv < a->Tk) return set_error(MDX_EINVAL, "ldv < Tk");
+    AttnParams p;
+    p.Q = (const bf16_t*)a->Q; p.K = (const bf16_t*)a->K; p.Vt = (const bf16_t*)a->Vt; p.O = (bf16_t*)a->O;
+    p.kvmap = a->kvmap;
+    p.B = (int)a->B; p.H = (int)a->H; p.Tq = (int)a->Tq; p.Tk = (int)a->Tk; p.d = (int)a->d; p.nsrc = (int)a->nsrc;
+    p.ldq = a->ldq; p.sQ = a->sQ; p.ldk = a->ldk; p.sK = a->sK; p.ldv = a->ldv; p.sV = a->sV; p.ldo = a->ldo; p.sO = a->sO;
+    p.scale_log2 = (float)(a->scale * 1.4426950408889634);
+    hipStream_t st = (hipStream_t)stream;
+    int d16 = (int)(a->d + 15) / 16;
+    switch (d16) {
+        case 1: return launch_attn_nw<1>(p, st);
+        case 2: return launch_attn_nw<2>(p, st);
+        case 3: return launch_attn_nw<3>(p, st);
+        case 4: return launch_attn_nw<4>(p, st);
+        case 5: return launch_attn_nw<5>(p, st);
+        case 6: return launch_attn_nw<6>(p, st);
+        case 8: return launch_attn_nw<8>(p, st);
+        case 10: return launch_attn_nw<10>(p, st);
+        default: return set_error(MDX_EUNSUPPORTED, "head dim %ld: no kernel instance (d/16 = %d)", (long)a->d, d16);
+    }
+}

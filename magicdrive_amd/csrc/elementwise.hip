@@ -1,0 +1,411 @@
+// elementwise.hip — the small kernels around the MFMA ops: direct (vector-ALU) convolution /
+// linear for tiny channel counts, residual adds / copies / nearest upsample / layout changes,
+// Fourier (NeRF) embedding, class-token gather, sinusoidal timestep features and the fused
+// classifier-free-guidance + DDIM update.  All are HBM/L2-bound byte movers: coalesced,
+// 16-byte vectorised where the layout allows, fp32 math.  Reference call sites: include/mdx.h.
+#include "common.h"
+#include "launch.h"
+
+namespace mdx {
+
+// ------------------------------------------------------------------------------------------
+// direct convolution / linear
+// ------------------------------------------------------------------------------------------
+struct CDParams {
+    const void* X; const bf16_t* W; void* Y; const void* R;
+    const float* bias; const float* temb; const int* sel;
+    int B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, sh, sw, ph, pw;
+    long ldx, ldy, ldr, temb_sel_stride, temb_b_stride;
+    int epi, x_f32, y_f32;
+};
+
+__device__ __forceinline__ float cd_finish(const CDParams& p, float acc, long m, int n, int b) {
+    if (p.bias) acc += p.bias[n];
+    if (p.temb) {
+        int sel = p.sel ? *p.sel : 0;
+        acc += p.temb[(long)sel * p.temb_sel_stride + (long)b * p.temb_b_stride + n];
+    }
+    if (p.epi == 2) acc = silu_f(acc);
+    if (p.R) acc += p.y_f32 ? ((const float*)p.R)[m * p.ldr + n] : bf2f(((const bf16_t*)p.R)[m * p.ldr + n]);
+    return acc;
+}
+
+// one thread per output element (n fastest): tiny K (conv_in K=36, cam2token K=189, bbox_proj K=216,
+// time-embedding MLP rows).
+template <bool XF32>
+__global__ __launch_bounds__(256) void conv_direct_simple_kernel(CDParams p) {
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    long total = (long)p.B * p.Ho * p.Wo * p.Cout;
+    if (idx >= total) return;
+    int n = (int)(idx % p.Cout);
+    long m = idx / p.Cout;
+    int hw = p.Ho * p.Wo;
+    int b = (int)(m / hw);
+    int rem = (int)(m - (long)b * hw);
+    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const bf16_t* w = p.W + (long)n * p.kh * p.kw * p.Cin;
+    float acc = 0.f;
+    for (int ky = 0; ky < p.kh; ++ky) {
+        int iy = oy * p.sh - p.ph + ky;
+        if ((unsigned)iy >= (unsigned)p.Hi) continue;
+        for (int kx = 0; kx < p.kw; ++kx) {
+            int ix = ox * p.sw - p.pw + kx;
+            if ((unsigned)ix >= (unsigned)p.Wi) continue;
+            long xo = (((long)b * p.Hi + iy) * p.Wi + ix) * p.ldx;
+            const bf16_t* wk = w + (ky * p.kw + kx) * p.Cin;
+            if (XF32) {
+                const float* x = (const float*)p.X + xo;
+                for (int c = 0; c < p.Cin; ++c) acc += x[c] * bf2f(wk[c]);
+            } else {
+                const bf16_t* x = (const bf16_t*)p.X + xo;
+                for (int c = 0; c < p.Cin; ++c) acc += bf2f(x[c]) * bf2f(wk[c]);
+            }
+        }
+    }
+    acc = cd_finish(p, acc, m, n, b);
+    if (p.y_f32) ((float*)p.Y)[m * p.ldy + n] = acc; else ((bf16_t*)p.Y)[m * p.ldy + n] = f2bf(acc);
+}
+
+// K-parallel variant for few output channels and long K (conv_out: Cout=4, K=2880):
+// one wave per output pixel, lanes stride over 16-byte chunks of (tap, ci), shuffle reduction.
+template <int NOUT>
+__global__ __launch_bounds__(256) void conv_direct_kpar_kernel(CDParams p) {
+    const int lane = threadIdx.x & 63;
+    long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    long M = (long)p.B * p.Ho * p.Wo;
+    if (m >= M) return;
+    int hw = p.Ho * p.Wo;
+    int b = (int)(m / hw);
+    int rem = (int)(m - (long)b * hw);
+    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int cpc = p.Cin / 8;                 // chunks per tap
+    const int nch = p.kh * p.kw * cpc;
+    const long K = (long)p.kh * p.kw * p.Cin;
+    float acc[NOUT];
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) acc[n] = 0.f;
+    for (int c = lane; c < nch; c += 64) {
+        int tap = c / cpc;
+        int ci = (c - tap * cpc) * 8;
+        int ky = tap / p.kw, kx = tap - ky * p.kw;
+        int iy = oy * p.sh - p.ph + ky, ix = ox * p.sw - p.pw + kx;
+        if ((unsigned)iy >= (unsigned)p.Hi || (unsigned)ix >= (unsigned)p.Wi) continue;
+        Frag8 xv;
+        xv.u = *(const uint4*)((const bf16_t*)p.X + (((long)b * p.Hi + iy) * p.Wi + ix) * p.ldx + ci);
+        float xf[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xf[e] = bf2f(xv.h[e]);
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) {
+            if (n < p.Cout) {
+                Frag8 wv;
+                wv.u = *(const uint4*)(p.W + (long)n * K + (long)tap * p.Cin + ci);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[n] += xf[e] * bf2f(wv.h[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) acc[n] = wave_sum(acc[n]);
+    if (lane < p.Cout && lane < NOUT) {
+        float a = 0.f;
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) if (n == lane) a = acc[n];
+        a = cd_finish(p, a, m, lane, b);
+        if (p.y_f32) ((float*)p.Y)[m * p.ldy + lane] = a; else ((bf16_t*)p.Y)[m * p.ldy + lane] = f2bf(a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// element-wise family
+// ------------------------------------------------------------------------------------------
+struct EWParams {
+    const void* X; void* Y; const int* ymap; const int* xmap;
+    int kind; long M; int C; long ldx, ldy;
+    int B, Hi, Wi, Ho, Wo, x_f32, y_f32; float alpha;
+};
+
+__device__ __forceinline__ float ew_load(const void* p, long i, int f32) {
+    return f32 ? ((const float*)p)[i] : bf2f(((const bf16_t*)p)[i]);
+}
+__device__ __forceinline__ void ew_store(void* p, long i, int f32, float v) {
+    if (f32) ((float*)p)[i] = v; else ((bf16_t*)p)[i] = f2bf(v);
+}
+
+// generic scalar path: one thread per element
+__global__ __launch_bounds__(256) void ew_scalar_kernel(EWParams p) {
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p.kind == MDX_EW_UPSAMPLE) {
+        long total = (long)p.B * p.Ho * p.Wo * p.C;
+        if (idx >= total) return;
+        int c = (int)(idx % p.C);
+        long pix = idx / p.C;
+        int ox = (int)(pix % p.Wo);
+        long t = pix / p.Wo;
+        int oy = (int)(t % p.Ho);
+        int b = (int)(t / p.Ho);
+        int iy = p.ymap[oy], ix = p.xmap[ox];
+        float v = ew_load(p.X, (((long)b * p.Hi + iy) * p.Wi + ix) * p.ldx + c, p.x_f32);
+        ew_store(p.Y, pix * p.ldy + c, p.y_f32, v);
+        return;
+    }
+    if (p.kind == MDX_EW_NCHW_TO_NHWC || p.kind == MDX_EW_NHWC_TO_NCHW) {
+        // X/Y indexed by (b, c, y, x); B,C,Hi,Wi describe the tensor
+        long total = (long)p.B * p.C * p.Hi * p.Wi;
+        if (idx >= total) return;
+        int x = (int)(idx % p.Wi);
+        long t = idx / p.Wi;
+        int y = (int)(t % p.Hi);
+        t /= p.Hi;
+        int c = (int)(t % p.C);
+        int b = (int)(t / p.C);
+        long nchw = idx;
+        long nhwc_pix = ((long)b * p.Hi + y) * p.Wi + x;
+        if (p.kind == MDX_EW_NCHW_TO_NHWC)
+            ew_store(p.Y, nhwc_pix * p.ldy + c, p.y_f32, ew_load(p.X, nchw, p.x_f32));
+        else
+            ew_store(p.Y, nchw, p.y_f32, ew_load(p.X, nhwc_pix * p.ldx + c, p.x_f32));
+        return;
+    }
+    long total = p.M * p.C;
+    if (idx >= total) return;
+    long m = idx / p.C;
+    int c = (int)(idx - m * p.C);
+    float x = ew_load(p.X, m * p.ldx + c, p.x_f32);
+    float r;
+    switch (p.kind) {
+        case MDX_EW_ADD: r = ew_load(p.Y, m * p.ldy + c, p.y_f32) + x; break;
+        case MDX_EW_COPY: r = x; break;
+        case MDX_EW_SILU: r = silu_f(x); break;
+        case MDX_EW_SCALE: r = x * p.alpha; break;
+        default: r = x; break;
+    }
+    ew_store(p.Y, m * p.ldy + c, p.y_f32, r);
+}
+
+// bf16 -> bf16 fast path, 8 channels per thread (ADD / COPY / SILU / SCALE)
+__global__ __launch_bounds__(256) void ew_vec8_kernel(EWParams p) {
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c8 = p.C / 8;
+    if (idx >= p.M * c8) return;
+    long m = idx / c8;
+    int c = (int)(idx - m * c8) * 8;
+    Frag8 x, y;
+    x.u = *(const uint4*)((const bf16_t*)p.X + m * p.ldx + c);
+    bf16_t* yp = (bf16_t*)p.Y + m * p.ldy + c;
+    if (p.kind == MDX_EW_ADD) y.u = *(const uint4*)yp;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float xv = bf2f(x.h[e]);
+        float r;
+        switch (p.kind) {
+            case MDX_EW_ADD: r = bf2f(y.h[e]) + xv; break;
+            case MDX_EW_SILU: r = silu_f(xv); break;
+            case MDX_EW_SCALE: r = xv * p.alpha; break;
+            default: r = xv; break;
+        }
+        y.h[e] = f2bf(r);
+    }
+    *(uint4*)yp = y.u;
+}
+
+// ------------------------------------------------------------------------------------------
+// Fourier embedding / gather / timestep features / CFG + DDIM
+// ------------------------------------------------------------------------------------------
+struct FourierParams { const float* X; bf16_t* Y; const uint8_t* mask; const float* null_feat; long n; int P, F; long ldy; };
+
+__global__ __launch_bounds__(256) void fourier_kernel(FourierParams p) {
+    const int per_pt = 3 + 6 * p.F;
+    const int width = p.P * per_pt;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.n * width) return;
+    long i = idx / width;
+    int j = (int)(idx - i * width);
+    float out;
+    if (p.mask && !p.mask[i]) {
+        out = p.null_feat ? p.null_feat[j] : 0.f;
+    } else {
+        int pt = j / per_pt;
+        int k = j - pt * per_pt;     // 0..per_pt-1 : [x(3) | sin f0 (3) | cos f0 (3) | sin f1 ...]
+        int comp = k % 3;
+        int fn = k / 3;              // 0 = identity, 1 = sin f0, 2 = cos f0, 3 = sin f1, ...
+        float x = p.X[(i * p.P + pt) * 3 + comp];
+        if (fn == 0) out = x;
+        else {
+            int fi = (fn - 1) >> 1;
+            float a = x * (float)(1 << fi);      // freq bands 2^0 .. 2^(F-1) (embedder.py:26-29)
+            out = ((fn - 1) & 1) ? cosf(a) : sinf(a);
+        }
+    }
+    p.Y[i * p.ldy + j] = f2bf(out);
+}
+
+struct GatherParams { const bf16_t* T; bf16_t* Y; const int64_t* idx; const uint8_t* mask; const bf16_t* null_row; long n; int C; long ldt, ldy; int n_rows; };
+
+__global__ __launch_bounds__(256) void gather_kernel(GatherParams p) {
+    long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= p.n * p.C) return;
+    long i = id / p.C;
+    int c = (int)(id - i * p.C);
+    bool m = p.mask ? p.mask[i] != 0 : true;
+    bf16_t v;
+    if (m) {
+        long r = p.idx[i];
+        if (r < 0) r += p.n_rows;                 // python-style negative index (bbox_embedder.py:179)
+        if (r < 0 || r >= p.n_rows) r = 0;
+        v = p.T[r * p.ldt + c];
+    } else {
+        v = p.null_row ? p.null_row[c] : (bf16_t)0;
+    }
+    p.Y[i * p.ldy + c] = v;
+}
+
+struct TimeEmbParams { const float* t; void* Y; long n; int dim, flip; long ldy; float shift, max_period; int y_f32; };
+
+__global__ __launch_bounds__(256) void timeemb_kernel(TimeEmbParams p) {
+    long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= p.n * p.dim) return;
+    long i = id / p.dim;
+    int j = (int)(id - i * p.dim);
+    const int half = p.dim / 2;
+    float out = 0.f;
+    if (j < 2 * half) {
+        int first = j < half;          // first half of the output
+        int k = first ? j : j - half;
+        // embeddings.py:47-61: exponent = -ln(max_period) * k / (half - shift); emb = t * exp(exponent)
+        float e = -logf(p.max_period) * (float)k / ((float)half - p.shift);
+        float a = p.t[i] * expf(e);
+        // unflipped layout is [sin | cos]; flip_sin_to_cos -> [cos | sin]
+        bool use_cos = p.flip ? first : !first;
+        out = use_cos ? cosf(a) : sinf(a);
+    }
+    if (p.y_f32) ((float*)p.Y)[i * p.ldy + j] = out; else ((bf16_t*)p.Y)[i * p.ldy + j] = f2bf(out);
+}
+
+struct DdimParams { float* x; const float* eps; const float* coef; int* step; float* x_in; long n; int cfg; float g; };
+
+__global__ __launch_bounds__(256) void ddim_kernel(DdimParams p) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int step = *p.step;
+    if (i < p.n) {
+        const float* c = p.coef + 4 * step;
+        float e;
+        if (p.cfg) {
+            float eu = p.eps[i], ec = p.eps[p.n + i];
+            e = eu + p.g * (ec - eu);
+        } else {
+            e = p.eps[i];
+        }
+        float x = p.x[i];
+        float x0 = (x - c[1] * e) / c[0];
+        float xn = c[2] * x0 + c[3] * e;
+        p.x[i] = xn;
+        if (p.x_in) {
+            p.x_in[i] = xn;
+            if (p.cfg) p.x_in[p.n + i] = xn;
+        }
+    }
+}
+// Separate 1-thread launch so every block of ddim_kernel has read *step before it changes.
+__global__ void step_inc_kernel(int* step) { *step += 1; }
+
+}  // namespace mdx
+
+using namespace mdx;
+
+extern "C" int mdx_conv2d_direct(const MdxConvDirectDesc* d, void* stream) {
+    if (!d || !d->X || !d->Wt || !d->Y) return set_error(MDX_EINVAL, "mdx_conv2d_direct: null operand");
+    if (d->epilogue == MDX_EPI_GEGLU) return set_error(MDX_EINVAL, "direct conv has no GEGLU epilogue");
+    CDParams p;
+    p.X = d->X; p.W = (const bf16_t*)d->Wt; p.Y = d->Y; p.R = d->R; p.bias = d->bias; p.temb = d->temb; p.sel = d->sel_ptr;
+    p.B = (int)d->B; p.Hi = (int)d->Hi; p.Wi = (int)d->Wi; p.Cin = (int)d->Cin; p.Ho = (int)d->Ho; p.Wo = (int)d->Wo; p.Cout = (int)d->Cout;
+    p.kh = (int)d->kh; p.kw = (int)d->kw; p.sh = (int)d->sh; p.sw = (int)d->sw; p.ph = (int)d->ph; p.pw = (int)d->pw;
+    p.ldx = d->ldx; p.ldy = d->ldy; p.ldr = d->ldr; p.temb_sel_stride = d->temb_sel_stride; p.temb_b_stride = d->temb_b_stride;
+    p.epi = (int)d->epilogue; p.x_f32 = (int)d->x_is_f32; p.y_f32 = (int)d->y_is_f32;
+    long M = (long)p.B * p.Ho * p.Wo;
+    if (M <= 0 || p.Cout <= 0) return MDX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool kpar = !p.x_f32 && p.Cout <= 8 && (p.Cin % 8) == 0 && (p.ldx % 8) == 0 && (long)p.kh * p.kw * p.Cin >= 512 &&
+                      ((uintptr_t)p.X & 15) == 0 && ((uintptr_t)p.W & 15) == 0;
+    if (kpar) {
+        dim3 grid((unsigned)((M + 3) / 4));
+        if (p.Cout <= 4) hipLaunchKernelGGL(conv_direct_kpar_kernel<4>, grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(conv_direct_kpar_kernel<8>, grid, dim3(256), 0, st, p);
+        return check_launch("conv_direct_kpar_kernel");
+    }
+    long total = M * p.Cout;
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (p.x_f32) hipLaunchKernelGGL(conv_direct_simple_kernel<true>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(conv_direct_simple_kernel<false>, grid, dim3(256), 0, st, p);
+    return check_launch("conv_direct_simple_kernel");
+}
+
+extern "C" int mdx_elementwise(const MdxEwDesc* d, void* stream) {
+    if (!d || !d->X || !d->Y) return set_error(MDX_EINVAL, "mdx_elementwise: null operand");
+    EWParams p;
+    p.X = d->X; p.Y = d->Y; p.ymap = d->ymap; p.xmap = d->xmap; p.kind = (int)d->kind; p.M = d->M; p.C = (int)d->C;
+    p.ldx = d->ldx; p.ldy = d->ldy; p.B = (int)d->B; p.Hi = (int)d->Hi; p.Wi = (int)d->Wi; p.Ho = (int)d->Ho; p.Wo = (int)d->Wo;
+    p.x_f32 = (int)d->x_is_f32; p.y_f32 = (int)d->y_is_f32; p.alpha = (float)d->alpha;
+    hipStream_t st = (hipStream_t)stream;
+    long total;
+    switch (p.kind) {
+        case MDX_EW_UPSAMPLE:
+            if (!p.ymap || !p.xmap) return set_error(MDX_EINVAL, "upsample needs ymap/xmap");
+            total = (long)p.B * p.Ho * p.Wo * p.C; break;
+        case MDX_EW_NCHW_TO_NHWC: case MDX_EW_NHWC_TO_NCHW:
+            total = (long)p.B * p.C * p.Hi * p.Wi; break;
+        case MDX_EW_ADD: case MDX_EW_COPY: case MDX_EW_SILU: case MDX_EW_SCALE:
+            total = p.M * p.C; break;
+        default: return set_error(MDX_EINVAL, "mdx_elementwise: unknown kind %d", p.kind);
+    }
+    if (total <= 0) return MDX_OK;
+    const bool flat = p.kind == MDX_EW_ADD || p.kind == MDX_EW_COPY || p.kind == MDX_EW_SILU || p.kind == MDX_EW_SCALE;
+    if (flat && !p.x_f32 && !p.y_f32 && p.C % 8 == 0 && p.ldx % 8 == 0 && p.ldy % 8 == 0 &&
+        ((uintptr_t)p.X & 15) == 0 && ((uintptr_t)p.Y & 15) == 0) {
+        long nv = p.M * (p.C / 8);
+        hipLaunchKernelGGL(ew_vec8_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, p);
+        return check_launch("ew_vec8_kernel");
+    }
+    hipLaunchKernelGGL(ew_scalar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    return check_launch("ew_scalar_kernel");
+}
+
+extern "C" int mdx_fourier_embed(const MdxFourierDesc* d, void* stream) {
+    if (!d || !d->X || !d->Y) return set_error(MDX_EINVAL, "mdx_fourier_embed: null operand");
+    if (d->F < 0 || d->F > 16) return set_error(MDX_EINVAL, "fourier: F out of range");
+    FourierParams p{d->X, (bf16_t*)d->Y, d->mask, d->null_feat, d->n, (int)d->P, (int)d->F, d->ldy};
+    long total = p.n * p.P * (3 + 6 * p.F);
+    if (total <= 0) return MDX_OK;
+    hipLaunchKernelGGL(fourier_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("fourier_kernel");
+}
+
+extern "C" int mdx_gather_rows(const MdxGatherDesc* d, void* stream) {
+    if (!d || !d->T || !d->Y || !d->idx) return set_error(MDX_EINVAL, "mdx_gather_rows: null operand");
+    GatherParams p{(const bf16_t*)d->T, (bf16_t*)d->Y, d->idx, d->mask, (const bf16_t*)d->null_row, d->n, (int)d->C, d->ldt, d->ldy, (int)d->n_rows};
+    long total = p.n * p.C;
+    if (total <= 0) return MDX_OK;
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("gather_kernel");
+}
+
+extern "C" int mdx_timestep_embedding(const MdxTimeEmbDesc* d, void* stream) {
+    if (!d || !d->t || !d->Y) return set_error(MDX_EINVAL, "mdx_timestep_embedding: null operand");
+    TimeEmbParams p{d->t, d->Y, d->n, (int)d->dim, (int)d->flip_sin_to_cos, d->ldy, (float)d->freq_shift, (float)d->max_period, 1};
+    long total = p.n * p.dim;
+    if (total <= 0) return MDX_OK;
+    hipLaunchKernelGGL(timeemb_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("timeemb_kernel");
+}
+
+extern "C" int mdx_cfg_ddim_step(const MdxDdimDesc* d, void* stream) {
+    if (!d || !d->x || !d->eps || !d->coef || !d->step_ptr) return set_error(MDX_EINVAL, "mdx_cfg_ddim_step: null operand");
+    DdimParams p{d->x, d->eps, d->coef, d->step_ptr, d->x_in, d->n, (int)d->cfg, (float)d->guidance};
+    if (p.n <= 0) return MDX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ddim_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
+    int rc = check_launch("ddim_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, p.step);
+    return check_launch("step_inc_kernel");
+}

@@ -1,0 +1,406 @@
+// gemm_conv.hip — bf16 MFMA GEMM and channels-last implicit-GEMM convolution for gfx950.
+//
+// One kernel template serves both: the only difference is how a row of the "A" operand is
+// addressed (a token row of a [M][K] matrix, or the (ky,kx,ci) gather of an output pixel's
+// receptive field in a [B][Hi][Wi][Cin] feature map — no im2col buffer ever exists in HBM).
+//
+//   C[m][n] = epi( sum_k A[m][k] * W[n][k] + bias[n] + temb[row(m)][n] ) + R[m][n]
+//
+// Tiling: 256 threads = 4 waves (2 x 2), block tile BM x BN x 64, each wave (BM/2) x (BN/2) out
+// of 32x32x16 bf16 MFMAs with fp32 accumulation.  Operands are staged global -> registers -> LDS
+// (double-buffered; the next tile's global loads are in flight while the current tile is
+// multiplied) with 16-byte vector accesses; LDS rows are padded by 16 B so the ds_read_b128
+// fragment reads of a 16-lane group hit 16 distinct 16-byte slots (conflict-free).
+// The MFMA is issued as D = Wfrag x Afrag so a lane ends up holding 4 CONSECUTIVE n for one m:
+// the epilogue does 8-byte bf16x4 stores and float4 bias loads instead of 2-byte scatters.
+//
+// Small-M / huge-K shapes (the 7x13 and 4x7 UNet levels: M = 546, 168 rows, K up to 23040)
+// are split along K across blockIdx.z into fp32 slabs and reduced by splitk_reduce_kernel,
+// which applies the same epilogue.  Slabs (not atomics) keep results run-to-run deterministic.
+//
+// Reference semantics replaced: ATen conv2d/addmm call sites listed in include/mdx.h.
+#include "common.h"
+#include "launch.h"
+
+namespace mdx {
+
+struct GCParams {
+    const bf16_t* A; const bf16_t* W; void* C; const void* R;
+    const float* bias; const float* temb; const int* sel; float* ws;
+    int M, N, K;
+    long lda, ldw, ldc, ldr;
+    long sA, sW, sC, sR;
+    long temb_sel_stride, temb_b_stride;
+    int rows_per_b;
+    int epi, splitk, kchunk, c_f32, batch;
+    long ws_bytes;
+    // conv geometry (CONV only); lda doubles as the pixel stride of X
+    int Hi, Wi, Cin, Ho, Wo, kh, kw, sh, sw, ph, pw;
+};
+
+constexpr int BK = 64;
+constexpr int LSTR = BK + 8;  // LDS row stride in elements (144 B)
+
+// ---- shared epilogue ---------------------------------------------------------------
+// v[4] are raw accumulators for output row m, raw columns nb..nb+3 (nb % 4 == 0).
+// For GEGLU, v = value columns and gte = gate columns (raw column nb+32+j).
+__device__ __forceinline__ void epilogue_store(const GCParams& p, long zb, int m, int nb,
+                                               const float* v, const float* gte) {
+    float o[4];
+    int ncol;  // output column of o[0]
+    const float* tb = nullptr;
+    if (p.temb) {
+        int sel = p.sel ? *p.sel : 0;
+        tb = p.temb + (long)sel * p.temb_sel_stride + (long)(m / p.rows_per_b) * p.temb_b_stride;
+    }
+    if (p.epi == 1) {  // GEGLU
+        ncol = (nb >> 6) * 32 + (nb & 63);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float h = v[j], g = gte[j];
+            if (p.bias) { h += p.bias[nb + j]; g += p.bias[nb + 32 + j]; }
+            o[j] = h * gelu_erf_f(g);
+        }
+    } else {
+        ncol = nb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = v[j];
+            if (p.bias) x += p.bias[nb + j];
+            if (tb) x += tb[nb + j];
+            if (p.epi == 2) x = silu_f(x);
+            o[j] = x;
+        }
+    }
+    if (p.c_f32) {
+        float* c = (float*)p.C + zb * p.sC + (long)m * p.ldc + ncol;
+        if (p.R) {
+            const float* r = (const float*)p.R + zb * p.sR + (long)m * p.ldr + ncol;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += r[j];
+        }
+        *(float4*)c = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+        bf16_t* c = (bf16_t*)p.C + zb * p.sC + (long)m * p.ldc + ncol;
+        if (p.R) {
+            const bf16_t* r = (const bf16_t*)p.R + zb * p.sR + (long)m * p.ldr + ncol;
+            uint2 rv = *(const uint2*)r;
+            o[0] += bf2f((bf16_t)(rv.x & 0xffff)); o[1] += bf2f((bf16_t)(rv.x >> 16));
+            o[2] += bf2f((bf16_t)(rv.y & 0xffff)); o[3] += bf2f((bf16_t)(rv.y >> 16));
+        }
+        uint2 ov; ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]);
+        *(uint2*)c = ov;
+    }
+}
+
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256) void gemm_conv_kernel(GCParams p) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int A_CH = BM * BK / 8 / 256;
+    constexpr int B_CH = BN * BK / 8 / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* As = (bf16_t*)smem;              // [2][BM][LSTR]
+    bf16_t* Bs = As + 2 * BM * LSTR;         // [2][BN][LSTR]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    long zb = 0;       // batch index
+    int kz = 0;        // split-K slice
+    if (p.batch > 1) zb = blockIdx.z; else kz = blockIdx.z;
+    const int kbeg = kz * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nt = (kend - kbeg + BK - 1) / BK;
+
+    const int kc = tid & 7;       // 16-byte chunk within the 64-wide k slab
+    const int rbase = tid >> 3;   // 0..31
+
+    // ---- per-thread row bookkeeping (fixed over the K loop) ----
+    const bf16_t* a_ptr[A_CH];
+    bool a_ok[A_CH];
+    int a_iy0[A_CH], a_ix0[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        int m = m0 + rbase + 32 * i;
+        a_ok[i] = m < p.M;
+        if (CONV) {
+            int mm = a_ok[i] ? m : 0;
+            int hw = p.Ho * p.Wo;
+            int b = mm / hw;
+            int rem = mm - b * hw;
+            int oy = rem / p.Wo;
+            int ox = rem - oy * p.Wo;
+            a_iy0[i] = oy * p.sh - p.ph;
+            a_ix0[i] = ox * p.sw - p.pw;
+            a_ptr[i] = p.A + (long)b * p.Hi * p.Wi * p.lda;
+        } else {
+            a_iy0[i] = 0; a_ix0[i] = 0;
+            a_ptr[i] = p.A + zb * p.sA + (long)(a_ok[i] ? m : 0) * p.lda;
+        }
+    }
+    const bf16_t* b_ptr[B_CH];
+    bool b_ok[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        int n = n0 + rbase + 32 * i;
+        b_ok[i] = n < p.N;
+        b_ptr[i] = p.W + zb * p.sW + (long)(b_ok[i] ? n : 0) * p.ldw;
+    }
+    // conv tap tracking for this thread's k chunk
+    int ky = 0, kx = 0, ci = 0;
+    if (CONV) {
+        int kk = kbeg + kc * 8;
+        int tap = kk / p.Cin;
+        ci = kk - tap * p.Cin;
+        ky = tap / p.kw;
+        kx = tap - ky * p.kw;
+    }
+
+    uint4 a_reg[A_CH], b_reg[B_CH];
+    auto load_tile = [&](int t) {
+        const int kk = kbeg + t * BK + kc * 8;
+        const bool kok = kk < kend;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (a_ok[i] && kok) {
+                if (CONV) {
+                    int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+                    if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+                        v = *(const uint4*)(a_ptr[i] + ((long)iy * p.Wi + ix) * p.lda + ci);
+                } else {
+                    v = *(const uint4*)(a_ptr[i] + kk);
+                }
+            }
+            a_reg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (b_ok[i] && kok) v = *(const uint4*)(b_ptr[i] + kk);
+            b_reg[i] = v;
+        }
+        if (CONV) {  // advance the tap cursor by one K slab
+            ci += BK;
+            while (ci >= p.Cin) {
+                ci -= p.Cin;
+                if (++kx == p.kw) { kx = 0; ++ky; }
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        bf16_t* as = As + buf * BM * LSTR;
+        bf16_t* bs = Bs + buf * BN * LSTR;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i)
+            *(uint4*)(as + (rbase + 32 * i) * LSTR + kc * 8) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i)
+            *(uint4*)(bs + (rbase + 32 * i) * LSTR + kc * 8) = b_reg[i];
+    };
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nt > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    const int frow = lane & 31;
+    const int fk = (lane >> 5) * 8;
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) load_tile(t + 1);
+        const bf16_t* as = As + buf * BM * LSTR + (wm * TM * 32 + frow) * LSTR + fk;
+        const bf16_t* bs = Bs + buf * BN * LSTR + (wn * TN * 32 + frow) * LSTR + fk;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            Frag8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i].u = *(const uint4*)(as + i * 32 * LSTR + ks * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j].u = *(const uint4*)(bs + j * 32 * LSTR + ks * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j].v, af[i].v, acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds m = column (lane&31), n rows 8g + 4*(lane>>5) + (0..3) ----
+    const int half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * TM * 32 + i * 32 + frow;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nb = n0 + wn * TN * 32 + j * 32 + 8 * g + 4 * half;
+                if (nb >= p.N) continue;
+                float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                if (p.splitk > 1) {
+                    float* w = p.ws + ((long)kz * p.M + m) * p.N + nb;
+                    *(float4*)w = make_float4(v[0], v[1], v[2], v[3]);
+                } else if (p.epi == 1) {
+                    if (TN == 2 && j == 0) {
+                        float gte[4] = {acc[i][TN - 1][4 * g], acc[i][TN - 1][4 * g + 1],
+                                        acc[i][TN - 1][4 * g + 2], acc[i][TN - 1][4 * g + 3]};
+                        epilogue_store(p, zb, m, nb, v, gte);
+                    }
+                } else {
+                    epilogue_store(p, zb, m, nb, v, nullptr);
+                }
+            }
+        }
+    }
+}
+
+// Sum the split-K slabs and apply the epilogue.  One thread per (m, 4 raw columns).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GCParams p) {
+    const int n4 = p.N / 4;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)p.M * n4) return;
+    int m = (int)(idx / n4);
+    int nb = (int)(idx - (long)m * n4) * 4;
+    if (p.epi == 1 && (nb & 63) >= 32) return;  // gate columns are consumed by their value thread
+    float v[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0};
+    for (int z = 0; z < p.splitk; ++z) {
+        const float* w = p.ws + ((long)z * p.M + m) * p.N + nb;
+        float4 a = *(const float4*)w;
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+        if (p.epi == 1) {
+            float4 b = *(const float4*)(w + 32);
+            g[0] += b.x; g[1] += b.y; g[2] += b.z; g[3] += b.w;
+        }
+    }
+    epilogue_store(p, 0, m, nb, v, g);
+}
+
+template <int BM, int BN, bool CONV>
+static int launch_one(const GCParams& p, hipStream_t st) {
+    constexpr size_t smem = (size_t)2 * (BM + BN) * LSTR * sizeof(bf16_t);
+    static bool attr_done = false;
+    auto kern = gemm_conv_kernel<BM, BN, CONV>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return set_error(MDX_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, p.batch > 1 ? p.batch : p.splitk);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+    return check_launch("gemm_conv_kernel");
+}
+
+// Tile / split-K choice.  The chip has 256 CUs; a launch wants >= ~2 blocks per CU.
+int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MDX_OK;
+    const bool geglu = p.epi == 1;
+    int BN = 128;
+    if (!geglu && (p.N <= 64 || (p.N % 128 != 0 && p.N <= 320))) BN = 64;
+    int BM = p.M >= 2048 ? 128 : 64;
+    if (geglu && (p.N % 64) != 0) return set_error(MDX_EINVAL, "GEGLU needs packed N %% 64 == 0 (N=%d)", p.N);
+    long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.batch > 1 ? p.batch : 1);
+    int splitk = 1;
+    if (p.splitk > 0) {
+        splitk = p.splitk;  // caller forced
+    } else if (p.batch <= 1 && p.ws && tiles < 384 && p.K >= 1024) {
+        long want = (768 + tiles - 1) / tiles;
+        long maxs = p.K / 512;  // keep >= 8 K-slabs per slice
+        splitk = (int)min(min(want, maxs), 32L);
+        if (splitk < 1) splitk = 1;
+    }
+    if (p.batch > 1) splitk = 1;
+    if (splitk > 1) {  // fit the fp32 slabs into the caller's workspace
+        long per = (long)p.M * p.N * (long)sizeof(float);
+        long fit = per > 0 ? p.ws_bytes / per : 0;
+        if (fit < splitk) splitk = fit < 1 ? 1 : (int)fit;
+    }
+    int kchunk = ((p.K + splitk - 1) / splitk + BK - 1) / BK * BK;
+    splitk = (p.K + kchunk - 1) / kchunk;
+    if (splitk > 1 && !p.ws) return set_error(MDX_EINVAL, "split-K needs a workspace");
+    p.splitk = splitk;
+    p.kchunk = kchunk;
+    int rc;
+#define MDX_GC(BM_, BN_)                                                               \
+    (conv ? launch_one<BM_, BN_, true>(p, st) : launch_one<BM_, BN_, false>(p, st))
+    if (BM == 128 && BN == 128) rc = MDX_GC(128, 128);
+    else if (BM == 128 && BN == 64) rc = MDX_GC(128, 64);
+    else if (BM == 64 && BN == 128) rc = MDX_GC(64, 128);
+    else rc = MDX_GC(64, 64);
+#undef MDX_GC
+    if (rc != MDX_OK) return rc;
+    if (splitk > 1) {
+        long n = (long)p.M * (p.N / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+        return check_launch("splitk_reduce_kernel");
+    }
+    return MDX_OK;
+}
+
+}  // namespace mdx
+
+using namespace mdx;
+
+static int check_common(int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_t ldr, const void* A, const void* W,
+                        const void* C, int64_t N) {
+    if (K % 8) return set_error(MDX_EINVAL, "K=%ld must be a multiple of 8", (long)K);
+    if ((lda % 8) || (ldw % 8)) return set_error(MDX_EINVAL, "lda/ldw must be multiples of 8");
+    if ((ldc % 4) || (ldr % 4)) return set_error(MDX_EINVAL, "ldc/ldr must be multiples of 4");
+    if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7))
+        return set_error(MDX_EINVAL, "operand pointers must be 16-byte (A, W) / 8-byte (C) aligned");
+    if (N % 4) return set_error(MDX_EINVAL, "N=%ld must be a multiple of 4", (long)N);
+    return MDX_OK;
+}
+
+extern "C" int mdx_gemm_bf16(const MdxGemmDesc* d, void* stream) {
+    if (!d || !d->A || !d->W || !d->C) return set_error(MDX_EINVAL, "mdx_gemm_bf16: null operand");
+    int rc = check_common(d->K, d->lda, d->ldw, d->ldc, d->ldr, d->A, d->W, d->C, d->N);
+    if (rc) return rc;
+    GCParams p = {};
+    p.A = (const bf16_t*)d->A; p.W = (const bf16_t*)d->W; p.C = d->C; p.R = d->R;
+    p.bias = d->bias; p.temb = d->temb; p.sel = d->sel_ptr; p.ws = d->ws;
+    p.M = (int)d->M; p.N = (int)d->N; p.K = (int)d->K;
+    p.lda = d->lda; p.ldw = d->ldw; p.ldc = d->ldc; p.ldr = d->ldr;
+    p.batch = d->batch > 1 ? (int)d->batch : 1;
+    p.sA = d->sA; p.sW = d->sW; p.sC = d->sC; p.sR = d->sR;
+    p.temb_sel_stride = d->temb_sel_stride; p.temb_b_stride = d->temb_b_stride;
+    p.rows_per_b = d->rows_per_b > 0 ? (int)d->rows_per_b : 1;
+    p.epi = (int)d->epilogue; p.splitk = (int)d->splitk; p.c_f32 = (int)d->c_is_f32; p.ws_bytes = d->ws_bytes;
+    return launch_gemm_conv(p, false, (hipStream_t)stream);
+}
+
+extern "C" int mdx_conv2d_bf16(const MdxConvDesc* d, void* stream) {
+    if (!d || !d->X || !d->Wt || !d->Y) return set_error(MDX_EINVAL, "mdx_conv2d_bf16: null operand");
+    if (d->Cin % 8) return set_error(MDX_EINVAL, "mdx_conv2d_bf16: Cin=%ld must be a multiple of 8", (long)d->Cin);
+    int64_t K = d->kh * d->kw * d->Cin;
+    int rc = check_common(K, d->ldx, K, d->ldy, d->ldr, d->X, d->Wt, d->Y, d->Cout);
+    if (rc) return rc;
+    if (d->epilogue == MDX_EPI_GEGLU) return set_error(MDX_EINVAL, "conv has no GEGLU epilogue");
+    GCParams p = {};
+    p.A = (const bf16_t*)d->X; p.W = (const bf16_t*)d->Wt; p.C = d->Y; p.R = d->R;
+    p.bias = d->bias; p.temb = d->temb; p.sel = d->sel_ptr; p.ws = d->ws;
+    p.M = (int)(d->B * d->Ho * d->Wo); p.N = (int)d->Cout; p.K = (int)K;
+    p.lda = d->ldx; p.ldw = K; p.ldc = d->ldy; p.ldr = d->ldr;
+    p.batch = 1;
+    p.temb_sel_stride = d->temb_sel_stride; p.temb_b_stride = d->temb_b_stride;
+    p.rows_per_b = (int)(d->Ho * d->Wo);
+    p.epi = (int)d->epilogue; p.splitk = (int)d->splitk; p.c_f32 = 0; p.ws_bytes = d->ws_bytes;
+    p.Hi = (int)d->Hi; p.Wi = (int)d->Wi; p.Cin = (int)d->Cin; p.Ho = (int)d->Ho; p.Wo = (int)d->Wo;
+    p.kh = (int)d->kh; p.kw = (int)d->kw; p.sh = (int)d->sh; p.sw = (int)d->sw; p.ph = (int)d->ph; p.pw = (int)d->pw;
+    return launch_gemm_conv(p, true, (hipStream_t)stream);
+}

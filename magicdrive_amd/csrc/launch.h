@@ -1,0 +1,27 @@
+// launch.h — host-side helpers: error reporting and launch checks for libmdx.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include "../../include/mdx.h"
+
+namespace mdx {
+
+char* error_buffer();  // thread-local, 512 bytes (api.hip)
+
+inline int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// Launch errors (bad configuration) surface through hipGetLastError without a sync.
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(MDX_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return MDX_OK;
+}
+
+}  // namespace mdx

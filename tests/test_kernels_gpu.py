@@ -1,0 +1,385 @@
+"""-m gpu: every HIP kernel behind the C-ABI vs a plain PyTorch fp32 reference of the same op.
+
+Inputs are bf16-rounded first so the comparison isolates the kernel's own arithmetic
+(fp32 accumulate, one bf16 rounding on store).  Tolerances follow xformers' bf16 table
+(third_party/xformers/xformers/ops/fmha/common.py:209-219): atol 2e-2, rtol 5e-3 at unit scale;
+we scale atol by the output magnitude.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from magicdrive_amd import _lib as L
+from magicdrive_amd import ops as O
+from magicdrive_amd import packing as PK
+
+BF = torch.bfloat16
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=BF, dev="cuda"):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev)
+
+
+def close(out, ref, rtol=1e-2, atol_rel=1e-2, name=""):
+    out = out.float().cpu()
+    ref = ref.float().cpu()
+    assert out.shape == ref.shape, (name, out.shape, ref.shape)
+    assert torch.isfinite(out).all(), name
+    scale = ref.abs().mean().item() + 1e-6
+    err = (out - ref).abs()
+    tol = atol_rel * scale + rtol * ref.abs()
+    bad = (err > tol).float().mean().item()
+    rel = (err.pow(2).sum().sqrt() / (ref.pow(2).sum().sqrt() + 1e-12)).item()
+    assert bad < 1e-3 and rel < 1e-2, f"{name}: frac_bad={bad:.2e} rel_l2={rel:.3e} max_err={err.max().item():.3e} scale={scale:.3e}"
+
+
+def ws_buf(dev, mb=64):
+    return torch.empty(mb * 1024 * 1024 // 4, dtype=torch.float32, device=dev)
+
+
+@pytest.mark.parametrize("M,N,K,bias,res,f32out", [
+    (8400, 320, 320, True, True, False),
+    (2100, 640, 2560, True, False, False),
+    (546, 1280, 1280, False, True, False),
+    (168, 1280, 5120, True, True, False),     # auto split-K
+    (50, 1280, 320, True, False, True),       # fp32 output, tiny M
+    (777, 96, 136, True, False, False),       # ragged everything, BN=64
+    (130, 20, 8, False, False, False),
+])
+def test_gemm(dev, M, N, K, bias, res, f32out):
+    A = rnd(M, K, seed=1); W = rnd(N, K, scale=K ** -0.5, seed=2)
+    b = rnd(N, seed=3, dtype=torch.float32) if bias else None
+    R = rnd(M, N, seed=4, dtype=torch.float32 if f32out else BF) if res else None
+    C = torch.full((M, N), float("nan"), dtype=torch.float32 if f32out else BF, device=dev)
+    O.run_ops([O.Gemm(A, W, C, bias=b, R=R, ws=ws_buf(dev))])
+    torch.cuda.synchronize()
+    ref = A.float().cpu() @ W.float().cpu().T
+    if bias: ref += b.cpu()
+    if res: ref += R.float().cpu()
+    close(C, ref, name=f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_forced_splitk_matches(dev):
+    M, N, K = 546, 640, 5760
+    A = rnd(M, K, seed=1); W = rnd(N, K, scale=K ** -0.5, seed=2); b = rnd(N, seed=3, dtype=torch.float32)
+    C1 = torch.zeros(M, N, dtype=BF, device=dev); C2 = torch.zeros_like(C1)
+    O.run_ops([O.Gemm(A, W, C1, bias=b, splitk=1), O.Gemm(A, W, C2, bias=b, splitk=6, ws=ws_buf(dev))])
+    torch.cuda.synchronize()
+    ref = A.float().cpu() @ W.float().cpu().T + b.cpu()
+    close(C1, ref, name="splitk=1"); close(C2, ref, name="splitk=6")
+
+
+def test_gemm_strided_views_and_temb(dev):
+    # A and C are column slices of wider buffers; temb row chosen by a device-side selector
+    M, N, K = 2 * 350, 640, 320
+    Abig = rnd(M, 2 * K, seed=5); Cbig = torch.zeros(M, 3 * N, dtype=BF, device=dev)
+    W = rnd(N, K, scale=K ** -0.5, seed=6)
+    temb = rnd(5, 2, N, seed=7, dtype=torch.float32)      # [sel][b][N]
+    sel = torch.tensor([3], dtype=torch.int32, device=dev)
+    A = Abig[:, K:]; C = Cbig[:, N:2 * N]
+    O.run_ops([O.Gemm(A, W, C, temb=temb, sel=sel, temb_sel_stride=2 * N, temb_b_stride=N, rows_per_b=350)])
+    torch.cuda.synchronize()
+    ref = A.float().cpu() @ W.float().cpu().T + temb[3].cpu().repeat_interleave(350, 0)
+    close(C, ref, name="gemm strided+temb")
+    assert Cbig[:, :N].abs().max().item() == 0 and Cbig[:, 2 * N:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("M,F_,K", [(2100, 2560, 640), (8400, 1280, 320), (546, 5120, 1280), (100, 128, 32)])
+def test_gemm_geglu(dev, M, F_, K):
+    A = rnd(M, K, seed=1); W = rnd(2 * F_, K, scale=K ** -0.5, seed=2, dtype=torch.float32, dev="cpu")
+    b = rnd(2 * F_, seed=3, dtype=torch.float32, dev="cpu")
+    Wp, bp = PK.pack_geglu(W, b)
+    C = torch.zeros(M, F_, dtype=BF, device=dev)
+    O.run_ops([O.Gemm(A, Wp.to(dev), C, bias=bp.to(dev), epilogue=L.EPI_GEGLU, ws=ws_buf(dev))])
+    torch.cuda.synchronize()
+    proj = A.float().cpu() @ W.to(BF).float().T + b
+    h, g = proj.chunk(2, dim=-1)
+    close(C, h * F.gelu(g), name="geglu")
+
+
+@pytest.mark.parametrize("Bt,T,Cc", [(6, 1400, 320), (6, 350, 640), (3, 91, 1280), (2, 28, 64)])
+def test_gemm_batched_vt(dev, Bt, T, Cc):
+    # V^T[b] = Wv @ X[b]^T into a kv-padded buffer
+    ldv = PK.round_up(T, 8)
+    X = rnd(Bt, T, Cc, seed=1); Wv = rnd(Cc, Cc, scale=Cc ** -0.5, seed=2)
+    Vt = torch.zeros(Bt, Cc, ldv, dtype=BF, device=dev)
+    O.run_ops([O.Gemm(Wv, X, Vt[:, :, :T])])
+    torch.cuda.synchronize()
+    ref = torch.einsum("ck,btk->bct", Wv.float().cpu(), X.float().cpu())
+    close(Vt[:, :, :T], ref, name="batched V^T")
+    assert Vt[:, :, T:].abs().max().item() == 0 if ldv > T else True
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad,res,temb", [
+    (2, 28, 50, 320, 320, 3, (1, 1), (1, 1), True, True),
+    (2, 28, 50, 320, 320, 3, (2, 2), (1, 1), False, False),
+    (6, 4, 7, 1280, 1280, 3, (1, 1), (1, 1), True, True),        # split-K regime
+    (3, 7, 13, 2560, 1280, 3, (1, 1), (1, 1), False, True),
+    (1, 40, 40, 8, 16, 3, (1, 1), (1, 1), False, False),
+    (1, 41, 40, 16, 32, 3, (2, 2), (2, 1), False, False),        # map-encoder style asymmetric pad
+    (1, 22, 20, 96, 256, 3, (2, 1), (2, 1), False, False),
+    (2, 14, 25, 640, 640, 1, (1, 1), (0, 0), True, False),       # 1x1
+])
+def test_conv_mfma(dev, B, H, W, Cin, Cout, k, stride, pad, res, temb):
+    x = rnd(B, H, W, Cin, seed=1)
+    w = rnd(Cout, Cin, k, k, scale=(Cin * k * k) ** -0.5, seed=2, dtype=torch.float32, dev="cpu")
+    b = rnd(Cout, seed=3, dtype=torch.float32)
+    Ho = (H + 2 * pad[0] - k) // stride[0] + 1; Wo = (W + 2 * pad[1] - k) // stride[1] + 1
+    y = torch.zeros(B, Ho, Wo, Cout, dtype=BF, device=dev)
+    R = rnd(B, Ho, Wo, Cout, seed=4) if res else None
+    tb = rnd(B, Cout, seed=5, dtype=torch.float32) if temb else None
+    O.run_ops([O.Conv(x, PK.pack_conv_weight(w).to(dev), y, bias=b, R=R, temb=tb, temb_b_stride=Cout if temb else 0,
+                      stride=stride, pad=pad, ws=ws_buf(dev))])
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.to(BF).float(), b.cpu(), stride=stride, padding=pad)
+    if temb: ref += tb.cpu()[:, :, None, None]
+    ref = ref.permute(0, 2, 3, 1)
+    if res: ref = ref + R.float().cpu()
+    close(y, ref, name="conv")
+
+
+def test_conv_silu_epilogue(dev):
+    x = rnd(1, 20, 20, 16, seed=1)
+    w = rnd(16, 16, 3, 3, scale=0.1, seed=2, dtype=torch.float32, dev="cpu"); b = rnd(16, seed=3, dtype=torch.float32)
+    y = torch.zeros(1, 20, 20, 16, dtype=BF, device=dev)
+    O.run_ops([O.Conv(x, PK.pack_conv_weight(w).to(dev), y, bias=b, epilogue=L.EPI_SILU)])
+    torch.cuda.synchronize()
+    ref = F.silu(F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.to(BF).float(), b.cpu(), padding=1)).permute(0, 2, 3, 1)
+    close(y, ref, name="conv+silu")
+
+
+@pytest.mark.parametrize("case", ["conv_in", "conv_out", "linear189", "map_in"])
+def test_conv_direct(dev, case):
+    if case == "conv_in":
+        B, H, W, Cin, Cout, k, xf, yf = 2, 28, 50, 4, 320, 3, True, False
+    elif case == "conv_out":
+        B, H, W, Cin, Cout, k, xf, yf = 2, 28, 50, 320, 4, 3, False, True
+    elif case == "linear189":
+        B, H, W, Cin, Cout, k, xf, yf = 12, 1, 1, 189, 768, 1, False, False
+    else:
+        B, H, W, Cin, Cout, k, xf, yf = 1, 30, 30, 8, 16, 3, False, False
+    x = rnd(B, H, W, Cin, seed=1, dtype=torch.float32 if xf else BF)
+    w = rnd(Cout, Cin, k, k, scale=(Cin * k * k) ** -0.5, seed=2, dtype=torch.float32, dev="cpu"); b = rnd(Cout, seed=3, dtype=torch.float32)
+    y = torch.zeros(B, H, W, Cout, dtype=torch.float32 if yf else BF, device=dev)
+    pad = (k // 2, k // 2)
+    O.run_ops([O.Conv(x, PK.pack_conv_weight(w).to(dev), y, bias=b, pad=pad, direct=True)])
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.to(BF).float(), b.cpu(), padding=pad).permute(0, 2, 3, 1)
+    close(y, ref, name=case)
+
+
+def ref_attention(q, k, v, heads, scale):
+    # xformers tests/test_mem_eff_attention.py:214-264 semantics (BMHK), fp32
+    B, Tq, Cc = q.shape
+    d = Cc // heads
+    qh = q.view(B, Tq, heads, d).transpose(1, 2)
+    kh = k.view(k.shape[0], -1, heads, d).transpose(1, 2)
+    vh = v.view(v.shape[0], -1, heads, d).transpose(1, 2)
+    att = (qh @ kh.transpose(-1, -2) * scale).softmax(-1)
+    return (att @ vh).transpose(1, 2).reshape(B, Tq, Cc)
+
+
+@pytest.mark.parametrize("B,heads,Tq,Tk,d", [
+    (6, 8, 1400, 1400, 40), (6, 8, 350, 350, 80), (6, 8, 91, 91, 160), (6, 8, 28, 28, 160),
+    (6, 8, 1400, 110, 40), (6, 8, 350, 78, 80), (3, 8, 91, 110, 160),
+    (2, 2, 100, 70, 16), (2, 4, 65, 33, 8), (1, 2, 64, 64, 32), (1, 1, 130, 200, 64), (1, 1, 40, 129, 96), (1, 1, 33, 65, 128),
+])
+def test_attention(dev, B, heads, Tq, Tk, d):
+    Cc = heads * d
+    q = rnd(B, Tq, Cc, seed=1); k = rnd(B, Tk, Cc, seed=2); v = rnd(B, Tk, Cc, seed=3)
+    ldv = PK.round_up(Tk, 8)
+    vt = torch.full((B, Cc, ldv), float("nan"), dtype=BF, device=dev)   # garbage in the kv pad must not leak
+    vt[:, :, :Tk] = v.transpose(1, 2)
+    o = torch.zeros(B, Tq, Cc, dtype=BF, device=dev)
+    scale = d ** -0.5
+    O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=Tk, scale=scale)])
+    torch.cuda.synchronize()
+    ref = ref_attention(q.float().cpu(), k.float().cpu(), v.float().cpu(), heads, scale)
+    close(o, ref, rtol=2e-2, atol_rel=2e-2, name=f"attn {B},{heads},{Tq},{Tk},{d}")
+
+
+def test_attention_strided_qk_buffer(dev):
+    # Q and K are the two halves of one fused projection buffer [B, T, 2C]
+    B, heads, T, d = 2, 8, 350, 80
+    Cc = heads * d
+    qk = rnd(B, T, 2 * Cc, seed=1); v = rnd(B, T, Cc, seed=3)
+    vt = torch.zeros(B, Cc, PK.round_up(T, 8), dtype=BF, device=dev); vt[:, :, :T] = v.transpose(1, 2)
+    o = torch.zeros(B, T, Cc, dtype=BF, device=dev)
+    O.run_ops([O.Attn(qk[:, :, :Cc], qk[:, :, Cc:], vt, o, heads=heads, Tk=T, scale=d ** -0.5)])
+    torch.cuda.synchronize()
+    ref = ref_attention(qk[:, :, :Cc].float().cpu(), qk[:, :, Cc:].float().cpu(), v.float().cpu(), heads, d ** -0.5)
+    close(o, ref, rtol=2e-2, atol_rel=2e-2, name="attn strided")
+
+
+def test_attention_softmax_rescale_branch(dev):
+    # §5.4 rule 26: force the running max to jump in a late kv tile
+    B, heads, Tq, Tk, d = 1, 1, 64, 320, 64
+    q = rnd(B, Tq, d, seed=1); k = rnd(B, Tk, d, seed=2); v = rnd(B, Tk, d, seed=3)
+    k[0, 250] = q[0, 5] * 6.0      # spike for query 5 in the 4th tile
+    k[0, 10] = q[0, 9] * 6.0       # and an early one that later tiles must not disturb
+    vt = torch.zeros(B, d, Tk, dtype=BF, device=dev); vt[:] = v.transpose(1, 2)
+    o = torch.zeros(B, Tq, d, dtype=BF, device=dev)
+    O.run_ops([O.Attn(q, k, vt, o, heads=1, Tk=Tk, scale=d ** -0.5)])
+    torch.cuda.synchronize()
+    ref = ref_attention(q.double().cpu(), k.double().cpu(), v.double().cpu(), 1, d ** -0.5)
+    close(o, ref, rtol=2e-2, atol_rel=2e-2, name="attn rescale")
+
+
+@pytest.mark.parametrize("b,heads,T,d", [(1, 8, 1400, 40), (2, 8, 350, 80), (2, 8, 91, 160), (1, 2, 50, 16)])
+def test_attention_crossview_two_sources(dev, b, heads, T, d):
+    # blocks.py:106-222 'add' mode: view i attends to its left and right neighbour separately; outputs summed
+    ncam = 6
+    pair = {0: [5, 1], 1: [0, 2], 2: [1, 3], 3: [2, 4], 4: [3, 5], 5: [4, 0]}
+    Cc = heads * d; B = b * ncam
+    q = rnd(B, T, Cc, seed=1); k = rnd(B, T, Cc, seed=2); v = rnd(B, T, Cc, seed=3)
+    vt = torch.zeros(B, Cc, PK.round_up(T, 8), dtype=BF, device=dev); vt[:, :, :T] = v.transpose(1, 2)
+    kvmap = torch.tensor([(i // ncam) * ncam + pair[i % ncam][s] for i in range(B) for s in range(2)], dtype=torch.int32, device=dev)
+    o = torch.zeros(B, T, Cc, dtype=BF, device=dev)
+    O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=T, scale=d ** -0.5, kvmap=kvmap, nsrc=2)])
+    torch.cuda.synchronize()
+    qc, kc, vc = q.float().cpu(), k.float().cpu(), v.float().cpu()
+    ref = torch.zeros(B, T, Cc)
+    for i in range(B):
+        for s in range(2):
+            j = (i // ncam) * ncam + pair[i % ncam][s]
+            ref[i] += ref_attention(qc[i:i + 1], kc[j:j + 1], vc[j:j + 1], heads, d ** -0.5)[0]
+    close(o, ref, rtol=2e-2, atol_rel=2e-2, name="attn cross-view")
+
+
+@pytest.mark.parametrize("B,HW,Cc,G,silu,eps", [(2, 1400, 320, 32, True, 1e-5), (2, 350, 1920, 32, True, 1e-5), (3, 91, 1280, 32, False, 1e-6),
+                                                   (2, 100, 32, 32, True, 1e-5), (1, 28, 2560, 32, True, 1e-5), (2, 64, 64, 8, False, 1e-5)])
+def test_groupnorm(dev, B, HW, Cc, G, silu, eps):
+    x = (rnd(B, HW, Cc, seed=1).float() * 2 + 0.7).to(BF)
+    gam = rnd(Cc, seed=2, dtype=torch.float32); bet = rnd(Cc, seed=3, dtype=torch.float32)
+    y = torch.zeros_like(x)
+    O.run_ops([O.GroupNorm(x, y, gam, bet, groups=G, eps=eps, silu=silu)])
+    torch.cuda.synchronize()
+    ref = F.group_norm(x.float().cpu().transpose(1, 2), G, gam.cpu(), bet.cpu(), eps)
+    if silu: ref = F.silu(ref)
+    close(y, ref.transpose(1, 2), name="groupnorm")
+
+
+def test_groupnorm_channel_slice_view(dev):
+    big = rnd(2, 50, 96, seed=1)
+    x = big[:, :, 32:96]
+    gam = rnd(64, seed=2, dtype=torch.float32); bet = rnd(64, seed=3, dtype=torch.float32)
+    y = torch.zeros(2, 50, 64, dtype=BF, device=dev)
+    O.run_ops([O.GroupNorm(x, y, gam, bet, groups=32, eps=1e-5)])
+    torch.cuda.synchronize()
+    ref = F.group_norm(x.float().cpu().transpose(1, 2), 32, gam.cpu(), bet.cpu(), 1e-5).transpose(1, 2)
+    close(y, ref, name="groupnorm view")
+
+
+@pytest.mark.parametrize("M,Cc", [(8400, 320), (2100, 640), (546, 1280), (37, 64), (5, 2048)])
+def test_layernorm(dev, M, Cc):
+    x = (rnd(M, Cc, seed=1).float() * 3 - 0.5).to(BF)
+    gam = rnd(Cc, seed=2, dtype=torch.float32); bet = rnd(Cc, seed=3, dtype=torch.float32)
+    y = torch.zeros_like(x)
+    O.run_ops([O.LayerNorm(x, y, gam, bet)])
+    torch.cuda.synchronize()
+    close(y, F.layer_norm(x.float().cpu(), (Cc,), gam.cpu(), bet.cpu()), name="layernorm")
+
+
+def test_elementwise_family(dev):
+    x = rnd(700, 320, seed=1); y0 = rnd(700, 320, seed=2)
+    y = y0.clone()
+    O.run_ops([O.Ew(L.EW_ADD, x, y)])
+    close(y, x.float().cpu() + y0.float().cpu(), name="add")
+    # concat by two strided copies
+    a = rnd(300, 64, seed=3); b = rnd(300, 40, seed=4)
+    cat = torch.zeros(300, 104, dtype=BF, device=dev)
+    O.run_ops([O.Ew(L.EW_COPY, a, cat[:, :64]), O.Ew(L.EW_COPY, b, cat[:, 64:])])
+    assert torch.equal(cat.cpu(), torch.cat([a, b], 1).cpu())
+    # fp32 copy / scale / silu
+    f = rnd(10, 7, seed=5, dtype=torch.float32); g = torch.zeros_like(f)
+    O.run_ops([O.Ew(L.EW_COPY, f, g)]); assert torch.equal(f.cpu(), g.cpu())
+    O.run_ops([O.Ew(L.EW_SCALE, f, g, alpha=0.5)]); assert torch.allclose(g.cpu(), f.cpu() * 0.5)
+    O.run_ops([O.Ew(L.EW_SILU, f, g)]); assert torch.allclose(g.cpu(), F.silu(f.cpu()), atol=1e-5)
+    # nearest upsample to an explicit size (4x7 -> 7x13)
+    u = rnd(2, 4, 7, 64, seed=6); up = torch.zeros(2, 7, 13, 64, dtype=BF, device=dev)
+    O.run_ops([O.Upsample(u, up, PK.nearest_index(4, 7).to(dev), PK.nearest_index(7, 13).to(dev))])
+    ref = F.interpolate(u.float().cpu().permute(0, 3, 1, 2), size=(7, 13), mode="nearest").permute(0, 2, 3, 1)
+    assert torch.equal(up.float().cpu(), ref)
+    # layouts
+    n = rnd(2, 4, 28, 50, seed=7, dtype=torch.float32); h = torch.zeros(2, 28, 50, 4, dtype=torch.float32, device=dev)
+    O.run_ops([O.Layout(n, h, True)]); assert torch.equal(h.cpu(), n.permute(0, 2, 3, 1).cpu())
+    back = torch.zeros_like(n)
+    O.run_ops([O.Layout(h, back, False)]); assert torch.equal(back.cpu(), n.cpu())
+    hb = torch.zeros(2, 28, 50, 4, dtype=BF, device=dev)
+    O.run_ops([O.Layout(n, hb, True)]); assert torch.equal(hb.cpu(), n.permute(0, 2, 3, 1).to(BF).cpu())
+    torch.cuda.synchronize()
+
+
+def test_fourier_gather_timeemb(dev):
+    # embedder.py:15-40 order: [x, sin(f0 x), cos(f0 x), sin(f1 x), ...]
+    n, Pn, Fq = 37, 8, 4
+    x = rnd(n, Pn, 3, scale=20.0, seed=1, dtype=torch.float32)
+    mask = (torch.arange(n) % 3 != 0).to(torch.uint8).to(dev)
+    null = rnd(Pn * 27, seed=2, dtype=torch.float32)
+    y = torch.zeros(n, Pn * 27, dtype=BF, device=dev)
+    O.run_ops([O.Fourier(x, y, Fq, mask=mask, null_feat=null)])
+    xc = x.cpu()
+    parts = [xc]
+    for f in [1.0, 2.0, 4.0, 8.0]:
+        parts += [torch.sin(xc * f), torch.cos(xc * f)]
+    ref = torch.cat(parts, -1).reshape(n, -1)
+    m = mask.cpu().float()[:, None]
+    ref = ref * m + null.cpu()[None] * (1 - m)
+    close(y, ref, rtol=1e-2, atol_rel=5e-3, name="fourier")
+    # gather with -1 indices under mask 0
+    T = rnd(10, 64, seed=3); idx = torch.tensor([0, 9, -1, 3, -1], dtype=torch.int64, device=dev)
+    mk = torch.tensor([1, 1, 0, 1, 0], dtype=torch.uint8, device=dev); nr = rnd(64, seed=4)
+    out = torch.zeros(5, 64, dtype=BF, device=dev)
+    O.run_ops([O.Gather(T, out, idx, mask=mk, null_row=nr)])
+    exp = torch.stack([T[0], T[9], nr, T[3], nr]).cpu()
+    assert torch.equal(out.cpu(), exp)
+    # timestep embedding vs the diffusers formula (embeddings.py:24-64, flip_sin_to_cos=True, shift 0)
+    t = torch.tensor([981.0, 501.0, 1.0, 0.0], device=dev)
+    te = torch.zeros(4, 320, dtype=torch.float32, device=dev)
+    O.run_ops([O.TimeEmb(t, te)])
+    half = 160
+    expo = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+    emb = t.cpu()[:, None] * torch.exp(expo)[None]
+    ref = torch.cat([torch.cos(emb), torch.sin(emb)], -1)
+    assert torch.allclose(te.cpu(), ref, atol=2e-4), (te.cpu() - ref).abs().max()
+    torch.cuda.synchronize()
+
+
+def test_cfg_ddim_and_graph_replay(dev):
+    n = 6 * 4 * 28 * 50
+    x0 = rnd(n, seed=1, dtype=torch.float32); x = x0.clone()
+    eps = rnd(2 * n, seed=2, dtype=torch.float32)
+    coef = torch.tensor([[0.9, 0.4359, 0.95, 0.3122], [0.95, 0.3122, 0.99, 0.1411]], dtype=torch.float32, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    xin = torch.zeros(2 * n, dtype=torch.float32, device=dev)
+    op = O.DdimStep(x, eps, coef, step, x_in=xin, cfg=True, guidance=2.0)
+    prog = O.build_program([op])
+    st = torch.cuda.current_stream().cuda_stream
+    prog.run(st)
+    torch.cuda.synchronize()
+
+    def ref_step(xc, c):
+        e = eps[:n].cpu() + 2.0 * (eps[n:].cpu() - eps[:n].cpu())
+        p0 = (xc - c[1] * e) / c[0]
+        return c[2] * p0 + c[3] * e
+    r1 = ref_step(x0.cpu(), coef[0].cpu())
+    assert torch.allclose(x.cpu(), r1, atol=1e-5) and step.item() == 1
+    assert torch.equal(xin[:n].cpu(), x.cpu()) and torch.equal(xin[n:].cpu(), x.cpu())
+    # replay through a captured hipGraph: picks row 1 of the table via the device-side counter
+    prog.launch(st)
+    torch.cuda.synchronize()
+    assert torch.allclose(x.cpu(), ref_step(r1, coef[1].cpu()), atol=1e-5) and step.item() == 2
+
+
+def test_error_paths(dev):
+    A = rnd(16, 12, seed=1); W = rnd(8, 12, seed=2); C = torch.zeros(16, 8, dtype=BF, device=dev)
+    with pytest.raises(L.MdxError):
+        O.run_ops([O.Gemm(A, W, C)])            # K % 8 != 0
+    q = rnd(1, 8, 12, seed=1)
+    with pytest.raises(L.MdxError):
+        O.run_ops([O.Attn(q, q, torch.zeros(1, 12, 8, dtype=BF, device=dev), torch.zeros_like(q), heads=1, Tk=8, scale=1.0)])  # d=12
