@@ -318,7 +318,7 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
     int splitk = 1;
     if (p.splitk > 0) {
         splitk = p.splitk;  // caller forced
-    } else if (p.batch <= 1 && p.ws && tiles < 384 && p.K >= 1024) {
+    } else if (p.batch <= 1 && p.ws && tiles < 384 && p.K >= 1024 && (p.N % 4) == 0) {
         long want = (768 + tiles - 1) / tiles;
         long maxs = p.K / 512;  // keep >= 8 K-slabs per slice
         splitk = (int)min(min(want, maxs), 32L);
@@ -363,7 +363,7 @@ static int check_common(int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_
     if ((ldc % 4) || (ldr % 4)) return set_error(MDX_EINVAL, "ldc/ldr must be multiples of 4");
     if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7))
         return set_error(MDX_EINVAL, "operand pointers must be 16-byte (A, W) / 8-byte (C) aligned");
-    if (N % 4) return set_error(MDX_EINVAL, "N=%ld must be a multiple of 4", (long)N);
+    (void)N;
     return MDX_OK;
 }
 
@@ -371,6 +371,12 @@ extern "C" int mdx_gemm_bf16(const MdxGemmDesc* d, void* stream) {
     if (!d || !d->A || !d->W || !d->C) return set_error(MDX_EINVAL, "mdx_gemm_bf16: null operand");
     int rc = check_common(d->K, d->lda, d->ldw, d->ldc, d->ldr, d->A, d->W, d->C, d->N);
     if (rc) return rc;
+    if (d->N % 4) {
+        // ragged N (V^T with Tk % 4 != 0): columns N..roundup4(N)-1 are written as exact zeros
+        // (their W rows are zero-filled), so they must exist in the row pitch and carry no epilogue.
+        if (d->bias || d->temb || d->R || d->epilogue || d->splitk > 1 || d->ldc < (d->N + 3) / 4 * 4)
+            return set_error(MDX_EINVAL, "N=%ld not a multiple of 4 needs a plain epilogue and ldc >= roundup4(N)", (long)d->N);
+    }
     GCParams p = {};
     p.A = (const bf16_t*)d->A; p.W = (const bf16_t*)d->W; p.C = d->C; p.R = d->R;
     p.bias = d->bias; p.temb = d->temb; p.sel = d->sel_ptr; p.ws = d->ws;
@@ -391,6 +397,7 @@ extern "C" int mdx_conv2d_bf16(const MdxConvDesc* d, void* stream) {
     int rc = check_common(K, d->ldx, K, d->ldy, d->ldr, d->X, d->Wt, d->Y, d->Cout);
     if (rc) return rc;
     if (d->epilogue == MDX_EPI_GEGLU) return set_error(MDX_EINVAL, "conv has no GEGLU epilogue");
+    if (d->Cout % 4) return set_error(MDX_EINVAL, "mdx_conv2d_bf16: Cout=%ld must be a multiple of 4", (long)d->Cout);
     GCParams p = {};
     p.A = (const bf16_t*)d->X; p.W = (const bf16_t*)d->Wt; p.C = d->Y; p.R = d->R;
     p.bias = d->bias; p.temb = d->temb; p.sel = d->sel_ptr; p.ws = d->ws;
