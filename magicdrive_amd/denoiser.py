@@ -1,0 +1,365 @@
+"""Plans: the op programs of the hot path at a fixed batch geometry.
+
+  SamplerPlan   — what StableDiffusionBEVControlNetPipeline.__call__ runs: one prologue program and one
+                  per-step program (ControlNet -> UNet -> CFG + DDIM), replayed num_inference_steps times
+                  (eager, or as a captured hipGraph).
+  ControlNetPlan / UNetPlan — the module-level forwards behind BEVControlNetModel.forward /
+                  UNet2DConditionModelMultiview.forward (reference signatures).
+
+View ordering everywhere: view index = (cfg_half * b + scene) * n_cam + cam, "uncond first, cond second"
+(pipeline_bev_controlnet.py:330-343, 352-354).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops as O
+from . import packing as PK
+from .engine import Act, Builder, PackedNet, TembTable, build_context_kv, level_sizes
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _rows_as_pixels(t2d: torch.Tensor) -> torch.Tensor:
+    """[M, C] view with row stride ld -> [M, 1, 1, C] 'image' of M one-pixel samples (for linear layers run
+    through the direct-conv kernel, which may write into a column/row slice of a wider buffer)."""
+    M, C = t2d.shape
+    ld = t2d.stride(0)
+    assert t2d.stride(1) == 1
+    return torch.as_strided(t2d, (M, 1, 1, C), (ld, ld, ld, 1), t2d.storage_offset())
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0
+
+
+class ConditioningBuffers:
+    """Input-side device buffers of the conditioning prologue + the ops that turn them into the context tokens
+    ehs_with_cam [B, 1+77+L, D] and the per-view map feature (BEVControlNetModel.forward :743-793, 842-850)."""
+
+    def __init__(self, bld: Builder, cn: PackedNet, cfg, n_scene: int, n_cam: int, L_box: int, latent_hw, n_text: int = 77):
+        dev = bld.device
+        cc = cfg["controlnet"]; bb = cc["bbox"]
+        self.n_scene, self.n_cam, self.L = n_scene, n_cam, L_box
+        B = n_scene * n_cam
+        D = cfg["cross_attention_dim"]
+        self.S = 1 + n_text + L_box
+        self.n_text = n_text
+        S = self.S
+        self.ctx = torch.zeros(B, S, D, dtype=BF16, device=dev)
+        # camera: [B, 7, 3] fp32 (columns of the (3,7) matrix) -> Fourier 189 -> cam2token -> ctx[:, 0]
+        ncol = cc["uncond_cam_in_dim"][1]
+        F_cam = cc["cam_embedder_num_freqs"]
+        self.cam_in = torch.zeros(B, ncol, 3, dtype=F32, device=dev)
+        cam_emb = torch.empty(B, ncol * (3 + 6 * F_cam), dtype=BF16, device=dev)
+        bld.emit(O.Fourier(self.cam_in, cam_emb, F_cam, name="cam.fourier"))
+        wc = cn.lin("cam2token.weight")
+        bld.emit(O.Conv(cam_emb.view(B, 1, 1, -1), wc.view(wc.shape[0], 1, 1, wc.shape[1]), _rows_as_pixels(self.ctx[:, 0, :]),
+                        bias=cn.vec("cam2token.bias"), pad=(0, 0), direct=True, name="cam2token"))
+        # boxes
+        if L_box > 0:
+            P, Fq = bb["n_corners"], bb["embedder_num_freq"]
+            fdim = P * (3 + 6 * Fq)
+            pd = bb["proj_dims"]; ctd = bb["class_token_dim"]
+            n = B * L_box
+            self.box_in = torch.zeros(n, P, 3, dtype=F32, device=dev)
+            self.box_mask = torch.zeros(n, dtype=torch.uint8, device=dev)
+            self.box_cls = torch.zeros(n, dtype=torch.int64, device=dev)
+            pos = torch.empty(n, fdim, dtype=BF16, device=dev)
+            bld.emit(O.Fourier(self.box_in, pos, Fq, mask=self.box_mask, null_feat=cn.vec("bbox_embedder.null_pos_feature"), name="box.fourier"))
+            e1 = torch.empty(n, pd[0] + ctd, dtype=BF16, device=dev)       # [silu(bbox_proj) | class token]
+            wp = cn.lin("bbox_embedder.bbox_proj.weight")
+            bld.emit(O.Conv(pos.view(n, 1, 1, fdim), wp.view(pd[0], 1, 1, fdim), _rows_as_pixels(e1[:, :pd[0]]),
+                            bias=cn.vec("bbox_embedder.bbox_proj.bias"), pad=(0, 0), epilogue=L.EPI_SILU, direct=True, name="box.bbox_proj"))
+            bld.emit(O.Gather(cn.table("bbox_embedder._class_tokens"), e1[:, pd[0]:], self.box_cls, mask=self.box_mask,
+                              null_row=cn.vec_bf16("bbox_embedder.null_class_feature"), name="box.class_token"))
+            e2 = torch.empty(n, pd[1], dtype=BF16, device=dev)
+            bld.emit(O.Gemm(e1, cn.lin("bbox_embedder.second_linear.0.weight"), e2, bias=cn.vec("bbox_embedder.second_linear.0.bias"), epilogue=L.EPI_SILU, name="box.mlp0"))
+            e3 = torch.empty(n, pd[2], dtype=BF16, device=dev)
+            bld.emit(O.Gemm(e2, cn.lin("bbox_embedder.second_linear.2.weight"), e3, bias=cn.vec("bbox_embedder.second_linear.2.bias"), epilogue=L.EPI_SILU, name="box.mlp2"))
+            # last layer writes straight into the box rows of every view's context (batched over views)
+            bld.emit(O.Gemm(e3.view(B, L_box, pd[2]), cn.lin("bbox_embedder.second_linear.4.weight"), self.ctx[:, 1 + n_text:, :],
+                            bias=cn.vec("bbox_embedder.second_linear.4.bias"), name="box.mlp4"))
+            self._keep = (pos, e1, e2, e3)
+        self._keep_cam = cam_emb
+        # BEV map encoder: once per scene (the reference convolves 6 identical copies every step)
+        h, w = latent_hw
+        msz = cc["map_size"]
+        ch = cc["conditioning_embedding_out_channels"]
+        self.map_in = torch.zeros(n_scene, msz[0], msz[1], msz[2], dtype=F32, device=dev)
+        x = torch.empty(n_scene, msz[1], msz[2], msz[0], dtype=BF16, device=dev)
+        bld.emit(O.Layout(self.map_in, x, True, name="map.nhwc"))
+        pre = "controlnet_cond_embedding."
+        layers = [(pre + "conv_in.", (1, 1), (1, 1), True)]
+        nblk = 0
+        while cn.has(f"{pre}blocks.{nblk}.weight"):
+            nblk += 1
+        for i in range(nblk):                               # map_embedder.py:36-56
+            if i < nblk - 2:
+                layers.append((f"{pre}blocks.{i}.", (1, 1), (1, 1), True) if i % 2 == 0 else (f"{pre}blocks.{i}.", (2, 2), (2, 1), True))
+            elif i == nblk - 2:
+                layers.append((f"{pre}blocks.{i}.", (1, 1), (2, 1), True))
+            else:
+                layers.append((f"{pre}blocks.{i}.", (2, 1), (2, 1), True))
+        layers.append((pre + "conv_out.", (1, 1), (1, 1), False))
+        keep = [x]
+        for key, stride, pad, act in layers:
+            wt = cn.conv(key + "weight")
+            Hi, Wi = x.shape[1], x.shape[2]
+            Ho = (Hi + 2 * pad[0] - 3) // stride[0] + 1
+            Wo = (Wi + 2 * pad[1] - 3) // stride[1] + 1
+            y = torch.empty(n_scene, Ho, Wo, wt.shape[0], dtype=BF16, device=dev)
+            bld.emit(O.Conv(x, wt, y, bias=cn.vec(key + "bias"), stride=stride, pad=pad, epilogue=L.EPI_SILU if act else L.EPI_NONE,
+                            direct=(wt.shape[3] % 8 != 0 or wt.shape[0] % 4 != 0), ws=bld.ws, name="map." + key))
+            keep.append(y)
+            x = y
+        if (x.shape[1], x.shape[2]) != (h, w):
+            raise ValueError(f"map encoder output {tuple(x.shape[1:3])} != latent size {(h, w)} (needs the ...Plus embedder, SURVEY.md §8f)")
+        C0 = x.shape[3]
+        self.map_rep = torch.empty(B, h, w, C0, dtype=BF16, device=dev)
+        for s in range(n_scene):
+            for c in range(n_cam):
+                bld.emit(O.Ew(L.EW_COPY, x[s].view(h * w, C0), self.map_rep[s * n_cam + c].view(h * w, C0), name="map.repeat"))
+        self._keep_map = keep
+
+    # ---- input marshalling (torch: dtype / layout of user tensors only) ----
+    def load(self, camera_param: torch.Tensor, text: torch.Tensor, bev_map: torch.Tensor, boxes: Optional[Dict[str, torch.Tensor]]):
+        """camera_param (n_scene, n_cam, 3, 7); text (n_scene, n_text, D); bev_map (n_scene, C, H, W);
+        boxes {bboxes (n_scene, n_cam | 1, L, 8, 3), classes, masks} or None."""
+        ns, nc = self.n_scene, self.n_cam
+        assert camera_param.shape[:2] == (ns, nc), f"camera_param {tuple(camera_param.shape)} vs scenes {ns} cams {nc}"
+        self.cam_in.copy_(camera_param.to(self.cam_in.device, F32).permute(0, 1, 3, 2).reshape(ns * nc, -1, 3))
+        assert text.shape[0] == ns and text.shape[1] == self.n_text
+        self.ctx.view(ns, nc, self.S, -1)[:, :, 1:1 + self.n_text, :] = text.to(self.ctx.device, BF16).unsqueeze(1)
+        self.map_in.copy_(bev_map.to(self.map_in.device, F32))
+        if self.L > 0:
+            assert boxes is not None
+            bb, cl, mk = boxes["bboxes"], boxes["classes"], boxes["masks"]
+            if bb.shape[1] != nc:                               # view-shared boxes (unet_addon_rawbox.py:785-787)
+                assert bb.shape[1] == 1
+                bb = bb.expand(ns, nc, *bb.shape[2:]); cl = cl.expand(ns, nc, -1); mk = mk.expand(ns, nc, -1)
+            assert bb.shape[2] == self.L, f"boxes padded to {bb.shape[2]} but plan built for L={self.L}"
+            self.box_in.copy_(bb.to(self.box_in.device, F32).reshape(-1, *bb.shape[3:]))
+            self.box_cls.copy_(cl.to(self.box_cls.device, torch.int64).reshape(-1))
+            self.box_mask.copy_(mk.to(self.box_mask.device).reshape(-1).to(torch.uint8))
+
+
+def _emit_controlnet(bld: Builder, cn: PackedNet, x_in: torch.Tensor, cond: ConditioningBuffers, temb: TembTable, ctx_kv, h, w):
+    """conv_in + map feature, then the encoder copy (unet_addon_rawbox.py:846-880). x_in fp32 [B,h,w,4]."""
+    c0 = bld.cfg["block_out_channels"][0]
+    x0 = bld.new(bld.B, h, w, c0)
+    bld.emit(O.Conv(x_in, cn.conv("conv_in.weight"), x0.bhwc, bias=cn.vec("conv_in.bias"), R=cond.map_rep, direct=True, name="cn.conv_in+map"))
+    return bld.encoder(cn, x0, temb, ctx_kv, "cn")
+
+
+def _zero_conv_keys(n_skips: int):
+    return [f"controlnet_down_blocks.{k}." for k in range(n_skips)]
+
+
+class SamplerPlan:
+    """Everything the DDIM loop needs for `b` scenes (x `n_cam` views, x2 with CFG) on one GPU."""
+
+    def __init__(self, cfg, unet: PackedNet, cn: PackedNet, device, b: int, do_cfg: bool, L_box: int, latent_hw=(28, 50),
+                 num_steps: int = 50, guidance_scale: float = 2.0, conditioning_scale: float = 1.0, n_text: int = 77):
+        self.cfg, self.device = cfg, device
+        n_cam = len(cfg["neighboring_view_pair"])
+        self.b, self.n_cam, self.c = b, n_cam, (2 if do_cfg else 1)
+        self.do_cfg = do_cfg
+        self.num_steps = num_steps
+        h, w = latent_hw
+        self.h, self.w = h, w
+        B = self.c * b * n_cam
+        self.B = B
+        Cl = cfg["in_channels"]
+        bld = Builder(cfg, device, B, n_cam)
+        self.bld = bld
+        # state
+        self.x = torch.zeros(b * n_cam, h, w, Cl, dtype=F32, device=device)            # latents, NHWC
+        self.x_in = torch.zeros(B, h, w, Cl, dtype=F32, device=device)                  # model input ([uncond|cond] copies)
+        self.eps = torch.zeros(B, h, w, cfg["out_channels"], dtype=F32, device=device)
+        self.coef = torch.zeros(num_steps, 4, dtype=F32, device=device)
+        self.step_ctr = torch.zeros(1, dtype=torch.int32, device=device)
+        # ---------------- prologue ----------------
+        self.cond = ConditioningBuffers(bld, cn, cfg, self.c * b, n_cam, L_box, latent_hw, n_text)
+        self.temb_cn = TembTable(cn, num_steps, device, per_sample=False)
+        self.temb_un = TembTable(unet, num_steps, device, per_sample=False)
+        self.temb_cn.sel = self.step_ctr
+        self.temb_un.sel = self.step_ctr
+        self.temb_cn.emit_fill(bld, cn, cfg)
+        self.temb_un.emit_fill(bld, unet, cfg)
+        self.kv_cn = build_context_kv(bld, cn, self.cond.ctx, B, self.cond.S)
+        self.kv_un = build_context_kv(bld, unet, self.cond.ctx, B, self.cond.S)
+        self.prologue_ops = bld.ops
+        bld.ops = []
+        # ---------------- one denoising step ----------------
+        cn_mid, cn_skips = _emit_controlnet(bld, cn, self.x_in, self.cond, self.temb_cn, self.kv_cn, h, w)
+        c0 = cfg["block_out_channels"][0]
+        u0 = bld.new(B, h, w, c0)
+        bld.emit(O.Conv(self.x_in, unet.conv("conv_in.weight"), u0.bhwc, bias=unet.vec("conv_in.bias"), direct=True, name="unet.conv_in"))
+        u_mid, u_skips = bld.encoder(unet, u0, self.temb_un, self.kv_un, "unet")
+        # zero-convs accumulate straight into the UNet skips / mid (unet_addon_rawbox.py:882-910 +
+        # unet_2d_condition_multiview.py:464-488); the adds happen after the UNet encoder+mid consumed the
+        # un-added tensors, exactly like the reference's out-of-place `sample + residual`.
+        assert len(cn_skips) == len(u_skips)
+        for k, (cs, us) in enumerate(zip(cn_skips, u_skips)):
+            key = f"controlnet_down_blocks.{k}."
+            bld.emit(O.Gemm(cs.tok, cn.lin(key + "weight", conditioning_scale), us.tok, bias=cn.vec(key + "bias", conditioning_scale), R=us.tok, name=f"zero_conv.{k}"))
+            bld.free(cs)
+        bld.emit(O.Gemm(cn_mid.tok, cn.lin("controlnet_mid_block.weight", conditioning_scale), u_mid.tok,
+                        bias=cn.vec("controlnet_mid_block.bias", conditioning_scale), R=u_mid.tok, name="zero_conv.mid"))
+        bld.free(cn_mid)
+        y = bld.decoder(unet, u_mid, u_skips, self.temb_un, self.kv_un, "unet")
+        bld.emit(O.Conv(y.bhwc, unet.conv("conv_out.weight"), self.eps, bias=unet.vec("conv_out.bias"), direct=True, name="unet.conv_out"))
+        bld.free(y)
+        bld.emit(O.DdimStep(self.x.view(-1), self.eps.view(-1), self.coef, self.step_ctr, x_in=self.x_in.view(-1), cfg=do_cfg, guidance=guidance_scale, name="cfg+ddim"))
+        self.step_ops = bld.ops
+        bld.ops = []
+        self.prologue: Optional[L.Program] = None
+        self.step: Optional[L.Program] = None
+
+    def compile(self):
+        self.prologue = O.build_program(self.prologue_ops)
+        self.step = O.build_program(self.step_ops)
+
+    # ---- per-call inputs ----
+    def load_inputs(self, latents: torch.Tensor, camera_param, text, bev_map, boxes, timesteps: torch.Tensor, coef: torch.Tensor):
+        """latents (b, n_cam, C, h, w) any float dtype; camera/text/map/boxes already hold the [uncond | cond] halves."""
+        b, nc = self.b, self.n_cam
+        assert latents.shape[:2] == (b, nc)
+        xl = latents.to(self.device, F32).reshape(b * nc, *latents.shape[2:]).permute(0, 2, 3, 1).contiguous()
+        self.x.copy_(xl)
+        self.x_in.view(self.c, b * nc, *self.x.shape[1:]).copy_(self.x.unsqueeze(0).expand(self.c, *self.x.shape))
+        self.cond.load(camera_param, text, bev_map, boxes)
+        t = timesteps.to(self.device, F32)
+        assert t.numel() == self.num_steps
+        self.temb_cn.t.copy_(t); self.temb_un.t.copy_(t)
+        self.coef.copy_(coef.to(self.device, F32))
+        self.step_ctr.zero_()
+
+    def run(self, use_graph: bool = True) -> torch.Tensor:
+        """prologue + num_steps denoising steps on the current stream; returns latents (b, n_cam, C, h, w) fp32."""
+        if self.prologue is None:
+            self.compile()
+        st = _stream()
+        self.prologue.run(st)
+        for _ in range(self.num_steps):
+            if use_graph:
+                self.step.launch(st)
+            else:
+                self.step.run(st)
+        return self.latents()
+
+    def latents(self) -> torch.Tensor:
+        return self.x.view(self.b, self.n_cam, self.h, self.w, -1).permute(0, 1, 4, 2, 3).contiguous()
+
+
+class ControlNetPlan:
+    """BEVControlNetModel.forward at a fixed geometry: returns 12 down residuals + mid (NCHW) + ehs_with_cam."""
+
+    def __init__(self, cfg, cn: PackedNet, device, n_scene: int, L_box: int, latent_hw, conditioning_scale: float = 1.0, n_text: int = 77):
+        n_cam = len(cfg["neighboring_view_pair"])
+        B = n_scene * n_cam
+        h, w = latent_hw
+        self.cfg, self.device, self.B, self.n_scene, self.n_cam, self.h, self.w = cfg, device, B, n_scene, n_cam, h, w
+        bld = Builder(cfg, device, B, n_cam)
+        self.bld = bld
+        self.sample_nchw = torch.zeros(B, cfg["in_channels"], h, w, dtype=F32, device=device)
+        self.x_in = torch.zeros(B, h, w, cfg["in_channels"], dtype=F32, device=device)
+        bld.emit(O.Layout(self.sample_nchw, self.x_in, True, name="cn.sample.nhwc"))
+        self.cond = ConditioningBuffers(bld, cn, cfg, n_scene, n_cam, L_box, latent_hw, n_text)
+        self.temb = TembTable(cn, B, device, per_sample=True)        # one timestep per view row
+        self.temb.emit_fill(bld, cn, cfg)
+        self.kv = build_context_kv(bld, cn, self.cond.ctx, B, self.cond.S)
+        mid, skips = _emit_controlnet(bld, cn, self.x_in, self.cond, self.temb, self.kv, h, w)
+        self.down_out: List[torch.Tensor] = []
+        for k, s in enumerate(skips):
+            key = f"controlnet_down_blocks.{k}."
+            r = bld.new(s.B, s.H, s.W, s.C)
+            bld.emit(O.Gemm(s.tok, cn.lin(key + "weight", conditioning_scale), r.tok, bias=cn.vec(key + "bias", conditioning_scale), name=f"zero_conv.{k}"))
+            o = torch.zeros(s.B, s.C, s.H, s.W, dtype=BF16, device=device)
+            bld.emit(O.Layout(r.bhwc, o, False, name=f"res{k}.nchw"))
+            self.down_out.append(o)
+        r = bld.new(mid.B, mid.H, mid.W, mid.C)
+        bld.emit(O.Gemm(mid.tok, cn.lin("controlnet_mid_block.weight", conditioning_scale), r.tok, bias=cn.vec("controlnet_mid_block.bias", conditioning_scale), name="zero_conv.mid"))
+        self.mid_out = torch.zeros(mid.B, mid.C, mid.H, mid.W, dtype=BF16, device=device)
+        bld.emit(O.Layout(r.bhwc, self.mid_out, False, name="mid.nchw"))
+        self.ops = bld.ops
+        self.program: Optional[L.Program] = None
+
+    def run(self, sample, timestep, camera_param, boxes, text, bev_map):
+        if self.program is None:
+            self.program = O.build_program(self.ops)
+        self.sample_nchw.copy_(sample.to(self.device, F32).reshape(self.B, *sample.shape[-3:]))
+        t = torch.as_tensor(timestep).to(self.device, F32).reshape(-1)
+        if t.numel() == 1:
+            t = t.expand(self.n_scene)
+        if t.numel() == self.n_scene:
+            t = t.repeat_interleave(self.n_cam)                      # unet_addon_rawbox.py:840-841
+        self.temb.t.copy_(t)
+        self.cond.load(camera_param, text, bev_map, boxes)
+        self.program.run(_stream())
+        return self.down_out, self.mid_out, self.cond.ctx
+
+
+class UNetPlan:
+    """UNet2DConditionModelMultiview.forward at a fixed geometry (sample (B,4,h,w), ehs (B,S,D), residuals)."""
+
+    def __init__(self, cfg, unet: PackedNet, device, B: int, S: int, latent_hw, with_residuals: bool = True):
+        n_cam = len(cfg["neighboring_view_pair"])
+        assert B % n_cam == 0, "batch must hold whole scenes: (b n) views (blocks.py:196-197)"
+        h, w = latent_hw
+        self.cfg, self.device, self.B, self.S, self.h, self.w = cfg, device, B, S, h, w
+        bld = Builder(cfg, device, B, n_cam)
+        self.bld = bld
+        D = cfg["cross_attention_dim"]
+        self.sample_nchw = torch.zeros(B, cfg["in_channels"], h, w, dtype=F32, device=device)
+        self.x_in = torch.zeros(B, h, w, cfg["in_channels"], dtype=F32, device=device)
+        self.ctx = torch.zeros(B, S, D, dtype=BF16, device=device)
+        bld.emit(O.Layout(self.sample_nchw, self.x_in, True, name="unet.sample.nhwc"))
+        self.temb = TembTable(unet, B, device, per_sample=True)
+        self.temb.emit_fill(bld, unet, cfg)
+        self.kv = build_context_kv(bld, unet, self.ctx, B, S)
+        c0 = cfg["block_out_channels"][0]
+        u0 = bld.new(B, h, w, c0)
+        bld.emit(O.Conv(self.x_in, unet.conv("conv_in.weight"), u0.bhwc, bias=unet.vec("conv_in.bias"), direct=True, name="unet.conv_in"))
+        mid, skips = bld.encoder(unet, u0, self.temb, self.kv, "unet")
+        self.res_in: List[torch.Tensor] = []
+        self.mid_in = None
+        if with_residuals:
+            for k, s in enumerate(skips):
+                rin = torch.zeros(s.B, s.C, s.H, s.W, dtype=BF16, device=device)
+                rn = bld.new(s.B, s.H, s.W, s.C)
+                bld.emit(O.Layout(rin, rn.bhwc, True, name=f"res{k}.nhwc"))
+                bld.emit(O.Ew(L.EW_ADD, rn.tok, s.tok, name=f"skip{k}+=res"))
+                bld.free(rn)
+                self.res_in.append(rin)
+            self.mid_in = torch.zeros(mid.B, mid.C, mid.H, mid.W, dtype=BF16, device=device)
+            rn = bld.new(mid.B, mid.H, mid.W, mid.C)
+            bld.emit(O.Layout(self.mid_in, rn.bhwc, True, name="midres.nhwc"))
+            bld.emit(O.Ew(L.EW_ADD, rn.tok, mid.tok, name="mid+=res"))
+            bld.free(rn)
+        y = bld.decoder(unet, mid, skips, self.temb, self.kv, "unet")
+        self.eps_nhwc = torch.zeros(B, h, w, cfg["out_channels"], dtype=F32, device=device)
+        bld.emit(O.Conv(y.bhwc, unet.conv("conv_out.weight"), self.eps_nhwc, bias=unet.vec("conv_out.bias"), direct=True, name="unet.conv_out"))
+        self.out_nchw = torch.zeros(B, cfg["out_channels"], h, w, dtype=F32, device=device)
+        bld.emit(O.Layout(self.eps_nhwc, self.out_nchw, False, name="eps.nchw"))
+        self.ops = bld.ops
+        self.program: Optional[L.Program] = None
+
+    def run(self, sample, timestep, ehs, down_res=None, mid_res=None):
+        if self.program is None:
+            self.program = O.build_program(self.ops)
+        self.sample_nchw.copy_(sample.to(self.device, F32))
+        t = torch.as_tensor(timestep).to(self.device, F32).reshape(-1)
+        self.temb.t.copy_(t.expand(self.B) if t.numel() == 1 else t)
+        self.ctx.copy_(ehs.to(self.device, BF16))
+        if self.res_in:
+            assert down_res is not None and len(down_res) == len(self.res_in)
+            for dst, src in zip(self.res_in, down_res):
+                dst.copy_(src.to(self.device, BF16))
+            self.mid_in.copy_(mid_res.to(self.device, BF16))
+        self.program.run(_stream())
+        return self.out_nchw

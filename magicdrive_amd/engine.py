@@ -1,0 +1,402 @@
+"""Host-side engine: turns (config, reference-layout state dicts, batch shape) into the flat op
+programs libmdx executes — a step-invariant *prologue* (conditioning encoders, context K/V, timestep
+tables) and the per-step *denoise* program (BEV-ControlNet -> multi-view UNet -> CFG + DDIM).
+
+What is hoisted out of the 50-step loop (the reference recomputes all of it every step):
+  * camera Fourier+cam2token, box Fourier+MLP, the [cam | text | box] context assembly
+      (magicdrive/networks/unet_addon_rawbox.py:743-793),
+  * the BEV-map conv encoder — once per map, not 6 x per step (unet_addon_rawbox.py:842-850),
+  * every attn2.to_k / to_v projection of the context (attention_processor.py:520-525),
+  * timestep sinusoid + time MLP + every resnet's time_emb_proj, for ALL steps at once, as one GEMM
+      (unet_2d_condition_multiview.py:386-411; resnet.py:612-618).
+What is de-duplicated inside a step: the cross-view attention's q/k/v/out projections run once per view
+instead of once per (view, neighbour) pair (magicdrive/networks/blocks.py:112-121).
+
+Every arithmetic op is a libmdx kernel (see ops.py); torch is used for device memory and for marshalling
+user inputs (dtype/layout of the arguments, uncond/cond concatenation).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops as O
+from . import packing as PK
+from .networks.spec import heads_at
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class PackedNet:
+    """Device-resident, kernel-layout weights of one network, packed lazily from a reference state dict."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device):
+        self.sd = sd
+        self.device = device
+        self.cache: Dict[Tuple, torch.Tensor] = {}
+
+    def has(self, key: str) -> bool:
+        return key in self.sd
+
+    def _get(self, tag, keys, fn):
+        ck = (tag,) + tuple(keys)
+        if ck not in self.cache:
+            self.cache[ck] = fn(*[self.sd[k].detach().float() for k in keys]).to(self.device)
+        return self.cache[ck]
+
+    def lin(self, key, scale: float = 1.0):            # [N,K] bf16 (1x1 convs too)
+        return self._get(("lin", scale), [key], lambda w: (w.reshape(w.shape[0], -1) * scale).contiguous().to(BF16))
+
+    def conv(self, key):                               # [Cout,kh,kw,Cin] bf16
+        return self._get("conv", [key], PK.pack_conv_weight)
+
+    def vec(self, key, scale: float = 1.0):            # fp32 vector
+        return self._get(("vec", scale), [key], lambda v: (v.reshape(-1) * scale).contiguous().to(F32))
+
+    def vec_bf16(self, key):
+        return self._get("vecbf", [key], lambda v: v.reshape(-1).contiguous().to(BF16))
+
+    def cat_lin(self, keys: Sequence[str]):            # rows concatenated
+        return self._get("catlin", keys, lambda *ws: torch.cat([w.reshape(w.shape[0], -1) for w in ws], 0).contiguous().to(BF16))
+
+    def cat_vec(self, keys: Sequence[str]):
+        return self._get("catvec", keys, lambda *vs: torch.cat([v.reshape(-1) for v in vs]).contiguous().to(F32))
+
+    def geglu(self, wkey, bkey):
+        w = self._get("gegluw", [wkey, bkey], lambda w, b: PK.pack_geglu(w, b)[0])
+        b = self._get("geglub", [wkey, bkey], lambda w, b: PK.pack_geglu(w, b)[1])
+        return w, b
+
+    def table(self, key):                              # 2-D bf16 table (class tokens)
+        return self._get("table", [key], lambda t: t.contiguous().to(BF16))
+
+
+class Pool:
+    """Exact-size free-list of device buffers; the program's ops alias freed buffers, which is safe because
+    a program executes in order on one stream."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free_list: Dict[Tuple, List[torch.Tensor]] = {}
+        self.total_bytes = 0
+
+    def get(self, shape, dtype=BF16) -> torch.Tensor:
+        n = 1
+        for s in shape:
+            n *= int(s)
+        key = (n, dtype)
+        fl = self.free_list.get(key)
+        if fl:
+            return fl.pop().view(*shape)
+        self.total_bytes += n * torch.empty(0, dtype=dtype).element_size()
+        return torch.empty(n, dtype=dtype, device=self.device).view(*shape)
+
+    def put(self, t: Optional[torch.Tensor]):
+        if t is None:
+            return
+        base = t.reshape(-1) if t.is_contiguous() else None
+        assert base is not None, "only whole contiguous buffers go back to the pool"
+        self.free_list.setdefault((base.numel(), base.dtype), []).append(base)
+
+
+def level_sizes(h: int, w: int, n_levels: int) -> List[Tuple[int, int]]:
+    """Spatial size per UNet level: Downsample2D = conv3x3 stride 2 pad 1 (resnet.py:198-222)."""
+    out = [(h, w)]
+    for _ in range(n_levels - 1):
+        h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        out.append((h, w))
+    return out
+
+
+class Act:
+    """A channels-last activation: tokens [B*H*W, C] bf16 plus its geometry."""
+
+    __slots__ = ("t", "B", "H", "W", "C")
+
+    def __init__(self, t, B, H, W, C):
+        self.t, self.B, self.H, self.W, self.C = t, B, H, W, C
+
+    @property
+    def tok(self):            # [M, C]
+        return self.t.view(self.B * self.H * self.W, self.C)
+
+    @property
+    def bhwc(self):
+        return self.t.view(self.B, self.H, self.W, self.C)
+
+    @property
+    def btc(self):
+        return self.t.view(self.B, self.H * self.W, self.C)
+
+
+class Builder:
+    """Emits IR ops for the two networks at a fixed batch geometry."""
+
+    def __init__(self, cfg, device, n_views: int, n_cam: int, ws_mb: int = 64):
+        self.cfg = cfg
+        self.device = device
+        self.B = n_views                  # c * b * n_cam views through the nets
+        self.n_cam = n_cam
+        self.pool = Pool(device)
+        self.ops: List[object] = []
+        self.ws = torch.empty(ws_mb * 1024 * 1024 // 4, dtype=F32, device=device)
+        self.groups = cfg["norm_num_groups"]
+        self.eps = cfg["norm_eps"]
+        pair = cfg["neighboring_view_pair"]
+        pair = {int(k): [int(x) for x in v] for k, v in pair.items()}
+        assert cfg.get("neighboring_attn_type", "add") == "add", "only the default 'add' neighbour mode is built"
+        kv = []
+        for i in range(n_views):
+            base = (i // n_cam) * n_cam
+            for nb in pair[i % n_cam]:
+                kv.append(base + nb)
+        assert all(len(v) == 2 for v in pair.values()), "cross-view kernel handles exactly 2 neighbours per view"
+        self.kvmap = torch.tensor(kv, dtype=torch.int32, device=device)
+
+    # ---- small helpers ---------------------------------------------------------------
+    def emit(self, op):
+        self.ops.append(op)
+        return op
+
+    def new(self, B, H, W, C) -> Act:
+        return Act(self.pool.get((B * H * W, C)), B, H, W, C)
+
+    def free(self, a):
+        self.pool.put(a.t if isinstance(a, Act) else a)
+
+    def groupnorm(self, net, pre, x: Act, eps, silu, name) -> Act:
+        y = self.new(x.B, x.H, x.W, x.C)
+        self.emit(O.GroupNorm(x.btc, y.btc, net.vec(pre + "weight"), net.vec(pre + "bias"), self.groups, eps, silu, name=name))
+        return y
+
+    def layernorm(self, net, pre, x: torch.Tensor, name) -> torch.Tensor:
+        y = self.pool.get(tuple(x.shape))
+        self.emit(O.LayerNorm(x, y, net.vec(pre + "weight"), net.vec(pre + "bias"), 1e-5, name=name))
+        return y
+
+    def gemm(self, A, W, N_out, bias=None, R=None, epilogue=L.EPI_NONE, name="", out=None, **kw) -> torch.Tensor:
+        C = out if out is not None else self.pool.get((A.shape[0], N_out))
+        self.emit(O.Gemm(A, W, C, bias=bias, R=R, epilogue=epilogue, ws=self.ws, name=name, **kw))
+        return C
+
+    # ---- resnet -------------------------------------------------------------------------
+    def resnet(self, net, pre, x: Act, temb: "TembTable", name) -> Act:
+        """ResnetBlock2D.forward (resnet.py:590-640)."""
+        cout = net.sd[pre + "conv1.weight"].shape[0]
+        a = self.groupnorm(net, pre + "norm1.", x, self.eps, True, name + ".norm1")
+        h = self.new(x.B, x.H, x.W, cout)
+        off = temb.offset[pre + "time_emb_proj.weight"]
+        self.emit(O.Conv(a.bhwc, net.conv(pre + "conv1.weight"), h.bhwc, bias=net.vec(pre + "conv1.bias"),
+                         temb=temb.table[:, off:], sel=temb.sel, temb_sel_stride=temb.sel_stride, temb_b_stride=temb.b_stride,
+                         ws=self.ws, name=name + ".conv1"))
+        self.free(a)
+        b = self.groupnorm(net, pre + "norm2.", h, self.eps, True, name + ".norm2")
+        self.free(h)
+        if net.has(pre + "conv_shortcut.weight"):
+            sc = self.new(x.B, x.H, x.W, cout)
+            self.gemm(x.tok, net.lin(pre + "conv_shortcut.weight"), cout, bias=net.vec(pre + "conv_shortcut.bias"), out=sc.tok, name=name + ".shortcut")
+        else:
+            sc = x
+        out = self.new(x.B, x.H, x.W, cout)
+        self.emit(O.Conv(b.bhwc, net.conv(pre + "conv2.weight"), out.bhwc, bias=net.vec(pre + "conv2.bias"), R=sc.bhwc, ws=self.ws, name=name + ".conv2"))
+        self.free(b)
+        if sc is not x:
+            self.free(sc)
+        return out
+
+    # ---- transformer ------------------------------------------------------------------------
+    def self_like_attention(self, net, pre, n: torch.Tensor, B, T, C, heads, cross_view: bool, name) -> torch.Tensor:
+        """q,k fused projection + V^T projection + fused attention over the same token set (attn1) or over the
+        two neighbour views (attn4).  n: normalised tokens [B*T, C]."""
+        qk = self.gemm(n, net.cat_lin([pre + "to_q.weight", pre + "to_k.weight"]), 2 * C, name=name + ".qk")
+        ldv = PK.round_up(T, 8)
+        vt = self.pool.get((B, C, ldv))
+        self.emit(O.Gemm(net.lin(pre + "to_v.weight"), n.view(B, T, C), vt[:, :, :T], name=name + ".vT"))
+        ao = self.pool.get((B * T, C))
+        qk3 = qk.view(B, T, 2 * C)
+        self.emit(O.Attn(qk3[:, :, :C], qk3[:, :, C:], vt, ao.view(B, T, C), heads=heads, Tk=T, scale=(C // heads) ** -0.5,
+                         kvmap=self.kvmap if cross_view else None, nsrc=2 if cross_view else 1, name=name + ".attn"))
+        self.pool.put(qk)
+        self.pool.put(vt)
+        return ao
+
+    def transformer_block(self, net, pre, h: torch.Tensor, B, T, C, heads, ctx_kv, name) -> torch.Tensor:
+        """BasicTransformerBlock / BasicMultiviewTransformerBlock.forward (magicdrive/networks/blocks.py:144-238)."""
+        # 1. self-attention
+        n1 = self.layernorm(net, pre + "norm1.", h, name + ".norm1")
+        ao = self.self_like_attention(net, pre + "attn1.", n1, B, T, C, heads, False, name + ".attn1")
+        self.pool.put(n1)
+        h1 = self.gemm(ao, net.lin(pre + "attn1.to_out.0.weight"), C, bias=net.vec(pre + "attn1.to_out.0.bias"), R=h, name=name + ".attn1.out")
+        self.pool.put(ao); self.pool.put(h)
+        # 2. context cross-attention with prologue-computed K / V^T
+        n2 = self.layernorm(net, pre + "norm2.", h1, name + ".norm2")
+        q2 = self.gemm(n2, net.lin(pre + "attn2.to_q.weight"), C, name=name + ".attn2.q")
+        self.pool.put(n2)
+        Kc, Vtc, S = ctx_kv[pre + "attn2."]
+        ao2 = self.pool.get((B * T, C))
+        self.emit(O.Attn(q2.view(B, T, C), Kc, Vtc, ao2.view(B, T, C), heads=heads, Tk=S, scale=(C // heads) ** -0.5, name=name + ".attn2"))
+        self.pool.put(q2)
+        h2 = self.gemm(ao2, net.lin(pre + "attn2.to_out.0.weight"), C, bias=net.vec(pre + "attn2.to_out.0.bias"), R=h1, name=name + ".attn2.out")
+        self.pool.put(ao2); self.pool.put(h1)
+        # 2b. cross-view attention: out = W_o (o_left + o_right) + 2 b_o ; connector ; residual (blocks.py:190-222)
+        if net.has(pre + "attn4.to_q.weight"):
+            n4 = self.layernorm(net, pre + "norm4.", h2, name + ".norm4")
+            ao4 = self.self_like_attention(net, pre + "attn4.", n4, B, T, C, heads, True, name + ".attn4")
+            self.pool.put(n4)
+            t4 = self.gemm(ao4, net.lin(pre + "attn4.to_out.0.weight"), C, bias=net.vec(pre + "attn4.to_out.0.bias", 2.0), name=name + ".attn4.out")
+            self.pool.put(ao4)
+            h3 = self.gemm(t4, net.lin(pre + "connector.weight"), C, bias=net.vec(pre + "connector.bias"), R=h2, name=name + ".connector")
+            self.pool.put(t4); self.pool.put(h2)
+        else:
+            h3 = h2
+        # 3. GEGLU feed-forward
+        n3 = self.layernorm(net, pre + "norm3.", h3, name + ".norm3")
+        wg, bg = net.geglu(pre + "ff.net.0.proj.weight", pre + "ff.net.0.proj.bias")
+        g = self.gemm(n3, wg, 4 * C, bias=bg, epilogue=L.EPI_GEGLU, name=name + ".ff.geglu")
+        self.pool.put(n3)
+        h4 = self.gemm(g, net.lin(pre + "ff.net.2.weight"), C, bias=net.vec(pre + "ff.net.2.bias"), R=h3, name=name + ".ff.out")
+        self.pool.put(g); self.pool.put(h3)
+        return h4
+
+    def transformer2d(self, net, pre, x: Act, heads, ctx_kv, name) -> Act:
+        """Transformer2DModel.forward (transformer_2d.py:276-315): GN(eps 1e-6) -> 1x1 -> block -> 1x1 -> + input."""
+        B, T, C = x.B, x.H * x.W, x.C
+        gn = self.groupnorm(net, pre + "norm.", x, 1e-6, False, name + ".norm")
+        h = self.gemm(gn.tok, net.lin(pre + "proj_in.weight"), C, bias=net.vec(pre + "proj_in.bias"), name=name + ".proj_in")
+        self.free(gn)
+        i = 0
+        while net.has(f"{pre}transformer_blocks.{i}.norm1.weight"):
+            h = self.transformer_block(net, f"{pre}transformer_blocks.{i}.", h, B, T, C, heads, ctx_kv, f"{name}.tb{i}")
+            i += 1
+        out = self.new(x.B, x.H, x.W, C)
+        self.gemm(h, net.lin(pre + "proj_out.weight"), C, bias=net.vec(pre + "proj_out.bias"), R=x.tok, out=out.tok, name=name + ".proj_out")
+        self.pool.put(h)
+        return out
+
+    # ---- encoder (shared by ControlNet and UNet) ----------------------------------------------
+    def encoder(self, net, x0: Act, temb, ctx_kv, tag) -> Tuple[Act, List[Act]]:
+        """down blocks + mid block; returns (mid output, skip list incl. conv_in output)."""
+        cfg = self.cfg
+        skips = [x0]
+        x = x0
+        nblk = len(cfg["block_out_channels"])
+        for i in range(nblk):
+            has_attn = cfg["down_block_types"][i].startswith("CrossAttn")
+            for j in range(cfg["layers_per_block"]):
+                y = self.resnet(net, f"down_blocks.{i}.resnets.{j}.", x, temb, f"{tag}.d{i}.r{j}")
+                if has_attn:
+                    z = self.transformer2d(net, f"down_blocks.{i}.attentions.{j}.", y, heads_at(cfg, i), ctx_kv, f"{tag}.d{i}.a{j}")
+                    self.free(y)
+                    y = z
+                skips.append(y)
+                x = y
+            dk = f"down_blocks.{i}.downsamplers.0.conv."
+            if net.has(dk + "weight"):
+                Ho, Wo = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
+                y = self.new(x.B, Ho, Wo, x.C)
+                self.emit(O.Conv(x.bhwc, net.conv(dk + "weight"), y.bhwc, bias=net.vec(dk + "bias"), stride=(2, 2), pad=(1, 1), ws=self.ws, name=f"{tag}.d{i}.down"))
+                skips.append(y)
+                x = y
+        m = self.resnet(net, "mid_block.resnets.0.", x, temb, f"{tag}.mid.r0")
+        m2 = self.transformer2d(net, "mid_block.attentions.0.", m, heads_at(cfg, nblk - 1), ctx_kv, f"{tag}.mid.a0")
+        self.free(m)
+        m3 = self.resnet(net, "mid_block.resnets.1.", m2, temb, f"{tag}.mid.r1")
+        self.free(m2)
+        return m3, skips
+
+    def decoder(self, net, x: Act, skips: List[Act], temb, ctx_kv, tag) -> Act:
+        """up blocks (unet_2d_blocks.py:1886-2111) with explicit upsample sizes
+        (unet_2d_condition_multiview.py:491-516), then conv_norm_out + SiLU (:519-521)."""
+        cfg = self.cfg
+        nblk = len(cfg["block_out_channels"])
+        rev_heads = [heads_at(cfg, k) for k in reversed(range(nblk))]
+        for i in range(nblk):
+            has_attn = cfg["up_block_types"][i].startswith("CrossAttn")
+            for j in range(cfg["layers_per_block"] + 1):
+                s = skips.pop()
+                cat = self.new(x.B, x.H, x.W, x.C + s.C)
+                self.emit(O.Ew(L.EW_COPY, x.tok, cat.tok[:, :x.C], name=f"{tag}.u{i}.cat{j}a"))
+                self.emit(O.Ew(L.EW_COPY, s.tok, cat.tok[:, x.C:], name=f"{tag}.u{i}.cat{j}b"))
+                self.free(x); self.free(s)
+                y = self.resnet(net, f"up_blocks.{i}.resnets.{j}.", cat, temb, f"{tag}.u{i}.r{j}")
+                self.free(cat)
+                if has_attn:
+                    z = self.transformer2d(net, f"up_blocks.{i}.attentions.{j}.", y, rev_heads[i], ctx_kv, f"{tag}.u{i}.a{j}")
+                    self.free(y)
+                    y = z
+                x = y
+            uk = f"up_blocks.{i}.upsamplers.0.conv."
+            if net.has(uk + "weight"):
+                Ho, Wo = skips[-1].H, skips[-1].W          # next skip's size (forced interpolation size)
+                up = self.new(x.B, Ho, Wo, x.C)
+                self.emit(O.Upsample(x.bhwc, up.bhwc, PK.nearest_index(x.H, Ho).to(self.device), PK.nearest_index(x.W, Wo).to(self.device), name=f"{tag}.u{i}.nearest"))
+                self.free(x)
+                y = self.new(x.B, Ho, Wo, x.C)
+                self.emit(O.Conv(up.bhwc, net.conv(uk + "weight"), y.bhwc, bias=net.vec(uk + "bias"), ws=self.ws, name=f"{tag}.u{i}.upconv"))
+                self.free(up)
+                x = y
+        y = self.groupnorm(net, "conv_norm_out.", x, self.eps, True, f"{tag}.norm_out")
+        self.free(x)
+        return y
+
+
+class TembTable:
+    """fp32 [rows, sum(Cout)] table of time_emb_proj(silu(time_mlp(sinusoid(t)))) for every resnet of one network.
+    rows = DDIM steps (pipeline: row picked by the device-side step counter) or batch entries (module API)."""
+
+    def __init__(self, net: PackedNet, rows: int, device, per_sample: bool):
+        keys = [k for k in net.sd.keys() if k.endswith("time_emb_proj.weight")]
+        self.keys = keys
+        self.offset: Dict[str, int] = {}
+        off = 0
+        for k in keys:
+            self.offset[k] = off
+            off += net.sd[k].shape[0]
+        self.width = off
+        self.rows = rows
+        self.table = torch.zeros(rows, off, dtype=F32, device=device)
+        self.sel = torch.zeros(1, dtype=torch.int32, device=device)
+        self.sel_stride = 0 if per_sample else off
+        self.b_stride = off if per_sample else 0
+        self.t = torch.zeros(rows, dtype=F32, device=device)          # timesteps, filled by the caller
+
+    def emit_fill(self, bld: Builder, net: PackedNet, cfg):
+        """Ops that (re)compute the whole table from self.t."""
+        c0 = cfg["block_out_channels"][0]
+        dev = bld.device
+        sin = torch.empty(self.rows, c0, dtype=F32, device=dev)
+        bld.emit(O.TimeEmb(self.t, sin, flip_sin_to_cos=cfg["flip_sin_to_cos"], freq_shift=cfg["freq_shift"], name="temb.sin"))
+        h1 = torch.empty(self.rows, 4 * c0, dtype=F32, device=dev)
+        h2 = torch.empty(self.rows, 4 * c0, dtype=F32, device=dev)
+        act = torch.empty(self.rows, 4 * c0, dtype=BF16, device=dev)
+        as4 = lambda t: t.view(self.rows, 1, 1, t.shape[1])
+        w1 = net.lin("time_embedding.linear_1.weight"); w2 = net.lin("time_embedding.linear_2.weight")
+        bld.emit(O.Conv(as4(sin), w1.view(w1.shape[0], 1, 1, w1.shape[1]), as4(h1), bias=net.vec("time_embedding.linear_1.bias"),
+                        pad=(0, 0), epilogue=L.EPI_SILU, direct=True, name="temb.linear_1+silu"))
+        bld.emit(O.Conv(as4(h1), w2.view(w2.shape[0], 1, 1, w2.shape[1]), as4(h2), bias=net.vec("time_embedding.linear_2.bias"),
+                        pad=(0, 0), direct=True, name="temb.linear_2"))
+        bld.emit(O.Ew(L.EW_SILU, h2, act, name="temb.silu"))
+        wcat = net.cat_lin(self.keys)
+        bcat = net.cat_vec([k[:-len("weight")] + "bias" for k in self.keys])
+        bld.emit(O.Gemm(act, wcat, self.table, bias=bcat, name="temb.table"))
+        self._keep = (sin, h1, h2, act)
+
+
+def build_context_kv(bld: Builder, net: PackedNet, ctx: torch.Tensor, B: int, S: int) -> Dict[str, Tuple[torch.Tensor, torch.Tensor, int]]:
+    """attn2 K and V^T of every transformer block of `net`, from ctx [B, S, D] (step-invariant)."""
+    out = {}
+    D = ctx.shape[-1]
+    ldv = PK.round_up(S, 8)
+    for k in net.sd.keys():
+        if not k.endswith("attn2.to_k.weight"):
+            continue
+        pre = k[:-len("to_k.weight")]
+        C = net.sd[k].shape[0]
+        Kc = torch.empty(B, S, C, dtype=BF16, device=bld.device)
+        Vt = torch.zeros(B, C, ldv, dtype=BF16, device=bld.device)
+        bld.emit(O.Gemm(ctx.view(B * S, D), net.lin(k), Kc.view(B * S, C), ws=bld.ws, name=pre + "K"))
+        bld.emit(O.Gemm(net.lin(pre + "to_v.weight"), ctx, Vt[:, :, :S], name=pre + "vT"))
+        out[pre] = (Kc, Vt, S)
+    return out
