@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the MI355X-native MagicDrive sampler hot path.
+
+Metric (BASELINE.json): 6-view scenes/sec at 224x400, 50-step DDIM, on 1/2/4/8 MI355X.
+Workload at every N: BASELINE.json configs[1] — "6-view 224x400, text-only conditioning, 50-step DDIM, bf16":
+the reference's own degenerate mode `camera_param=None` (learned unconditional camera for all six views,
+CFG forced off: pipeline_bev_controlnet.py:260-264), no boxes, zero BEV map; SD-1.5-sized multi-view UNet +
+BEV-ControlNet with seeded random weights (no checkpoints exist offline), synthetic prompt embeddings.
+One bench "step" = one complete `pipe(...)` call: conditioning prologue + 50 denoising steps for
+`--scenes-per-gpu` scenes per rank, inputs resident in HBM, output_type="latent" (VAE decode and CLIP are
+outside the built hot path).  Weak scaling: every rank samples its own scenes; the only
+collective is the final all_gather of the result latents (RCCL), inside the timed region.
+
+Launch: `python bench.py` (1 GPU) or
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+
+
+def build_pipeline(cfg, device):
+    from magicdrive_amd import schedulers
+    from magicdrive_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiview
+    from magicdrive_amd.networks.unet_addon_rawbox import BEVControlNetModel
+    from magicdrive_amd.pipeline.pipeline_bev_controlnet import StableDiffusionBEVControlNetPipeline
+    unet = UNet2DConditionModelMultiview.from_config(cfg, seed=0)
+    cn = BEVControlNetModel.from_config(cfg, seed=1)
+    pipe = StableDiffusionBEVControlNetPipeline(unet=unet, controlnet=cn, scheduler=schedulers.DDIMScheduler())
+    return pipe.to(device), unet, cn
+
+
+def per_op_profile(plan, reps=3):
+    """HIP-event timing of every launch of the step program on the stream it is launched on."""
+    from magicdrive_amd import _lib as L, flops as FL
+    st = torch.cuda.current_stream().cuda_stream
+    lowered = [op.lower() for op in plan.step_ops]
+    n = len(lowered)
+    best = [float("inf")] * n
+    for _ in range(reps):
+        plan.step_ctr.zero_()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        evs[0].record()
+        for i, (code, desc) in enumerate(lowered):
+            L.call_op(code, desc, st)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        for i in range(n):
+            best[i] = min(best[i], evs[i].elapsed_time(evs[i + 1]))
+    fam = {}
+    rows = []
+    for op, ms in zip(plan.step_ops, best):
+        k = FL.kernel_family(op)
+        f = fam.setdefault(k, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+        f["ms"] += ms; f["flops"] += FL.op_flops(op); f["bytes"] += FL.op_bytes(op); f["launches"] += 1
+        rows.append({"name": getattr(op, "name", ""), "family": k, "ms": ms, "gflop": FL.op_flops(op) / 1e9})
+    return fam, rows
+
+
+def cpu_baseline(cfg, n_steps_timed=2):
+    """The CPU oracle (restatement of the reference's diffusers path, fp32) on this host's cores: one warm-up
+    denoise step + `n_steps_timed` timed steps of ONE scene of the same workload, extrapolated to 50 steps."""
+    from magicdrive_amd import synthetic
+    from magicdrive_amd.networks import spec
+    from oracle import denoiser as D
+    usd = spec.random_state_dict(spec.unet_param_shapes(cfg), 0)
+    csd = spec.random_state_dict(spec.controlnet_param_shapes(cfg), 1)
+    sc = synthetic.make_scene_batch(1, ctx_dim=cfg["cross_attention_dim"], max_len=None, zero_map=True)
+    n_cam = len(cfg["neighboring_view_pair"])
+    lat = torch.stack([sc["latents"]] * n_cam, 1)
+    cam = D.uncond_cam_param(csd, 1, n_cam)
+    cores = torch.get_num_threads()
+
+    def one_step(t):
+        with torch.no_grad():
+            d, m, ctx = D.controlnet_forward(csd, cfg, lat, torch.tensor([t]), cam, None, sc["prompt_embeds"], sc["bev_map"])
+            return D.unet_forward(usd, cfg, lat.reshape(-1, *lat.shape[2:]), t, ctx, d, m)
+    one_step(981)
+    t0 = time.perf_counter()
+    for i in range(n_steps_timed):
+        one_step(961 - 20 * i)
+    dt = (time.perf_counter() - t0) / n_steps_timed
+    return {"value": 1.0 / (50 * dt), "unit": "scenes/s", "cores": cores, "kind": "port",
+            "sample": f"1 scene, text-only config, {n_steps_timed} timed denoise steps after 1 warm-up ({dt:.2f} s/step, torch {torch.__version__} fp32), extrapolated x50"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scenes-per-gpu", type=int, default=4)
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-op-profile", action="store_true")
+    ap.add_argument("--ops-json", type=str, default="")
+    ap.add_argument("--full-cond", action="store_true", help="configs[2] shape: camera + 32 boxes + map + CFG 2.0 (parity-test config, not the headline)")
+    args = ap.parse_args()
+
+    from magicdrive_amd import distributed as DD
+    from magicdrive_amd import synthetic, flops as FL
+    from magicdrive_amd.networks import spec
+    rank, world, local = DD.init_from_env()
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    cfg = spec.SD15_CONFIG
+    pipe, unet, cn = build_pipeline(cfg, dev)
+    pipe.use_graph = not args.no_graph
+    b = args.scenes_per_gpu
+    n_total = b * world
+    mine = DD.shard_scenes(n_total, rank, world)
+    scenes = [synthetic.make_scene_batch(1, seed=1234 + i, max_len=(32 if args.full_cond else None), zero_map=not args.full_cond) for i in mine]
+    cat = lambda k: torch.cat([s[k] for s in scenes]).to(dev)
+    prompt, neg, bev, lat = cat("prompt_embeds"), cat("negative_prompt_embeds"), cat("bev_map"), cat("latents")
+    cam = cat("camera_param") if args.full_cond else None
+    boxes = {k: torch.cat([s["bboxes_3d_data"][k] for s in scenes]).to(dev) for k in ("bboxes", "classes", "masks")} if args.full_cond else None
+    gs = 2.0 if args.full_cond else 1.0
+
+    def one_call():
+        out = pipe(prompt=None, image=bev, camera_param=cam, height=224, width=400, num_inference_steps=args.ddim_steps,
+                   guidance_scale=gs, latents=lat, prompt_embeds=prompt, negative_prompt_embeds=neg, output_type="latent",
+                   bev_controlnet_kwargs={"bboxes_3d_data": boxes} if boxes is not None else {}).images
+        return DD.gather_scene_results(out, n_total, rank, world)
+
+    for _ in range(args.warmup):
+        res = one_call()
+    DD.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = one_call()
+    torch.cuda.synchronize(); DD.barrier()
+    dt = DD.max_over_ranks(time.perf_counter() - t0, dev)
+    assert torch.isfinite(res).all(), "non-finite latents"
+    scenes_per_s = n_total * args.steps / dt
+
+    if rank != 0:
+        return
+    plan = next(iter(pipe._plans.values()))
+    f_step = FL.program_flops(plan.step_ops)
+    f_pro = FL.program_flops(plan.prologue_ops)
+    f_scene = (args.ddim_steps * f_step["total"] + f_pro["total"]) / b          # per scene, incl. CFG duplication if any
+    out = {
+        "metric": "6-view scenes/sec at 224x400, 50-step DDIM", "value": scenes_per_s, "unit": "scenes/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": ("configs[2]: 6-view 224x400, camera+32 boxes+BEV map, CFG 2.0" if args.full_cond else
+                                "configs[1]: 6-view 224x400, text-only conditioning (camera_param=None -> CFG off), 50-step DDIM, bf16"),
+                   "scenes_per_gpu": b, "ddim_steps": args.ddim_steps, "unet_params_M": round(unet.num_parameters() / 1e6, 1),
+                   "controlnet_params_M": round(cn.num_parameters() / 1e6, 1), "parallelism": f"scene-sharded x{world}",
+                   "hipgraph": pipe.use_graph, "output_type": "latent",
+                   "tflop_per_scene": round(f_scene / 1e12, 3),
+                   "mfma_frac_end_to_end": round(f_scene * scenes_per_s / world / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
+    }
+    if not args.no_op_profile:
+        fam, rows = per_op_profile(plan)
+        dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
+        name, d = dom
+        compute = {k: v for k, v in fam.items() if v["flops"] > 0 and k.startswith(("gemm_conv", "attn"))}
+        if name.startswith(("gemm_conv", "attn")):
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                               "launches_per_step": d["launches"], "avg_launch_us": 1e3 * d["ms"] / d["launches"]}
+        else:
+            ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                               "traffic": None, "launches_per_step": d["launches"], "avg_launch_us": 1e3 * d["ms"] / d["launches"]}
+        out["roofline"]["per_family"] = {k: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"],
+                                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None}
+                                         for k, v in fam.items()}
+        tot_ms = sum(v["ms"] for v in compute.values()); tot_fl = sum(v["flops"] for v in compute.values())
+        out["roofline"]["attn_conv_gemm_tflops"] = round(tot_fl / (tot_ms * 1e-3) / 1e12, 2)
+        if args.ops_json:
+            os.makedirs(os.path.dirname(args.ops_json) or ".", exist_ok=True)
+            with open(args.ops_json, "w") as f:
+                json.dump(rows, f)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,171 @@
+"""Common host-side behaviour of the two network classes: config + reference-layout state dict,
+`from_pretrained` / `save_pretrained` in the diffusers directory layout the reference uses
+(`<dir>/config.json` + `diffusion_pytorch_model.(safetensors|bin)`), `.to()`, `.dtype`.
+
+The classes hold weights as a plain state dict (reference key names); the arithmetic lives in libmdx
+programs built by magicdrive_amd.denoiser.  There is deliberately no nn.Module forward to fall back to.
+"""
+from __future__ import annotations
+
+import copy
+import json
+import os
+from collections import OrderedDict
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import torch
+
+from ..engine import PackedNet
+from . import spec
+
+WEIGHTS_BIN = "diffusion_pytorch_model.bin"
+WEIGHTS_ST = "diffusion_pytorch_model.safetensors"
+CONFIG_NAME = "config.json"
+
+_ARCH_KEYS = ("in_channels", "out_channels", "flip_sin_to_cos", "freq_shift", "down_block_types", "up_block_types",
+              "block_out_channels", "layers_per_block", "norm_num_groups", "norm_eps", "cross_attention_dim", "attention_head_dim")
+
+
+def arch_config_from_json(js: Dict, base: Optional[Dict] = None) -> Dict:
+    """diffusers config.json -> our cfg dict (unknown keys ignored, missing keys = SD-1.5 defaults)."""
+    cfg = copy.deepcopy(base or spec.SD15_CONFIG)
+    for k in _ARCH_KEYS:
+        if k in js and js[k] is not None:
+            v = js[k]
+            cfg[k] = tuple(v) if isinstance(v, list) else v
+    if js.get("neighboring_view_pair"):
+        cfg["neighboring_view_pair"] = {int(k): [int(x) for x in v] for k, v in js["neighboring_view_pair"].items()}
+    for k in ("neighboring_attn_type", "zero_module_type"):
+        if k in js:
+            cfg[k] = js[k]
+    unsupported = {"use_linear_projection": False, "only_cross_attention": False, "dual_cross_attention": False,
+                   "class_embed_type": None, "addition_embed_type": None, "resnet_time_scale_shift": "default",
+                   "upcast_attention": False, "center_input_sample": False}
+    for k, ok in unsupported.items():
+        if k in js and js[k] not in (ok, None) and js[k] != ok:
+            raise NotImplementedError(f"config option {k}={js[k]!r} is outside the built hot path (SD-1.5 MagicDrive uses {ok!r})")
+    cn = cfg["controlnet"]
+    for k in ("camera_in_dim", "camera_out_dim", "map_size", "conditioning_embedding_out_channels", "uncond_cam_in_dim"):
+        if k in js and js[k] is not None:
+            cn[k] = tuple(js[k]) if isinstance(js[k], list) else js[k]
+    if "cam_embedder_param" in js and js["cam_embedder_param"]:
+        cn["cam_embedder_num_freqs"] = js["cam_embedder_param"].get("num_freqs", cn["cam_embedder_num_freqs"])
+    if "bbox_embedder_param" in js and js["bbox_embedder_param"]:
+        bp = js["bbox_embedder_param"]
+        for k in ("n_classes", "class_token_dim", "embedder_num_freq"):
+            if k in bp:
+                cn["bbox"][k] = bp[k]
+        if "proj_dims" in bp:
+            cn["bbox"]["proj_dims"] = tuple(bp["proj_dims"])
+    return cfg
+
+
+class MdxModel:
+    """Base of UNet2DConditionModelMultiview / BEVControlNetModel."""
+
+    _shape_fn = None          # staticmethod(cfg) -> OrderedDict name -> shape
+
+    def __init__(self, cfg: Dict, state_dict: Dict[str, torch.Tensor], torch_dtype=torch.bfloat16):
+        self.cfg = copy.deepcopy(cfg)
+        shapes = type(self)._shape_fn(self.cfg)
+        missing = [k for k in shapes if k not in state_dict]
+        if missing:
+            raise KeyError(f"{type(self).__name__}: state dict lacks {len(missing)} tensors, e.g. {missing[:4]}")
+        for k, shp in shapes.items():
+            if tuple(state_dict[k].shape) != tuple(shp):
+                raise ValueError(f"{type(self).__name__}: {k} has shape {tuple(state_dict[k].shape)}, config implies {tuple(shp)}")
+        self._sd = OrderedDict((k, state_dict[k].detach()) for k in shapes)
+        self._dtype = torch_dtype
+        self._device = torch.device("cpu")
+        self._packed: Optional[PackedNet] = None
+        self._plans: Dict[tuple, object] = {}
+        self.config = SimpleNamespace(**{k: v for k, v in self.cfg.items() if k != "controlnet"})
+        self.training = False
+
+    # ---- construction ----
+    @classmethod
+    def from_config(cls, cfg: Dict, seed: int = 0, torch_dtype=torch.bfloat16):
+        """Seeded random weights of the given architecture (no pretrained weights exist offline)."""
+        return cls(cfg, spec.random_state_dict(cls._shape_fn(cfg), seed), torch_dtype)
+
+    @classmethod
+    def from_pretrained(cls, path: str, torch_dtype=torch.bfloat16, subfolder: Optional[str] = None, **unused):
+        d = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(d, CONFIG_NAME)) as f:
+            js = json.load(f)
+        cfg = arch_config_from_json(js)
+        if os.path.exists(os.path.join(d, WEIGHTS_ST)):
+            from safetensors.torch import load_file
+            sd = load_file(os.path.join(d, WEIGHTS_ST))
+        elif os.path.exists(os.path.join(d, WEIGHTS_BIN)):
+            sd = torch.load(os.path.join(d, WEIGHTS_BIN), map_location="cpu")
+        else:
+            raise FileNotFoundError(f"no {WEIGHTS_ST} / {WEIGHTS_BIN} under {d}")
+        return cls(cfg, sd, torch_dtype)
+
+    def save_pretrained(self, path: str, safe_serialization: bool = True):
+        os.makedirs(path, exist_ok=True)
+        js = {k: (list(v) if isinstance(v, tuple) else v) for k, v in self.cfg.items() if k != "controlnet"}
+        js["neighboring_view_pair"] = {str(k): v for k, v in self.cfg["neighboring_view_pair"].items()}
+        js["_class_name"] = type(self).__name__
+        self._extra_config(js)
+        with open(os.path.join(path, CONFIG_NAME), "w") as f:
+            json.dump(js, f, indent=2)
+        sd = {k: v.contiguous() for k, v in self._sd.items()}
+        if safe_serialization:
+            from safetensors.torch import save_file
+            save_file(sd, os.path.join(path, WEIGHTS_ST))
+        else:
+            torch.save(sd, os.path.join(path, WEIGHTS_BIN))
+
+    def _extra_config(self, js):
+        pass
+
+    # ---- torch-module-like surface the reference's callers touch ----
+    def state_dict(self):
+        return self._sd
+
+    def eval(self):
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("magicdrive_amd builds the inference hot path only")
+        return self
+
+    def requires_grad_(self, flag: bool = False):
+        return self
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def device(self):
+        return self._device
+
+    def to(self, *args, **kw):
+        for a in list(args) + list(kw.values()):
+            if isinstance(a, torch.dtype):
+                if a not in (torch.bfloat16, torch.float16, torch.float32):
+                    raise ValueError(a)
+                self._dtype = a          # API dtype of inputs/outputs; kernels compute in bf16 with fp32 accumulate
+            elif isinstance(a, (str, torch.device)):
+                dev = torch.device(a)
+                if dev != self._device:
+                    self._device = dev
+                    self._packed = None
+                    self._plans.clear()
+        return self
+
+    def cuda(self, index: int = 0):
+        return self.to(torch.device("cuda", index))
+
+    def packed(self) -> PackedNet:
+        if self._packed is None:
+            self._packed = PackedNet(self._sd, self._device)
+        return self._packed
+
+    def num_parameters(self) -> int:
+        return sum(v.numel() for v in self._sd.values())

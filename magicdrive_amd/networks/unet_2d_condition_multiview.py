@@ -1,0 +1,46 @@
+"""UNet2DConditionModelMultiview — drop-in for magicdrive/networks/unet_2d_condition_multiview.py.
+
+Same checkpoint layout, same forward signature and return object (.sample) as the reference class
+(:327-339, 524-527); the forward runs a libmdx op program (magicdrive_amd.denoiser.UNetPlan).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional, Sequence
+
+import torch
+
+from ..denoiser import UNetPlan
+from . import spec
+from .base import MdxModel
+
+
+class UNet2DConditionOutput(SimpleNamespace):
+    """.sample like diffusers' UNet2DConditionOutput (unet_2d_condition.py:37-45)."""
+
+
+class UNet2DConditionModelMultiview(MdxModel):
+    _shape_fn = staticmethod(spec.unet_param_shapes)
+
+    @torch.no_grad()
+    def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, class_labels=None,
+                timestep_cond=None, attention_mask=None, cross_attention_kwargs=None,
+                down_block_additional_residuals: Optional[Sequence[torch.Tensor]] = None,
+                mid_block_additional_residual: Optional[torch.Tensor] = None, return_dict: bool = True):
+        if class_labels is not None or timestep_cond is not None or attention_mask is not None:
+            raise NotImplementedError("class_labels / timestep_cond / attention_mask are unused by MagicDrive's sampler")
+        if self._device.type != "cuda":
+            raise RuntimeError("UNet2DConditionModelMultiview.forward needs .to('cuda'): there is no CPU path")
+        B, _, h, w = sample.shape
+        S = encoder_hidden_states.shape[1]
+        with_res = down_block_additional_residuals is not None
+        key = (B, S, h, w, with_res)
+        if key not in self._plans:
+            self._plans[key] = UNetPlan(self.cfg, self.packed(), self._device, B, S, (h, w), with_residuals=with_res)
+        out = self._plans[key].run(sample, timestep, encoder_hidden_states, down_block_additional_residuals, mid_block_additional_residual)
+        out = out.to(sample.dtype if sample.is_floating_point() else self._dtype).clone()
+        if not return_dict:
+            return (out,)
+        return UNet2DConditionOutput(sample=out)
+
+    __call__ = forward

@@ -1,0 +1,260 @@
+"""StableDiffusionBEVControlNetPipeline — drop-in for magicdrive/pipeline/pipeline_bev_controlnet.py.
+
+`__call__` keeps the reference signature (:115-141) and return contract (:466-498: `.images` is
+List[List[PIL]] (B x N_cam) for output_type="pil", ndarray (B,N,H,W,3) for "np", latents (B,N,4,h,w) for
+"latent").  The 50-step loop (:349-451) — BEV-ControlNet, multi-view UNet, CFG combine, scheduler step — is
+one libmdx op program per step (magicdrive_amd.denoiser.SamplerPlan), replayed as a hipGraph; everything
+timestep-independent runs once in a prologue program.
+
+Scope notes: CLIP text encoding and the VAE decode are outside the built hot path; they are
+used as ordinary torch modules when the caller supplies them (`prompt_embeds=` / `output_type="latent"`
+bypass them).  The fused scheduler is DDIM eta=0 (the north-star config); other schedulers raise.
+"""
+from __future__ import annotations
+
+import inspect
+import json
+import os
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional, Union
+
+import numpy as np
+import torch
+
+from ..denoiser import SamplerPlan
+from ..schedulers import DDIMScheduler
+
+
+@dataclass
+class BEVStableDiffusionPipelineOutput:
+    images: Union[List[List[Any]], np.ndarray, torch.Tensor]
+    nsfw_content_detected: Optional[List[bool]]
+
+
+class _NullBar:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def update(self, n=1):
+        pass
+
+
+class StableDiffusionBEVControlNetPipeline:
+    def __init__(self, vae=None, text_encoder=None, unet=None, controlnet=None, scheduler=None, tokenizer=None,
+                 safety_checker=None, feature_extractor=None, requires_safety_checker: bool = False):
+        assert safety_checker is None, "Please do not use safety_checker."          # pipeline_bev_controlnet.py:63
+        self.vae, self.text_encoder, self.unet, self.controlnet = vae, text_encoder, unet, controlnet
+        self.scheduler = scheduler if scheduler is not None else DDIMScheduler()
+        self.tokenizer = tokenizer
+        self.vae_scale_factor = 8
+        self._progress_bar_config: Dict[str, Any] = {}
+        self._device = torch.device("cpu")
+        self._plans: Dict[tuple, SamplerPlan] = {}
+        self.use_graph = True
+
+    # ---- construction / housekeeping the reference's callers use (misc/test_utils.py:94-138) ----
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, controlnet=None, unet=None, safety_checker=None,
+                        feature_extractor=None, torch_dtype=torch.bfloat16, vae=None, text_encoder=None, tokenizer=None, **kw):
+        root = pretrained_model_name_or_path
+        sch = DDIMScheduler()
+        p = os.path.join(root, "scheduler", "scheduler_config.json")
+        if os.path.exists(p):
+            with open(p) as f:
+                sch = DDIMScheduler.from_config(json.load(f))
+        if text_encoder is None and os.path.isdir(os.path.join(root, "text_encoder")):
+            import transformers
+            text_encoder = transformers.CLIPTextModel.from_pretrained(os.path.join(root, "text_encoder")).eval()
+            tokenizer = transformers.CLIPTokenizer.from_pretrained(os.path.join(root, "tokenizer"))
+        return cls(vae=vae, text_encoder=text_encoder, unet=unet, controlnet=controlnet, scheduler=sch, tokenizer=tokenizer)
+
+    def to(self, device):
+        self._device = torch.device(device)
+        for m in (self.unet, self.controlnet):
+            if m is not None:
+                m.to(self._device)
+        for m in (self.vae, self.text_encoder):
+            if m is not None and hasattr(m, "to"):
+                m.to(self._device)
+        self._plans.clear()
+        return self
+
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def _execution_device(self):
+        return self._device
+
+    def enable_xformers_memory_efficient_attention(self, *a, **k):
+        """Accepted for call-site compatibility (misc/test_utils.py:131-132); attention is always the fused HIP kernel."""
+
+    def enable_vae_slicing(self):
+        if self.vae is not None and hasattr(self.vae, "enable_slicing"):
+            self.vae.enable_slicing()
+
+    def set_progress_bar_config(self, **kwargs):
+        self._progress_bar_config = kwargs
+
+    def progress_bar(self, iterable=None, total=None):
+        if self._progress_bar_config.get("disable", True):
+            return _NullBar() if iterable is None else iterable
+        from tqdm.auto import tqdm
+        return tqdm(iterable, **self._progress_bar_config) if iterable is not None else tqdm(total=total, **self._progress_bar_config)
+
+    # ---- helpers with the behaviour of pipeline_controlnet.py:285-437, 634-680 ----
+    def _encode_prompt(self, prompt, device, num_images_per_prompt, do_cfg, negative_prompt=None, prompt_embeds=None, negative_prompt_embeds=None):
+        if prompt_embeds is None:
+            if self.text_encoder is None or self.tokenizer is None:
+                raise ValueError("pass prompt_embeds= (and negative_prompt_embeds=) or construct the pipeline with text_encoder + tokenizer")
+            prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+            tok = self.tokenizer(prompts, padding="max_length", max_length=self.tokenizer.model_max_length, truncation=True, return_tensors="pt")
+            prompt_embeds = self.text_encoder(tok.input_ids.to(device))[0]
+        bs = prompt_embeds.shape[0]
+        prompt_embeds = prompt_embeds.repeat_interleave(num_images_per_prompt, dim=0)
+        if do_cfg:
+            if negative_prompt_embeds is None:
+                if self.text_encoder is None or self.tokenizer is None:
+                    raise ValueError("classifier-free guidance needs negative_prompt_embeds= when no text encoder is attached")
+                neg = [""] * bs if negative_prompt is None else ([negative_prompt] * bs if isinstance(negative_prompt, str) else list(negative_prompt))
+                tok = self.tokenizer(neg, padding="max_length", max_length=prompt_embeds.shape[1], truncation=True, return_tensors="pt")
+                negative_prompt_embeds = self.text_encoder(tok.input_ids.to(device))[0]
+            negative_prompt_embeds = negative_prompt_embeds.repeat_interleave(num_images_per_prompt, dim=0)
+        return prompt_embeds, negative_prompt_embeds
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        """pipeline_controlnet.py:665-680 + utils/torch_utils.py:36-77: drawn on the generator's device (CPU by
+        default, so seeds are device independent), then moved."""
+        shape = (batch_size, num_channels_latents, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if latents is None:
+            gdev = generator.device if isinstance(generator, torch.Generator) else torch.device("cpu")
+            latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype)
+        else:
+            assert tuple(latents.shape) == shape, f"latents {tuple(latents.shape)} != {shape}"
+        return latents.to(device) * self.scheduler.init_noise_sigma
+
+    def prepare_extra_step_kwargs(self, generator, eta):
+        """Same guard as the reference (:82-98): a scheduler whose step() takes `generator` is refused."""
+        params = set(inspect.signature(self.scheduler.step).parameters.keys())
+        if "generator" in params:
+            raise RuntimeError("If you fixed the logic for generator, please remove this. Otherwise, please use other sampler.")
+        return {"eta": eta} if "eta" in params else {}
+
+    def decode_latents(self, latents):
+        """pipeline_bev_controlnet.py:100-112 (5-D latents); VAE is a caller-supplied torch module."""
+        if self.vae is None:
+            raise ValueError("no VAE attached: use output_type='latent' or pass vae= to the pipeline")
+        sf = getattr(getattr(self.vae, "config", None), "scaling_factor", 0.18215)
+        bs = latents.shape[0]
+        x = (latents / sf).reshape(-1, *latents.shape[2:])
+        vdt = next(self.vae.parameters()).dtype
+        image = self.vae.decode(x.to(vdt)).sample
+        image = image.reshape(bs, -1, *image.shape[1:])
+        image = (image / 2 + 0.5).clamp(0, 1)
+        return image.cpu().permute(0, 1, 3, 4, 2).float().numpy()
+
+    @staticmethod
+    def numpy_to_pil_double(images):
+        from PIL import Image
+        out = []
+        for imgs in images:
+            arr = (imgs * 255).round().astype("uint8")
+            out.append([Image.fromarray(a) for a in arr])
+        return out
+
+    # ---- the sampler ----
+    @torch.no_grad()
+    def __call__(self, prompt: Union[str, List[str], None], image: torch.Tensor, camera_param: Optional[torch.Tensor],
+                 height: int, width: int, num_inference_steps: int = 50, guidance_scale: float = 7.5,
+                 negative_prompt: Optional[Union[str, List[str]]] = None, num_images_per_prompt: Optional[int] = 1,
+                 eta: float = 0.0, generator: Optional[torch.Generator] = None, latents: Optional[torch.Tensor] = None,
+                 prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
+                 output_type: Optional[str] = "pil", return_dict: bool = True,
+                 callback: Optional[Callable[[int, int, torch.Tensor], None]] = None, callback_steps: int = 1,
+                 cross_attention_kwargs: Optional[Dict[str, Any]] = None, controlnet_conditioning_scale: float = 1,
+                 guess_mode: bool = False, use_zero_map_as_unconditional: bool = False, bev_controlnet_kwargs={},
+                 bbox_max_length=None):
+        if guess_mode:
+            raise NotImplementedError("guess_mode is outside the built hot path")
+        if eta != 0.0:
+            raise NotImplementedError("the fused sampler is deterministic DDIM (eta = 0)")
+        if not isinstance(self.scheduler, DDIMScheduler):
+            raise NotImplementedError(f"{type(self.scheduler).__name__}: only magicdrive_amd.schedulers.DDIMScheduler has a fused step (UniPC is the next row, SURVEY.md §8f.2)")
+        if self._device.type != "cuda":
+            raise RuntimeError("pipeline.to('cuda') first: the sampler has no CPU path")
+        device = self._device
+        if prompt is not None and isinstance(prompt, str):
+            batch_size = 1
+        elif prompt is not None and isinstance(prompt, list):
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        do_cfg = guidance_scale > 1.0
+        n_cam = len(self.unet.cfg["neighboring_view_pair"])
+        if camera_param is None:                                       # :260-264
+            camera_param = self.controlnet.uncond_cam_param((batch_size, n_cam))
+            do_cfg = False
+        prompt_embeds, negative_prompt_embeds = self._encode_prompt(prompt, device, num_images_per_prompt, do_cfg, negative_prompt,
+                                                                    prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds)
+        b = batch_size * num_images_per_prompt
+        image = image.to(device, torch.float32)
+        if image.shape[0] == 1 and b > 1:
+            image = image.expand(b, *image.shape[1:])
+        assert image.shape[0] == b, f"image batch {image.shape[0]} != {b}"
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        timesteps = self.scheduler.timesteps
+        num_channels_latents = self.unet.config.in_channels
+        latents = self.prepare_latents(b, num_channels_latents, height, width, prompt_embeds.dtype, device, generator, latents)
+        self.prepare_extra_step_kwargs(generator, eta)
+        assert camera_param.shape[0] == batch_size, f"Except {batch_size} camera params, but you have bs={len(camera_param)}"
+        n_cam = camera_param.shape[1]
+        latents = torch.stack([latents] * n_cam, dim=1)                 # the SAME noise for every view (:326)
+        camera_param = camera_param.to(device)
+        boxes = dict(bev_controlnet_kwargs).get("bboxes_3d_data", None)
+        text = prompt_embeds
+        if do_cfg:
+            kw = self.controlnet.add_uncond_to_kwargs(camera_param=camera_param, image=image, max_len=bbox_max_length,
+                                                      bboxes_3d_data=boxes)
+            camera_param, boxes = kw["camera_param"], kw["bboxes_3d_data"]
+            uncond_image = torch.zeros_like(image) if use_zero_map_as_unconditional else kw["image"]
+            image = torch.cat([uncond_image, image])
+            text = torch.cat([negative_prompt_embeds.to(device), prompt_embeds.to(device)])
+        elif boxes is not None and bbox_max_length is not None and boxes["bboxes"].shape[2] < bbox_max_length:
+            raise NotImplementedError("bbox_max_length padding without CFG")
+        L_box = 0 if boxes is None else int(boxes["bboxes"].shape[2])
+        h, w = latents.shape[-2:]
+        key = (b, do_cfg, L_box, h, w, num_inference_steps, float(guidance_scale), float(controlnet_conditioning_scale), text.shape[1])
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = SamplerPlan(self.unet.cfg, self.unet.packed(), self.controlnet.packed(), device, b, do_cfg, L_box, (h, w),
+                               num_steps=num_inference_steps, guidance_scale=guidance_scale,
+                               conditioning_scale=float(controlnet_conditioning_scale), n_text=text.shape[1])
+            plan.compile()
+            self._plans[key] = plan
+        plan.load_inputs(latents, camera_param, text, image, boxes, timesteps, self.scheduler.coefficient_table())
+        st = torch.cuda.current_stream().cuda_stream
+        plan.prologue.run(st)
+        with self.progress_bar(total=num_inference_steps) as bar:
+            for i, t in enumerate(timesteps):
+                if self.use_graph:
+                    plan.step.launch(st)
+                else:
+                    plan.step.run(st)
+                bar.update()
+                if callback is not None and i % callback_steps == 0:
+                    callback(i, t, plan.latents().to(prompt_embeds.dtype))
+        latents = plan.latents().to(prompt_embeds.dtype)
+        if output_type == "latent":
+            out, nsfw = latents, None
+        else:
+            out = self.decode_latents(latents)
+            nsfw = None
+            if output_type == "pil":
+                out = self.numpy_to_pil_double(out)
+        if not return_dict:
+            return (out, nsfw)
+        return BEVStableDiffusionPipelineOutput(images=out, nsfw_content_detected=nsfw)

@@ -84,3 +84,31 @@ def test_sampler_loop_tiny(dev, tiny, do_cfg, Lb):
     # and is deterministic run to run
     sp.load_inputs(lat6, cam, text, bev, boxes, ts, sch.coefficient_table())
     assert torch.equal(sp.run(use_graph=True).cpu(), eager)
+
+
+def test_real_size_one_pass_sd15(dev):
+    """SD-1.5-sized networks (921.5 M + 363.0 M params), one scene, 32 boxes/view, distinct noise per view:
+    ControlNet + UNet forward of the HIP path vs the CPU oracle on the same bf16-rounded weights."""
+    cfg = spec.SD15_CONFIG
+    usd, csd = state_dicts(cfg)
+    nb, Lb, hw = 1, 32, (28, 50)
+    sc = scene(cfg, nb, Lb, hw)
+    g = torch.Generator().manual_seed(11)
+    lat = torch.randn(nb, 6, 4, *hw, generator=g)
+    t = torch.tensor([501])
+    with torch.no_grad():
+        d, m, ctx = D.controlnet_forward(bf16_round(csd), cfg, lat, t, sc["camera_param"], sc["bboxes_3d_data"], sc["prompt_embeds"], sc["bev_map"])
+        e = D.unet_forward(bf16_round(usd), cfg, lat.reshape(-1, 4, *hw), 501, ctx, d, m)
+    cn = PackedNet(csd, dev); un = PackedNet(usd, dev)
+    cp = DN.ControlNetPlan(cfg, cn, dev, nb, Lb, hw)
+    down, mid, ctx_g = cp.run(lat, t, sc["camera_param"], sc["bboxes_3d_data"], sc["prompt_embeds"], sc["bev_map"])
+    torch.cuda.synchronize()
+    assert rel_l2(ctx_g, ctx) < 1e-2
+    errs = [per_view_max_rel(a, b_) for a, b_ in zip(down, d)] + [per_view_max_rel(mid, m)]
+    assert max(errs) < 3e-2, errs
+    up = DN.UNetPlan(cfg, un, dev, nb * 6, ctx.shape[1], hw)
+    out = up.run(lat.reshape(-1, 4, *hw), 501, ctx, d, m)
+    torch.cuda.synchronize()
+    err = per_view_max_rel(out, e)
+    print(f"[sd15 one pass] controlnet residual max rel {max(errs):.4f}; eps per-view max rel {err:.4f}")
+    assert err < 3e-2, err
