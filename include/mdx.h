@@ -223,13 +223,16 @@ int mdx_timestep_embedding(const MdxTimeEmbDesc* d, void* stream);
  * coef: fp32 [n_steps][4] = {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)}; row = *step_ptr.
  * eps holds [uncond | cond] halves of n elements each when cfg != 0.  After the update the
  * kernel increments *step_ptr (single thread) so a replayed graph walks the table, and also
- * refreshes the bf16/fp32 model-input copy(ies) `x_in` (n elements, duplicated for CFG).
+ * refreshes the model-input copy(ies) `x_in` (duplicated [uncond | cond] for CFG):
+ *   xin_ld == 0 : x_in is fp32, flat, same layout as x;
+ *   xin_ld  > 0 : x_in is bf16 channels-last with pixel stride xin_ld >= xin_c (x has xin_c channels per
+ *                 pixel; the pad channels are never written) — the layout conv_in's MFMA path reads.
  */
 typedef struct MdxDdimDesc {
-    float* x; const float* eps; const float* coef; int32_t* step_ptr; float* x_in; void* reserved_p;
+    float* x; const float* eps; const float* coef; int32_t* step_ptr; void* x_in; void* reserved_p;
     int64_t n, cfg;
     double guidance;
-    int64_t reserved0;
+    int64_t xin_c, xin_ld;
 } MdxDdimDesc;
 int mdx_cfg_ddim_step(const MdxDdimDesc* d, void* stream);
 

@@ -48,7 +48,7 @@ MdxEwDesc = _struct("MdxEwDesc", _f(P, "X Y ymap xmap") + _f(I, "kind M C ldx ld
 MdxFourierDesc = _struct("MdxFourierDesc", _f(P, "X Y mask null_feat") + _f(I, "n P F ldy"))
 MdxGatherDesc = _struct("MdxGatherDesc", _f(P, "T Y idx mask null_row reserved_p") + _f(I, "n C ldt ldy n_rows reserved0"))
 MdxTimeEmbDesc = _struct("MdxTimeEmbDesc", _f(P, "t Y") + _f(I, "n dim flip_sin_to_cos ldy") + _f(D, "freq_shift max_period"))
-MdxDdimDesc = _struct("MdxDdimDesc", _f(P, "x eps coef step_ptr x_in reserved_p") + _f(I, "n cfg") + _f(D, "guidance") + _f(I, "reserved0"))
+MdxDdimDesc = _struct("MdxDdimDesc", _f(P, "x eps coef step_ptr x_in reserved_p") + _f(I, "n cfg") + _f(D, "guidance") + _f(I, "xin_c xin_ld"))
 
 DESC_OF_OP = {
     OP_GEMM: MdxGemmDesc, OP_CONV: MdxConvDesc, OP_CONV_DIRECT: MdxConvDirectDesc, OP_ATTN: MdxAttnDesc,

@@ -135,26 +135,31 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
                 }
             }
             // ---- online softmax (this lane: one query, 32 of the 64 kv) ----
+            // raw scores stay unscaled: max on raw values (scale > 0), then one fma + one v_exp per score.
+            if (j0 + KVT > p.Tk) {                 // only the last tile has kv >= Tk to mask (wave-uniform branch)
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int kv = j0 + sub * 32 + mfma32_row(r, lane);
+                        if (kv >= p.Tk) sacc[sub][r] = -INFINITY;
+                    }
+            }
             float mx = -INFINITY;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int kv = j0 + sub * 32 + mfma32_row(r, lane);
-                    float sv = kv < p.Tk ? sacc[sub][r] * p.scale_log2 : -INFINITY;
-                    sacc[sub][r] = sv;
-                    mx = fmaxf(mx, sv);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[sub][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;
             const float m_new = fmaxf(m_run, mx);       // finite: every tile has >= 1 valid kv
-            const float alpha = exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
             m_run = m_new;
             float psum = 0.f;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float pv = exp2f(sacc[sub][r] - m_new);
+                    float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[sub][r], p.scale_log2, -m_new));
                     sacc[sub][r] = pv;
                     psum += pv;
                 }
@@ -237,7 +242,7 @@ static int launch_attn_nw(const AttnParams& p, hipStream_t st) {
     // 4 waves (128 queries) per workgroup when there are enough rows to fill 256 CUs, else
     // smaller workgroups so short sequences (91, 28 tokens) still spread over the chip.
     long blocks4 = (long)((p.Tq + 127) / 128) * p.H * p.B;
-    if (p.Tq >= 256 && blocks4 >= 256) return launch_attn<D16, 4>(p, st);
+    if (p.Tq >= 256 && blocks4 >= 4096) return launch_attn<D16, 4>(p, st);
     if (p.Tq >= 64) return launch_attn<D16, 2>(p, st);
     return launch_attn<D16, 1>(p, st);
 }

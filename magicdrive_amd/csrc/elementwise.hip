@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void timeemb_kernel(TimeEmbParams p) {
     if (p.y_f32) ((float*)p.Y)[i * p.ldy + j] = out; else ((bf16_t*)p.Y)[i * p.ldy + j] = f2bf(out);
 }
 
-struct DdimParams { float* x; const float* eps; const float* coef; int* step; float* x_in; long n; int cfg; float g; };
+struct DdimParams { float* x; const float* eps; const float* coef; int* step; void* x_in; long n; int cfg; float g; int xin_c, xin_ld; };
 
 __global__ __launch_bounds__(256) void ddim_kernel(DdimParams p) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -301,8 +301,18 @@ __global__ __launch_bounds__(256) void ddim_kernel(DdimParams p) {
         float xn = c[2] * x0 + c[3] * e;
         p.x[i] = xn;
         if (p.x_in) {
-            p.x_in[i] = xn;
-            if (p.cfg) p.x_in[p.n + i] = xn;
+            if (p.xin_ld > 0) {          // bf16 channels-last copy with padded pixel stride
+                long px = i / p.xin_c;
+                int c = (int)(i - px * p.xin_c);
+                bf16_t* xi = (bf16_t*)p.x_in;
+                bf16_t v = f2bf(xn);
+                xi[px * p.xin_ld + c] = v;
+                if (p.cfg) xi[(p.n / p.xin_c + px) * p.xin_ld + c] = v;
+            } else {
+                float* xi = (float*)p.x_in;
+                xi[i] = xn;
+                if (p.cfg) xi[p.n + i] = xn;
+            }
         }
     }
 }
@@ -400,7 +410,8 @@ extern "C" int mdx_timestep_embedding(const MdxTimeEmbDesc* d, void* stream) {
 
 extern "C" int mdx_cfg_ddim_step(const MdxDdimDesc* d, void* stream) {
     if (!d || !d->x || !d->eps || !d->coef || !d->step_ptr) return set_error(MDX_EINVAL, "mdx_cfg_ddim_step: null operand");
-    DdimParams p{d->x, d->eps, d->coef, d->step_ptr, d->x_in, d->n, (int)d->cfg, (float)d->guidance};
+    DdimParams p{d->x, d->eps, d->coef, d->step_ptr, d->x_in, d->n, (int)d->cfg, (float)d->guidance, (int)d->xin_c, (int)d->xin_ld};
+    if (p.xin_ld > 0 && (p.xin_c <= 0 || p.xin_ld < p.xin_c || p.n % p.xin_c)) return set_error(MDX_EINVAL, "ddim: bad x_in channel layout");
     if (p.n <= 0) return MDX_OK;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(ddim_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);

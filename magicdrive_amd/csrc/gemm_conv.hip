@@ -311,7 +311,7 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MDX_OK;
     const bool geglu = p.epi == 1;
     int BN = 128;
-    if (!geglu && (p.N <= 64 || (p.N % 128 != 0 && p.N <= 320))) BN = 64;
+    if (!geglu && (p.N <= 64 || (p.N % 128 != 0 && p.N <= 192))) BN = 64;
     int BM = p.M >= 2048 ? 128 : 64;
     if (geglu && (p.N % 64) != 0) return set_error(MDX_EINVAL, "GEGLU needs packed N %% 64 == 0 (N=%d)", p.N);
     long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.batch > 1 ? p.batch : 1);

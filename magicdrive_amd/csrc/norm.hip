@@ -2,9 +2,9 @@
 //
 // GroupNorm: ATen native_group_norm + silu as used by ResnetBlock2D (diffusers/models/resnet.py:
 //   596-598, 626-630), Transformer2DModel.norm (transformer_2d.py:278, eps 1e-6) and conv_norm_out
-//   (unet_2d_condition_multiview.py:519-521).  One workgroup per (batch, group); the group's
-//   HW x (C/G) slab (<= 8400 x 80 elements, L2 resident) is read three times: mean, centred
-//   variance (two-pass: no E[x^2]-E[x]^2 cancellation), normalise+affine(+SiLU)+store.
+//   (unet_2d_condition_multiview.py:519-521).  One 1024-thread workgroup per (batch, group); the group's
+//   HW x (C/G) slab (<= 1400 x 80 elements, L2 resident) is read twice: pivot-shifted sum / sum of
+//   squares, then normalise+affine(+SiLU)+store.
 // LayerNorm: nn.LayerNorm over C (attention.py:85,104,120; blocks.py:67-71), one wave per token
 //   row, 16-byte loads, shuffle reductions.
 #include "common.h"
@@ -17,31 +17,38 @@ struct GNParams {
     int B, HW, C, G; long ldx, ldy; float eps; int silu;
 };
 
-__device__ __forceinline__ float block_sum_256(float v, float* red) {
-    v = wave_sum(v);
+constexpr int GN_THREADS = 1024;
+
+// block-wide sum of two values at once (16 waves)
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
+    a = wave_sum(a);
+    b = wave_sum(b);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
-    if (lane == 0) red[wave] = v;
+    if (lane == 0) { red[wave] = a; red[16 + wave] = b; }
     __syncthreads();
-    float t = red[0] + red[1] + red[2] + red[3];
-    return t;
+    float ta = 0.f, tb = 0.f;
+#pragma unroll
+    for (int i = 0; i < GN_THREADS / 64; ++i) { ta += red[i]; tb += red[16 + i]; }
+    a = ta; b = tb;
 }
 
-// VEC = channels handled per thread-iteration (cpg % VEC == 0), VEC in {1,2,4,8}
+// One workgroup (16 waves) per (batch, group).  Pass 1: sum and sum of squares of (x - pivot), pivot = the
+// group's first element (shifting by a sample of the data keeps E[d^2] - E[d]^2 well conditioned in fp32);
+// pass 2: normalise + affine (+SiLU) + store.  32-bit index math, VEC channels per thread-iteration.
 template <int VEC>
-__global__ __launch_bounds__(256) void groupnorm_kernel(GNParams p) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(GN_THREADS) void groupnorm_kernel(GNParams p) {
+    __shared__ float red[32];
     const int g = blockIdx.x, b = blockIdx.y;
     const int cpg = p.C / p.G;
     const int vpp = cpg / VEC;                 // vectors per pixel in this group
-    const long nvec = (long)p.HW * vpp;
+    const int nvec = p.HW * vpp;
     const bf16_t* xb = p.X + (long)b * p.HW * p.ldx + (long)g * cpg;
     bf16_t* yb = p.Y + (long)b * p.HW * p.ldy + (long)g * cpg;
+    const int ldx = (int)p.ldx, ldy = (int)p.ldy;
 
-    auto load = [&](long i, float* v) {
-        long px = i / vpp;
-        int cv = (int)(i - px * vpp) * VEC;
-        const bf16_t* s = xb + px * p.ldx + cv;
+    auto load = [&](int px, int cv, float* v) {
+        const bf16_t* s = xb + px * ldx + cv;
         if constexpr (VEC == 8) {
             Frag8 f; f.u = *(const uint4*)s;
 #pragma unroll
@@ -58,47 +65,44 @@ __global__ __launch_bounds__(256) void groupnorm_kernel(GNParams p) {
         }
     };
 
-    float s1 = 0.f;
-    for (long i = threadIdx.x; i < nvec; i += 256) {
-        float v[VEC]; load(i, v);
+    const float pivot = bf2f(xb[0]);
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < nvec; i += GN_THREADS) {
+        int px = i / vpp;
+        int cv = (i - px * vpp) * VEC;
+        float v[VEC]; load(px, cv, v);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) s1 += v[e];
+        for (int e = 0; e < VEC; ++e) { float dlt = v[e] - pivot; s1 += dlt; s2 += dlt * dlt; }
     }
-    const float n = (float)((long)p.HW * cpg);
-    const float mean = block_sum_256(s1, red) / n;
-    float s2 = 0.f;
-    for (long i = threadIdx.x; i < nvec; i += 256) {
-        float v[VEC]; load(i, v);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) { float dlt = v[e] - mean; s2 += dlt * dlt; }
-    }
-    const float var = block_sum_256(s2, red) / n;
+    block_sum2(s1, s2, red);
+    const float n = (float)p.HW * (float)cpg;
+    const float md = s1 / n;                          // mean of (x - pivot)
+    const float mean = pivot + md;
+    const float var = fmaxf(s2 / n - md * md, 0.f);
     const float rstd = rsqrtf(var + p.eps);
-    for (long i = threadIdx.x; i < nvec; i += 256) {
-        float v[VEC]; load(i, v);
-        long px = i / vpp;
-        int cv = (int)(i - px * vpp) * VEC;
+    for (int i = threadIdx.x; i < nvec; i += GN_THREADS) {
+        int px = i / vpp;
+        int cv = (i - px * vpp) * VEC;
+        float v[VEC]; load(px, cv, v);
         const int c0 = g * cpg + cv;
-        bf16_t o[VEC];
+        float o[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             float y = (v[e] - mean) * rstd * p.gamma[c0 + e] + p.beta[c0 + e];
             if (p.silu) y = silu_f(y);
-            o[e] = f2bf(y);
+            o[e] = y;
         }
-        bf16_t* dptr = yb + px * p.ldy + cv;
+        bf16_t* dptr = yb + px * ldy + cv;
         if constexpr (VEC == 8) {
-            Frag8 f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f.h[e] = o[e];
-            *(uint4*)dptr = f.u;
+            uint4 u; u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]); u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
+            *(uint4*)dptr = u;
         } else if constexpr (VEC == 4) {
-            uint2 u; u.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16); u.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+            uint2 u; u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]);
             *(uint2*)dptr = u;
         } else if constexpr (VEC == 2) {
-            *(uint32_t*)dptr = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+            *(uint32_t*)dptr = pack2bf(o[0], o[1]);
         } else {
-            *dptr = o[0];
+            *dptr = f2bf(o[0]);
         }
     }
 }
@@ -175,10 +179,10 @@ extern "C" int mdx_groupnorm_bf16(const MdxGroupNormDesc* d, void* stream) {
     dim3 grid(p.G, p.B);
     hipStream_t st = (hipStream_t)stream;
     switch (vec) {
-        case 8: hipLaunchKernelGGL(groupnorm_kernel<8>, grid, dim3(256), 0, st, p); break;
-        case 4: hipLaunchKernelGGL(groupnorm_kernel<4>, grid, dim3(256), 0, st, p); break;
-        case 2: hipLaunchKernelGGL(groupnorm_kernel<2>, grid, dim3(256), 0, st, p); break;
-        default: hipLaunchKernelGGL(groupnorm_kernel<1>, grid, dim3(256), 0, st, p); break;
+        case 8: hipLaunchKernelGGL(groupnorm_kernel<8>, grid, dim3(GN_THREADS), 0, st, p); break;
+        case 4: hipLaunchKernelGGL(groupnorm_kernel<4>, grid, dim3(GN_THREADS), 0, st, p); break;
+        case 2: hipLaunchKernelGGL(groupnorm_kernel<2>, grid, dim3(GN_THREADS), 0, st, p); break;
+        default: hipLaunchKernelGGL(groupnorm_kernel<1>, grid, dim3(GN_THREADS), 0, st, p); break;
     }
     return check_launch("groupnorm_kernel");
 }

@@ -21,6 +21,7 @@ from . import packing as PK
 from .engine import Act, Builder, PackedNet, TembTable, build_context_kv, level_sizes
 
 BF16, F32 = torch.bfloat16, torch.float32
+CIN_PAD = 8      # latent channels (4) zero-padded so conv_in meets the MFMA path's Cin % 8 == 0
 
 
 def _rows_as_pixels(t2d: torch.Tensor) -> torch.Tensor:
@@ -148,10 +149,11 @@ class ConditioningBuffers:
 
 
 def _emit_controlnet(bld: Builder, cn: PackedNet, x_in: torch.Tensor, cond: ConditioningBuffers, temb: TembTable, ctx_kv, h, w):
-    """conv_in + map feature, then the encoder copy (unet_addon_rawbox.py:846-880). x_in fp32 [B,h,w,4]."""
+    """conv_in + map feature, then the encoder copy (unet_addon_rawbox.py:846-880).
+    x_in: bf16 [B,h,w,CIN_PAD] — latent channels zero-padded to 8 so conv_in runs on the MFMA implicit-GEMM path."""
     c0 = bld.cfg["block_out_channels"][0]
     x0 = bld.new(bld.B, h, w, c0)
-    bld.emit(O.Conv(x_in, cn.conv("conv_in.weight"), x0.bhwc, bias=cn.vec("conv_in.bias"), R=cond.map_rep, direct=True, name="cn.conv_in+map"))
+    bld.emit(O.Conv(x_in, cn.conv_cin_padded("conv_in.weight", x_in.shape[3]), x0.bhwc, bias=cn.vec("conv_in.bias"), R=cond.map_rep, ws=bld.ws, name="cn.conv_in+map"))
     return bld.encoder(cn, x0, temb, ctx_kv, "cn")
 
 
@@ -178,7 +180,7 @@ class SamplerPlan:
         self.bld = bld
         # state
         self.x = torch.zeros(b * n_cam, h, w, Cl, dtype=F32, device=device)            # latents, NHWC
-        self.x_in = torch.zeros(B, h, w, Cl, dtype=F32, device=device)                  # model input ([uncond|cond] copies)
+        self.x_in = torch.zeros(B, h, w, CIN_PAD, dtype=BF16, device=device)            # model input ([uncond|cond] copies), channels padded
         self.eps = torch.zeros(B, h, w, cfg["out_channels"], dtype=F32, device=device)
         self.coef = torch.zeros(num_steps, 4, dtype=F32, device=device)
         self.step_ctr = torch.zeros(1, dtype=torch.int32, device=device)
@@ -198,7 +200,7 @@ class SamplerPlan:
         cn_mid, cn_skips = _emit_controlnet(bld, cn, self.x_in, self.cond, self.temb_cn, self.kv_cn, h, w)
         c0 = cfg["block_out_channels"][0]
         u0 = bld.new(B, h, w, c0)
-        bld.emit(O.Conv(self.x_in, unet.conv("conv_in.weight"), u0.bhwc, bias=unet.vec("conv_in.bias"), direct=True, name="unet.conv_in"))
+        bld.emit(O.Conv(self.x_in, unet.conv_cin_padded("conv_in.weight", CIN_PAD), u0.bhwc, bias=unet.vec("conv_in.bias"), ws=bld.ws, name="unet.conv_in"))
         u_mid, u_skips = bld.encoder(unet, u0, self.temb_un, self.kv_un, "unet")
         # zero-convs accumulate straight into the UNet skips / mid (unet_addon_rawbox.py:882-910 +
         # unet_2d_condition_multiview.py:464-488); the adds happen after the UNet encoder+mid consumed the
@@ -214,7 +216,8 @@ class SamplerPlan:
         y = bld.decoder(unet, u_mid, u_skips, self.temb_un, self.kv_un, "unet")
         bld.emit(O.Conv(y.bhwc, unet.conv("conv_out.weight"), self.eps, bias=unet.vec("conv_out.bias"), direct=True, name="unet.conv_out"))
         bld.free(y)
-        bld.emit(O.DdimStep(self.x.view(-1), self.eps.view(-1), self.coef, self.step_ctr, x_in=self.x_in.view(-1), cfg=do_cfg, guidance=guidance_scale, name="cfg+ddim"))
+        bld.emit(O.DdimStep(self.x.view(-1), self.eps.view(-1), self.coef, self.step_ctr, x_in=self.x_in.view(-1, CIN_PAD), cfg=do_cfg,
+                            guidance=guidance_scale, xin_c=Cl, name="cfg+ddim"))
         self.step_ops = bld.ops
         bld.ops = []
         self.prologue: Optional[L.Program] = None
@@ -231,7 +234,7 @@ class SamplerPlan:
         assert latents.shape[:2] == (b, nc)
         xl = latents.to(self.device, F32).reshape(b * nc, *latents.shape[2:]).permute(0, 2, 3, 1).contiguous()
         self.x.copy_(xl)
-        self.x_in.view(self.c, b * nc, *self.x.shape[1:]).copy_(self.x.unsqueeze(0).expand(self.c, *self.x.shape))
+        self.x_in.view(self.c, b * nc, self.h, self.w, CIN_PAD)[..., :xl.shape[-1]].copy_(self.x.unsqueeze(0).expand(self.c, *self.x.shape))
         self.cond.load(camera_param, text, bev_map, boxes)
         t = timesteps.to(self.device, F32)
         assert t.numel() == self.num_steps
@@ -267,8 +270,8 @@ class ControlNetPlan:
         bld = Builder(cfg, device, B, n_cam)
         self.bld = bld
         self.sample_nchw = torch.zeros(B, cfg["in_channels"], h, w, dtype=F32, device=device)
-        self.x_in = torch.zeros(B, h, w, cfg["in_channels"], dtype=F32, device=device)
-        bld.emit(O.Layout(self.sample_nchw, self.x_in, True, name="cn.sample.nhwc"))
+        self.x_in = torch.zeros(B, h, w, CIN_PAD, dtype=BF16, device=device)
+        bld.emit(O.Layout(self.sample_nchw, self.x_in[..., :cfg["in_channels"]], True, name="cn.sample.nhwc"))
         self.cond = ConditioningBuffers(bld, cn, cfg, n_scene, n_cam, L_box, latent_hw, n_text)
         self.temb = TembTable(cn, B, device, per_sample=True)        # one timestep per view row
         self.temb.emit_fill(bld, cn, cfg)
@@ -316,15 +319,15 @@ class UNetPlan:
         self.bld = bld
         D = cfg["cross_attention_dim"]
         self.sample_nchw = torch.zeros(B, cfg["in_channels"], h, w, dtype=F32, device=device)
-        self.x_in = torch.zeros(B, h, w, cfg["in_channels"], dtype=F32, device=device)
+        self.x_in = torch.zeros(B, h, w, CIN_PAD, dtype=BF16, device=device)
         self.ctx = torch.zeros(B, S, D, dtype=BF16, device=device)
-        bld.emit(O.Layout(self.sample_nchw, self.x_in, True, name="unet.sample.nhwc"))
+        bld.emit(O.Layout(self.sample_nchw, self.x_in[..., :cfg["in_channels"]], True, name="unet.sample.nhwc"))
         self.temb = TembTable(unet, B, device, per_sample=True)
         self.temb.emit_fill(bld, unet, cfg)
         self.kv = build_context_kv(bld, unet, self.ctx, B, S)
         c0 = cfg["block_out_channels"][0]
         u0 = bld.new(B, h, w, c0)
-        bld.emit(O.Conv(self.x_in, unet.conv("conv_in.weight"), u0.bhwc, bias=unet.vec("conv_in.bias"), direct=True, name="unet.conv_in"))
+        bld.emit(O.Conv(self.x_in, unet.conv_cin_padded("conv_in.weight", CIN_PAD), u0.bhwc, bias=unet.vec("conv_in.bias"), ws=bld.ws, name="unet.conv_in"))
         mid, skips = bld.encoder(unet, u0, self.temb, self.kv, "unet")
         self.res_in: List[torch.Tensor] = []
         self.mid_in = None

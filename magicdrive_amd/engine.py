@@ -52,6 +52,13 @@ class PackedNet:
     def conv(self, key):                               # [Cout,kh,kw,Cin] bf16
         return self._get("conv", [key], PK.pack_conv_weight)
 
+    def conv_cin_padded(self, key, cin_pad: int):      # [Cout,kh,kw,cin_pad] bf16, extra input channels zero
+        def f(w):
+            wp = torch.zeros(w.shape[0], cin_pad, w.shape[2], w.shape[3])
+            wp[:, :w.shape[1]] = w
+            return PK.pack_conv_weight(wp)
+        return self._get(("convpad", cin_pad), [key], f)
+
     def vec(self, key, scale: float = 1.0):            # fp32 vector
         return self._get(("vec", scale), [key], lambda v: (v.reshape(-1) * scale).contiguous().to(F32))
 

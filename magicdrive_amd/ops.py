@@ -395,9 +395,10 @@ class DdimStep:
     eps: torch.Tensor                    # fp32 [c*n], same layout ([uncond | cond] when cfg)
     coef: torch.Tensor                   # fp32 [steps, 4]
     step: torch.Tensor                   # int32 [1]
-    x_in: Optional[torch.Tensor] = None  # fp32 [c*n] model-input copy
+    x_in: Optional[torch.Tensor] = None  # fp32 flat [c*n]  or  bf16 [c*pixels, ld] channels-last with ld >= C (padded)
     cfg: bool = False
     guidance: float = 1.0
+    xin_c: int = 0                        # channels per pixel of x (for the bf16 padded x_in)
     name: str = ""
     opcode = L.OP_DDIM
 
@@ -408,7 +409,12 @@ class DdimStep:
         d = L.MdxDdimDesc()
         d.x, d.eps, d.coef, d.step_ptr, d.x_in = _p(self.x), _p(self.eps), _p(self.coef), _p(self.step), _p(self.x_in)
         if self.x_in is not None:
-            _chk(self.x_in.is_contiguous() and self.x_in.numel() == self.eps.numel() and self.x_in.dtype == F32, "ddim: x_in")
+            if self.x_in.dtype == F32:
+                _chk(self.x_in.is_contiguous() and self.x_in.numel() == self.eps.numel(), "ddim: x_in")
+            else:
+                _chk(self.x_in.dtype == BF16 and self.x_in.dim() == 2 and self.x_in.is_contiguous() and self.xin_c > 0, "ddim: bf16 x_in must be [pixels, ld]")
+                _chk(self.x_in.shape[0] * self.xin_c == self.eps.numel() and self.x_in.shape[1] >= self.xin_c, "ddim: bf16 x_in shape")
+                d.xin_c, d.xin_ld = self.xin_c, self.x_in.shape[1]
         d.n, d.cfg, d.guidance = n, int(self.cfg), float(self.guidance)
         return self.opcode, d
 

@@ -159,9 +159,16 @@ def run_ddim(op: O.DdimStep):
     xn = c[2] * x0 + c[3] * e
     op.x.copy_(xn)
     if op.x_in is not None:
-        op.x_in[:n].copy_(xn)
-        if op.cfg:
-            op.x_in[n:].copy_(xn)
+        if op.x_in.dtype == torch.float32:
+            op.x_in[:n].copy_(xn)
+            if op.cfg:
+                op.x_in[n:].copy_(xn)
+        else:
+            npx = n // op.xin_c
+            v = xn.view(npx, op.xin_c).to(op.x_in.dtype)
+            op.x_in[:npx, :op.xin_c].copy_(v)
+            if op.cfg:
+                op.x_in[npx:, :op.xin_c].copy_(v)
     op.step += 1
 
 

@@ -383,3 +383,23 @@ def test_error_paths(dev):
     q = rnd(1, 8, 12, seed=1)
     with pytest.raises(L.MdxError):
         O.run_ops([O.Attn(q, q, torch.zeros(1, 12, 8, dtype=BF, device=dev), torch.zeros_like(q), heads=1, Tk=8, scale=1.0)])  # d=12
+
+
+def test_cfg_ddim_bf16_padded_model_input(dev):
+    # x_in as the channels-last bf16 copy with pixel stride 8 that conv_in's MFMA path reads
+    npx, Cc = 6 * 28 * 50, 4
+    n = npx * Cc
+    x = rnd(n, seed=1, dtype=torch.float32); x0 = x.clone()
+    eps = rnd(2 * n, seed=2, dtype=torch.float32)
+    coef = torch.tensor([[0.9, 0.4359, 0.95, 0.3122]], dtype=torch.float32, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    xin = torch.full((2 * npx, 8), 7.0, dtype=BF, device=dev)
+    O.run_ops([O.DdimStep(x, eps, coef, step, x_in=xin, cfg=True, guidance=2.0, xin_c=Cc)])
+    torch.cuda.synchronize()
+    e = eps[:n].cpu() + 2.0 * (eps[n:].cpu() - eps[:n].cpu())
+    c = coef[0].cpu()
+    ref = c[2] * (x0.cpu() - c[1] * e) / c[0] + c[3] * e
+    assert torch.allclose(x.cpu(), ref, atol=1e-5)
+    exp = ref.view(npx, Cc).to(BF)
+    assert torch.equal(xin[:npx, :Cc].cpu(), exp) and torch.equal(xin[npx:, :Cc].cpu(), exp)
+    assert (xin[:, Cc:].float() == 7.0).all(), "pad channels must not be touched"
