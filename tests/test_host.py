@@ -1,0 +1,115 @@
+"""CPU: host-side logic — packing, scheduler table, checkpoint layout round trip, API error behaviour."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import state_dicts
+from magicdrive_amd import packing as PK, schedulers, synthetic
+from magicdrive_amd.networks import spec
+from magicdrive_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiview
+from magicdrive_amd.networks.unet_addon_rawbox import BEVControlNetModel
+from magicdrive_amd.pipeline.pipeline_bev_controlnet import StableDiffusionBEVControlNetPipeline
+from magicdrive_amd.misc.common import load_module
+from oracle import denoiser as D
+
+
+def test_nearest_index_matches_torch_interpolate():
+    for n_in, n_out in [(4, 7), (7, 13), (14, 25), (13, 25), (25, 50), (7, 14), (27, 54), (3, 8)]:
+        x = torch.arange(n_in, dtype=torch.float32).view(1, 1, 1, n_in)
+        ref = F.interpolate(x, size=(1, n_out), mode="nearest").view(-1).long()
+        assert torch.equal(PK.nearest_index(n_in, n_out).long(), ref), (n_in, n_out)
+
+
+def test_geglu_packing_roundtrip():
+    w = torch.randn(256, 16); b = torch.randn(256)
+    wp, bp = PK.pack_geglu(w, b)
+    x = torch.randn(5, 16)
+    raw = x @ wp.float().T + bp
+    r = raw.view(5, 4, 2, 32)
+    got = (r[:, :, 0] * F.gelu(r[:, :, 1])).reshape(5, 128)
+    h, g = (x @ w.to(torch.bfloat16).float().T + b).chunk(2, -1)
+    assert torch.allclose(got, h * F.gelu(g), atol=1e-5)
+
+
+def test_ddim_table_matches_oracle_scheduler():
+    s = schedulers.DDIMScheduler(); o = D.DDIM()
+    ts = s.set_timesteps(50); assert torch.equal(ts, o.set_timesteps(50))
+    tab = s.coefficient_table()
+    for i, t in enumerate(ts.tolist()):
+        a_t, a_p = o.coefficients(t)
+        exp = torch.tensor([a_t ** 0.5, (1 - a_t) ** 0.5, a_p ** 0.5, (1 - a_p) ** 0.5])
+        assert torch.allclose(tab[i], exp, atol=1e-6)
+
+
+def test_checkpoint_layout_roundtrip(tmp_path):
+    cfg = spec.TINY_CONFIG
+    u = UNet2DConditionModelMultiview.from_config(cfg, seed=0)
+    c = BEVControlNetModel.from_config(cfg, seed=1)
+    u.save_pretrained(str(tmp_path / "unet")); c.save_pretrained(str(tmp_path / "controlnet"), safe_serialization=False)
+    assert os.path.exists(tmp_path / "unet" / "diffusion_pytorch_model.safetensors") and os.path.exists(tmp_path / "controlnet" / "diffusion_pytorch_model.bin")
+    u2 = UNet2DConditionModelMultiview.from_pretrained(str(tmp_path / "unet"))
+    c2 = BEVControlNetModel.from_pretrained(str(tmp_path), subfolder="controlnet")
+    assert all(torch.equal(u.state_dict()[k], u2.state_dict()[k]) for k in u.state_dict())
+    assert all(torch.equal(c.state_dict()[k], c2.state_dict()[k]) for k in c.state_dict())
+    assert u2.cfg["block_out_channels"] == cfg["block_out_channels"] and c2.cfg["controlnet"]["bbox"]["proj_dims"] == cfg["controlnet"]["bbox"]["proj_dims"]
+    assert u2.config.in_channels == 4 and u2.dtype == torch.bfloat16
+
+
+def test_state_dict_validation():
+    cfg = spec.TINY_CONFIG
+    usd, _ = state_dicts(cfg)
+    bad = dict(usd); bad.pop("conv_in.weight")
+    with pytest.raises(KeyError):
+        UNet2DConditionModelMultiview(cfg, bad)
+    bad = dict(usd); bad["conv_in.weight"] = torch.zeros(3, 3)
+    with pytest.raises(ValueError):
+        UNet2DConditionModelMultiview(cfg, bad)
+
+
+def test_uncond_helpers_match_reference_semantics():
+    cfg = spec.TINY_CONFIG
+    c = BEVControlNetModel.from_config(cfg, seed=1)
+    p = c.uncond_cam_param((2, 6))
+    assert p.shape == (2, 6, 3, 7) and torch.equal(p[0, 0], p[1, 5])
+    assert torch.equal(p, D.uncond_cam_param(c.state_dict(), 2, 6))
+    sc = synthetic.make_scene_batch(2, ctx_dim=64, max_len=3)
+    kw = c.add_uncond_to_kwargs(camera_param=sc["camera_param"], bboxes_3d_data=sc["bboxes_3d_data"], image=sc["bev_map"], max_len=5)
+    assert kw["camera_param"].shape == (4, 6, 3, 7) and torch.equal(kw["camera_param"][2:], sc["camera_param"])
+    assert kw["bboxes_3d_data"]["bboxes"].shape == (4, 6, 5, 8, 3) and not kw["bboxes_3d_data"]["masks"][:2].any()
+    assert torch.equal(kw["bboxes_3d_data"]["bboxes"][2:, :, :3], sc["bboxes_3d_data"]["bboxes"])
+
+
+def test_pipeline_api_errors_without_gpu():
+    cfg = spec.TINY_CONFIG
+    pipe = StableDiffusionBEVControlNetPipeline(unet=UNet2DConditionModelMultiview.from_config(cfg), controlnet=BEVControlNetModel.from_config(cfg, 1))
+    sc = synthetic.make_scene_batch(1, ctx_dim=64, max_len=2)
+    with pytest.raises(RuntimeError):          # no CPU path, loudly
+        pipe(None, sc["bev_map"], sc["camera_param"], 224, 400, prompt_embeds=sc["prompt_embeds"], negative_prompt_embeds=sc["negative_prompt_embeds"])
+    with pytest.raises(AssertionError):
+        StableDiffusionBEVControlNetPipeline(safety_checker=object())
+
+    class GenScheduler(schedulers.DDIMScheduler):
+        def step(self, model_output, timestep, sample, eta=0.0, generator=None):
+            return None
+    pipe.scheduler = GenScheduler()
+    with pytest.raises(RuntimeError):          # reference guard pipeline_bev_controlnet.py:94-97
+        pipe.prepare_extra_step_kwargs(None, 0.0)
+    with pytest.raises(RuntimeError):
+        UNet2DConditionModelMultiview.from_config(cfg).forward(torch.zeros(6, 4, 28, 50), 1, torch.zeros(6, 78, 64))
+
+
+def test_plugin_strings_resolve_like_the_reference_config():
+    # configs/model/SDv1.5mv_rawbox.yaml:11-13,24 with the package name swapped
+    assert load_module("magicdrive_amd.pipeline.pipeline_bev_controlnet.StableDiffusionBEVControlNetPipeline") is StableDiffusionBEVControlNetPipeline
+    assert load_module("magicdrive_amd.networks.unet_2d_condition_multiview.UNet2DConditionModelMultiview") is UNet2DConditionModelMultiview
+    assert load_module("magicdrive_amd.networks.unet_addon_rawbox.BEVControlNetModel") is BEVControlNetModel
+
+
+def test_prepare_latents_is_seed_and_device_independent():
+    cfg = spec.TINY_CONFIG
+    pipe = StableDiffusionBEVControlNetPipeline(unet=UNet2DConditionModelMultiview.from_config(cfg), controlnet=BEVControlNetModel.from_config(cfg, 1))
+    a = pipe.prepare_latents(2, 4, 224, 400, torch.float32, "cpu", torch.Generator().manual_seed(3))
+    b = torch.randn(2, 4, 28, 50, generator=torch.Generator().manual_seed(3))
+    assert torch.equal(a, b)

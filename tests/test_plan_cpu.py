@@ -1,0 +1,93 @@
+"""CPU: the op programs the engine builds (topology, weight packing, hoisting, buffer aliasing) are executed
+by the independent torch interpreter tests/plan_interp.py and compared with the oracle and the goldens.
+This checks everything about the HIP path except the kernels' own arithmetic (that is tests/test_kernels_gpu.py)."""
+import os
+
+import pytest
+import torch
+
+import plan_interp
+from helpers import bf16_round, cfg_inputs, rel_l2, scene, state_dicts
+from magicdrive_amd import denoiser as DN, flops, schedulers
+from magicdrive_amd.engine import PackedNet
+from magicdrive_amd.networks import spec
+from oracle import denoiser as D
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CPU = torch.device("cpu")
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = spec.TINY_CONFIG
+    usd, csd = state_dicts(cfg)
+    return cfg, usd, csd, PackedNet(usd, CPU), PackedNet(csd, CPU)
+
+
+def test_module_plans_match_golden_forward(tiny):
+    cfg, usd, csd, un, cn = tiny
+    G = torch.load(os.path.join(GOLD, "tiny_forward.pt"))
+    sc = scene(cfg, 2, 5)
+    lat = torch.randn(2, 6, 4, 28, 50, generator=torch.Generator().manual_seed(G["lat_seed"]))
+    t = G["timesteps"]
+    cp = DN.ControlNetPlan(cfg, cn, CPU, 2, 5, (28, 50))
+    cp.sample_nchw.copy_(lat.reshape(-1, 4, 28, 50)); cp.temb.t.copy_(t.float().repeat_interleave(6))
+    cp.cond.load(sc["camera_param"], sc["prompt_embeds"], sc["bev_map"], sc["bboxes_3d_data"])
+    plan_interp.run(cp.ops)
+    assert rel_l2(cp.cond.ctx, G["ctx"].float()) < 5e-3
+    assert rel_l2(cp.mid_out, G["mid"]) < 3e-2 and rel_l2(cp.down_out[-1], G["down_last"]) < 3e-2
+    with torch.no_grad():
+        d, m, ctx = D.controlnet_forward(csd, cfg, lat, t, sc["camera_param"], sc["bboxes_3d_data"], sc["prompt_embeds"], sc["bev_map"])
+    up = DN.UNetPlan(cfg, un, CPU, 12, ctx.shape[1], (28, 50))
+    up.sample_nchw.copy_(lat.reshape(-1, 4, 28, 50)); up.temb.t.copy_(t.float().repeat_interleave(6)); up.ctx.copy_(ctx)
+    for dst, src in zip(up.res_in, d):
+        dst.copy_(src)
+    up.mid_in.copy_(m)
+    plan_interp.run(up.ops)
+    per_view = max(rel_l2(up.out_nchw[i], G["eps"][i]) for i in range(12))
+    assert per_view < 3e-2, per_view
+
+
+@pytest.mark.parametrize("do_cfg", [True, False])
+def test_sampler_plan_matches_golden_pipeline(tiny, do_cfg):
+    cfg, usd, csd, un, cn = tiny
+    G = torch.load(os.path.join(GOLD, "tiny_pipeline.pt"))
+    sc = scene(cfg, 2, 5)
+    steps = G["steps"]
+    sch = schedulers.DDIMScheduler(); ts = sch.set_timesteps(steps)
+    if do_cfg:
+        cam, text, bev, boxes = cfg_inputs(D, csd, sc)
+        sp = DN.SamplerPlan(cfg, un, cn, CPU, 2, True, 5, (28, 50), num_steps=steps, guidance_scale=G["guidance"])
+        gold = G["latents_cfg"]
+    else:       # camera_param=None path: learned uncond camera, CFG forced off, no boxes, zero map
+        cam, text, bev, boxes = D.uncond_cam_param(csd, 2, 6), sc["prompt_embeds"], torch.zeros_like(sc["bev_map"]), None
+        sp = DN.SamplerPlan(cfg, un, cn, CPU, 2, False, 0, (28, 50), num_steps=steps, guidance_scale=G["guidance"])
+        gold = G["latents_textonly"]
+    sp.load_inputs(torch.stack([sc["latents"]] * 6, 1), cam, text, bev, boxes, ts, sch.coefficient_table())
+    plan_interp.run(sp.prologue_ops)
+    for _ in range(steps):
+        plan_interp.run(sp.step_ops, lower_check=False)
+    assert sp.step_ctr.item() == steps
+    assert rel_l2(sp.latents(), gold) < 4e-2, rel_l2(sp.latents(), gold)
+    # every buffer handed out was returned to the pool (no leak that would grow with the step count)
+    assert all(v for v in sp.bld.pool.free_list.values())
+
+
+def test_step_program_work_is_deduplicated():
+    """F_step(224x400, L=32, c=1) ~= 2.325 TF after removing the reference's redundant work."""
+    cfg = spec.SD15_CONFIG
+    z = lambda shapes: {k: torch.zeros(1).expand(s) for k, s in shapes.items()}      # shape-only weights
+
+    class ShapeNet(PackedNet):
+        def _get(self, tag, keys, fn):
+            ck = (tag,) + tuple(keys)
+            if ck not in self.cache:
+                small = [torch.zeros(self.sd[k].shape) for k in keys]
+                self.cache[ck] = fn(*small)
+            return self.cache[ck]
+    un = ShapeNet(z(spec.unet_param_shapes(cfg)), CPU); cn = ShapeNet(z(spec.controlnet_param_shapes(cfg)), CPU)
+    sp = DN.SamplerPlan(cfg, un, cn, CPU, 1, False, 32, (28, 50), num_steps=50)
+    f = flops.program_flops(sp.step_ops)["total"] / 1e12
+    fp = flops.program_flops(sp.prologue_ops)["total"] / 1e12
+    assert abs(f - 2.325) < 0.01, f
+    assert abs(fp - 0.045) < 0.005, fp

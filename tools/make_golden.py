@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.pt by running the REAL reference (imported from /root/reference through
+oracle/refshim.py) on seeded inputs.  Runs only in the authoring container; the fixtures travel.
+
+Weights are NOT stored: they are regenerated anywhere from seeds by
+magicdrive_amd.networks.spec.random_state_dict (CPU generator, order independent); each fixture records a
+checksum of the state dicts it was produced with so a drifted init is detected, not silently compared.
+
+Fixtures
+  tiny_forward.pt   BEVControlNetModel.forward + UNet2DConditionModelMultiview.forward (reference modules),
+                    2 scenes x 6 views with DISTINCT noise per view, 5 boxes/view, two different timesteps.
+  tiny_pipeline.pt  StableDiffusionBEVControlNetPipeline.__call__ (reference pipeline, generator-free DDIM subclass,
+                    SURVEY.md §0.2), 5 steps, guidance 2.0, output_type="latent"; and the camera_param=None path.
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from helpers import scene, state_dicts  # noqa: E402
+from magicdrive_amd.networks import spec  # noqa: E402
+from oracle import ref_models  # noqa: E402
+
+
+def checksum(sd):
+    return float(sum(v.double().abs().sum() for v in sd.values()))
+
+
+def main():
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    cfg = spec.TINY_CONFIG
+    usd, csd = state_dicts(cfg)
+    meta = {"unet_checksum": checksum(usd), "cn_checksum": checksum(csd), "torch": str(torch.__version__)}
+
+    # ---- module-level forwards
+    ns, unet, cnet = ref_models.build_reference(cfg, usd, csd)
+    nb, Lb, hw = 2, 5, (28, 50)
+    sc = scene(cfg, nb, Lb, hw)
+    g = torch.Generator().manual_seed(7)
+    lat = torch.randn(nb, 6, 4, *hw, generator=g)
+    t = torch.tensor([981, 501])
+    with torch.no_grad():
+        d, m, ctx = cnet(lat, t, sc["camera_param"], sc["bboxes_3d_data"], sc["prompt_embeds"], sc["bev_map"], return_dict=False)
+        e = unet(lat.reshape(-1, 4, *hw), t.repeat_interleave(6), encoder_hidden_states=ctx,
+                 down_block_additional_residuals=d, mid_block_additional_residual=m).sample
+    torch.save({"meta": meta, "lat_seed": 7, "timesteps": t, "ctx": ctx.half(), "mid": m.clone(), "eps": e.clone(),
+                "down_absmean": torch.tensor([x.abs().mean() for x in d]), "down_first": d[0][:, :, ::7, ::10].clone(),
+                "down_last": d[-1].clone()}, os.path.join(out_dir, "tiny_forward.pt"))
+    print("tiny_forward: eps std", e.std().item())
+
+    # ---- the reference pipeline __call__
+    ns, pipe = ref_models.build_reference_pipeline(cfg, usd, csd)
+    sc = scene(cfg, 2, 5, hw)
+    with torch.no_grad():
+        out = pipe(prompt=None, image=sc["bev_map"], camera_param=sc["camera_param"], height=224, width=400, num_inference_steps=5,
+                   guidance_scale=2.0, latents=sc["latents"].clone(), prompt_embeds=sc["prompt_embeds"],
+                   negative_prompt_embeds=sc["negative_prompt_embeds"], output_type="latent",
+                   bev_controlnet_kwargs={"bboxes_3d_data": sc["bboxes_3d_data"]}).images
+        out_nocam = pipe(prompt=None, image=torch.zeros_like(sc["bev_map"]), camera_param=None, height=224, width=400, num_inference_steps=5,
+                         guidance_scale=2.0, latents=sc["latents"].clone(), prompt_embeds=sc["prompt_embeds"],
+                         negative_prompt_embeds=sc["negative_prompt_embeds"], output_type="latent",
+                         bev_controlnet_kwargs={"bboxes_3d_data": None}).images
+    torch.save({"meta": meta, "steps": 5, "guidance": 2.0, "latents_cfg": out.clone(), "latents_textonly": out_nocam.clone()},
+               os.path.join(out_dir, "tiny_pipeline.pt"))
+    print("tiny_pipeline: |x|", out.abs().mean().item(), out_nocam.abs().mean().item())
+    for f in os.listdir(out_dir):
+        print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
