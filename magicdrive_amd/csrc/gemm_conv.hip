@@ -21,80 +21,19 @@
 // Reference semantics replaced: ATen conv2d/addmm call sites listed in include/mdx.h.
 #include "common.h"
 #include "launch.h"
+#include "gemm_params.h"
+#include <cstdlib>
 
 namespace mdx {
 
-struct GCParams {
-    const bf16_t* A; const bf16_t* W; void* C; const void* R;
-    const float* bias; const float* temb; const int* sel; float* ws;
-    int M, N, K;
-    long lda, ldw, ldc, ldr;
-    long sA, sW, sC, sR;
-    long temb_sel_stride, temb_b_stride;
-    int rows_per_b;
-    int epi, splitk, kchunk, c_f32, batch;
-    long ws_bytes;
-    // conv geometry (CONV only); lda doubles as the pixel stride of X
-    int Hi, Wi, Cin, Ho, Wo, kh, kw, sh, sw, ph, pw;
-};
 
-constexpr int BK = 64;
-constexpr int LSTR = BK + 8;  // LDS row stride in elements (144 B)
+int launch_gemm_dma(const GCParams& p, bool conv, int tile, hipStream_t st);
+void dma_tile_dims(int tile, int* bm, int* bn);
 
-// ---- shared epilogue ---------------------------------------------------------------
-// v[4] are raw accumulators for output row m, raw columns nb..nb+3 (nb % 4 == 0).
-// For GEGLU, v = value columns and gte = gate columns (raw column nb+32+j).
-__device__ __forceinline__ void epilogue_store(const GCParams& p, long zb, int m, int nb,
-                                               const float* v, const float* gte) {
-    float o[4];
-    int ncol;  // output column of o[0]
-    const float* tb = nullptr;
-    if (p.temb) {
-        int sel = p.sel ? *p.sel : 0;
-        tb = p.temb + (long)sel * p.temb_sel_stride + (long)(m / p.rows_per_b) * p.temb_b_stride;
-    }
-    if (p.epi == 1) {  // GEGLU
-        ncol = (nb >> 6) * 32 + (nb & 63);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float h = v[j], g = gte[j];
-            if (p.bias) { h += p.bias[nb + j]; g += p.bias[nb + 32 + j]; }
-            o[j] = h * gelu_erf_f(g);
-        }
-    } else {
-        ncol = nb;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float x = v[j];
-            if (p.bias) x += p.bias[nb + j];
-            if (tb) x += tb[nb + j];
-            if (p.epi == 2) x = silu_f(x);
-            o[j] = x;
-        }
-    }
-    if (p.c_f32) {
-        float* c = (float*)p.C + zb * p.sC + (long)m * p.ldc + ncol;
-        if (p.R) {
-            const float* r = (const float*)p.R + zb * p.sR + (long)m * p.ldr + ncol;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] += r[j];
-        }
-        *(float4*)c = make_float4(o[0], o[1], o[2], o[3]);
-    } else {
-        bf16_t* c = (bf16_t*)p.C + zb * p.sC + (long)m * p.ldc + ncol;
-        if (p.R) {
-            const bf16_t* r = (const bf16_t*)p.R + zb * p.sR + (long)m * p.ldr + ncol;
-            uint2 rv = *(const uint2*)r;
-            o[0] += bf2f((bf16_t)(rv.x & 0xffff)); o[1] += bf2f((bf16_t)(rv.x >> 16));
-            o[2] += bf2f((bf16_t)(rv.y & 0xffff)); o[3] += bf2f((bf16_t)(rv.y >> 16));
-        }
-        uint2 ov; ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]);
-        *(uint2*)c = ov;
-    }
-}
-
-template <int BM, int BN, bool CONV>
+template <int BM, int BN, int BK, bool CONV>
 __global__ __launch_bounds__(256) void gemm_conv_kernel(GCParams p) {
+    constexpr int LSTR = BK + 8;  // LDS row stride in elements (+16 B pad: conflict-free ds_read_b128)
+    constexpr int KCH = BK / 8;   // 16-byte chunks per row of a slab
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int A_CH = BM * BK / 8 / 256;
     constexpr int B_CH = BN * BK / 8 / 256;
@@ -115,8 +54,9 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GCParams p) {
     const int kend = min(p.K, kbeg + p.kchunk);
     const int nt = (kend - kbeg + BK - 1) / BK;
 
-    const int kc = tid & 7;       // 16-byte chunk within the 64-wide k slab
-    const int rbase = tid >> 3;   // 0..31
+    constexpr int RSTEP = 256 / KCH;   // rows covered by one pass of the 256 threads
+    const int kc = tid % KCH;     // 16-byte chunk within the BK-wide k slab
+    const int rbase = tid / KCH;
 
     // ---- per-thread row bookkeeping (fixed over the K loop) ----
     const bf16_t* a_ptr[A_CH];
@@ -124,7 +64,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GCParams p) {
     int a_iy0[A_CH], a_ix0[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-        int m = m0 + rbase + 32 * i;
+        int m = m0 + rbase + RSTEP * i;
         a_ok[i] = m < p.M;
         if (CONV) {
             int mm = a_ok[i] ? m : 0;
@@ -145,7 +85,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GCParams p) {
     bool b_ok[B_CH];
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-        int n = n0 + rbase + 32 * i;
+        int n = n0 + rbase + RSTEP * i;
         b_ok[i] = n < p.N;
         b_ptr[i] = p.W + zb * p.sW + (long)(b_ok[i] ? n : 0) * p.ldw;
     }
@@ -196,10 +136,10 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GCParams p) {
         bf16_t* bs = Bs + buf * BN * LSTR;
 #pragma unroll
         for (int i = 0; i < A_CH; ++i)
-            *(uint4*)(as + (rbase + 32 * i) * LSTR + kc * 8) = a_reg[i];
+            *(uint4*)(as + (rbase + RSTEP * i) * LSTR + kc * 8) = a_reg[i];
 #pragma unroll
         for (int i = 0; i < B_CH; ++i)
-            *(uint4*)(bs + (rbase + 32 * i) * LSTR + kc * 8) = b_reg[i];
+            *(uint4*)(bs + (rbase + RSTEP * i) * LSTR + kc * 8) = b_reg[i];
     };
 
     f32x16_t acc[TM][TN];
@@ -291,11 +231,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GCParams p) {
     epilogue_store(p, 0, m, nb, v, g);
 }
 
-template <int BM, int BN, bool CONV>
+template <int BM, int BN, int BK, bool CONV>
 static int launch_one(const GCParams& p, hipStream_t st) {
-    constexpr size_t smem = (size_t)2 * (BM + BN) * LSTR * sizeof(bf16_t);
+    constexpr size_t smem = (size_t)2 * (BM + BN) * (BK + 8) * sizeof(bf16_t);
     static bool attr_done = false;
-    auto kern = gemm_conv_kernel<BM, BN, CONV>;
+    auto kern = gemm_conv_kernel<BM, BN, BK, CONV>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return set_error(MDX_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -306,20 +246,42 @@ static int launch_one(const GCParams& p, hipStream_t st) {
     return check_launch("gemm_conv_kernel");
 }
 
-// Tile / split-K choice.  The chip has 256 CUs; a launch wants >= ~2 blocks per CU.
+// Tile / split-K choice.  The chip has 256 CUs.
+//   MDX_GEMM_IMPL=0 : register-staged main loop (gemm_conv_kernel), 128/64 tiles
+//   MDX_GEMM_IMPL=1 : LDS-DMA ring main loop (gemm_dma_kernel), tile picked per shape (default)
+//   MDX_GEMM_IMPL=10+t : LDS-DMA with tile id t forced (benchmarking)
 int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MDX_OK;
     const bool geglu = p.epi == 1;
-    int BN = 128;
-    if (!geglu && (p.N <= 64 || (p.N % 128 != 0 && p.N <= 192))) BN = 64;
-    int BM = p.M >= 2048 ? 128 : 64;
     if (geglu && (p.N % 64) != 0) return set_error(MDX_EINVAL, "GEGLU needs packed N %% 64 == 0 (N=%d)", p.N);
+    static const int impl = [] { const char* e = getenv("MDX_GEMM_IMPL"); return e ? atoi(e) : 0; }();
+    int BM, BN, tile = -1;
+    if (impl == 0) {
+        BN = 128;
+        if (!geglu && (p.N <= 64 || (p.N % 128 != 0 && p.N <= 192))) BN = 64;
+        BM = p.M >= 2048 ? 128 : 64;
+    } else {
+        if (impl >= 10) {
+            tile = impl - 10;
+        } else {
+            const long nb = p.batch > 1 ? p.batch : 1;
+            auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * nb; };
+            // biggest tile that still gives every CU a block; N tails waste MFMA work, so prefer BN that divides N
+            if (p.N >= 256 && p.N % 256 == 0 && blocks(256, 256) >= 200) tile = 2;
+            else if (p.N >= 96 && blocks(256, 128) >= 200) tile = 1;
+            else if (p.N >= 96 && blocks(128, 128) >= 128) tile = 0;
+            else if (p.N >= 96) tile = p.M > 64 ? 0 : 3;
+            else tile = p.M >= 2048 ? 4 : 5;
+        }
+        if (geglu && (tile == 4 || tile == 5)) tile = 3;
+        dma_tile_dims(tile, &BM, &BN);
+    }
     long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.batch > 1 ? p.batch : 1);
     int splitk = 1;
     if (p.splitk > 0) {
         splitk = p.splitk;  // caller forced
-    } else if (p.batch <= 1 && p.ws && tiles < 384 && p.K >= 1024 && (p.N % 4) == 0) {
-        long want = (768 + tiles - 1) / tiles;
+    } else if (p.batch <= 1 && p.ws && tiles < 160 && p.K >= 1024 && (p.N % 4) == 0) {
+        long want = (512 + tiles - 1) / tiles;
         long maxs = p.K / 512;  // keep >= 8 K-slabs per slice
         splitk = (int)min(min(want, maxs), 32L);
         if (splitk < 1) splitk = 1;
@@ -330,19 +292,25 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
         long fit = per > 0 ? p.ws_bytes / per : 0;
         if (fit < splitk) splitk = fit < 1 ? 1 : (int)fit;
     }
+    constexpr int BK = 64;   // split-K slices are multiples of the largest slab
     int kchunk = ((p.K + splitk - 1) / splitk + BK - 1) / BK * BK;
     splitk = (p.K + kchunk - 1) / kchunk;
     if (splitk > 1 && !p.ws) return set_error(MDX_EINVAL, "split-K needs a workspace");
     p.splitk = splitk;
     p.kchunk = kchunk;
     int rc;
-#define MDX_GC(BM_, BN_)                                                               \
-    (conv ? launch_one<BM_, BN_, true>(p, st) : launch_one<BM_, BN_, false>(p, st))
-    if (BM == 128 && BN == 128) rc = MDX_GC(128, 128);
-    else if (BM == 128 && BN == 64) rc = MDX_GC(128, 64);
-    else if (BM == 64 && BN == 128) rc = MDX_GC(64, 128);
-    else rc = MDX_GC(64, 64);
+    if (impl != 0) {
+        rc = launch_gemm_dma(p, conv, tile, st);
+    } else {
+        static const int bk = [] { const char* e = getenv("MDX_GEMM_BK"); return e ? atoi(e) : 64; }();
+#define MDX_GC(BM_, BN_) (bk == 32 ? (conv ? launch_one<BM_, BN_, 32, true>(p, st) : launch_one<BM_, BN_, 32, false>(p, st)) \
+                                   : (conv ? launch_one<BM_, BN_, 64, true>(p, st) : launch_one<BM_, BN_, 64, false>(p, st)))
+        if (BM == 128 && BN == 128) rc = MDX_GC(128, 128);
+        else if (BM == 128 && BN == 64) rc = MDX_GC(128, 64);
+        else if (BM == 64 && BN == 128) rc = MDX_GC(64, 128);
+        else rc = MDX_GC(64, 64);
 #undef MDX_GC
+    }
     if (rc != MDX_OK) return rc;
     if (splitk > 1) {
         long n = (long)p.M * (p.N / 4);

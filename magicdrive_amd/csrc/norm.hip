@@ -65,14 +65,29 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_kernel(GNParams p) {
         }
     };
 
+    // Loads are issued GN_U at a time before any is consumed (the loop is latency-, not bandwidth-bound:
+    // a group's slab sits in L2), and a group that fits in GN_U vectors per thread is read only ONCE.
+    constexpr int GN_U = (VEC == 8) ? 4 : 8;          // <= 32 live values per thread (1024-thread WG: 128 VGPR budget)
     const float pivot = bf2f(xb[0]);
     float s1 = 0.f, s2 = 0.f;
-    for (int i = threadIdx.x; i < nvec; i += GN_THREADS) {
-        int px = i / vpp;
-        int cv = (i - px * vpp) * VEC;
-        float v[VEC]; load(px, cv, v);
+    float v[GN_U][VEC];
+    const bool single = nvec <= GN_U * GN_THREADS;
+    for (int base = threadIdx.x; base < nvec; base += GN_U * GN_THREADS) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { float dlt = v[e] - pivot; s1 += dlt; s2 += dlt * dlt; }
+        for (int u = 0; u < GN_U; ++u) {
+            const int i = base + u * GN_THREADS;
+            if (i < nvec) {
+                int px = i / vpp;
+                load(px, (i - px * vpp) * VEC, v[u]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[u][e] = pivot;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GN_U; ++u)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { float dlt = v[u][e] - pivot; s1 += dlt; s2 += dlt * dlt; }
     }
     block_sum2(s1, s2, red);
     const float n = (float)p.HW * (float)cpg;
@@ -80,29 +95,43 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_kernel(GNParams p) {
     const float mean = pivot + md;
     const float var = fmaxf(s2 / n - md * md, 0.f);
     const float rstd = rsqrtf(var + p.eps);
-    for (int i = threadIdx.x; i < nvec; i += GN_THREADS) {
-        int px = i / vpp;
-        int cv = (i - px * vpp) * VEC;
-        float v[VEC]; load(px, cv, v);
-        const int c0 = g * cpg + cv;
-        float o[VEC];
+    for (int base = threadIdx.x; base < nvec; base += GN_U * GN_THREADS) {
+        if (!single) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            float y = (v[e] - mean) * rstd * p.gamma[c0 + e] + p.beta[c0 + e];
-            if (p.silu) y = silu_f(y);
-            o[e] = y;
+            for (int u = 0; u < GN_U; ++u) {
+                const int i = base + u * GN_THREADS;
+                if (i < nvec) {
+                    int px = i / vpp;
+                    load(px, (i - px * vpp) * VEC, v[u]);
+                }
+            }
         }
-        bf16_t* dptr = yb + px * ldy + cv;
-        if constexpr (VEC == 8) {
-            uint4 u; u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]); u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
-            *(uint4*)dptr = u;
-        } else if constexpr (VEC == 4) {
-            uint2 u; u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]);
-            *(uint2*)dptr = u;
-        } else if constexpr (VEC == 2) {
-            *(uint32_t*)dptr = pack2bf(o[0], o[1]);
-        } else {
-            *dptr = f2bf(o[0]);
+#pragma unroll
+        for (int u = 0; u < GN_U; ++u) {
+            const int i = base + u * GN_THREADS;
+            if (i >= nvec) continue;
+            const int px = i / vpp;
+            const int cv = (i - px * vpp) * VEC;
+            const int c0 = g * cpg + cv;
+            float o[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float y = (v[u][e] - mean) * rstd * p.gamma[c0 + e] + p.beta[c0 + e];
+                if (p.silu) y = silu_f(y);
+                o[e] = y;
+            }
+            bf16_t* dptr = yb + px * ldy + cv;
+            if constexpr (VEC == 8) {
+                uint4 u4; u4.x = pack2bf(o[0], o[1]); u4.y = pack2bf(o[2], o[3]); u4.z = pack2bf(o[4], o[5]); u4.w = pack2bf(o[6], o[7]);
+                *(uint4*)dptr = u4;
+            } else if constexpr (VEC == 4) {
+                uint2 u2; u2.x = pack2bf(o[0], o[1]); u2.y = pack2bf(o[2], o[3]);
+                *(uint2*)dptr = u2;
+            } else if constexpr (VEC == 2) {
+                *(uint32_t*)dptr = pack2bf(o[0], o[1]);
+            } else {
+                *dptr = f2bf(o[0]);
+            }
         }
     }
 }
