@@ -24,6 +24,7 @@
 //     the two normalised outputs are summed in registers (blocks.py:213-217).
 #include "common.h"
 #include "launch.h"
+#include <cstdlib>
 
 namespace mdx {
 
@@ -44,6 +45,12 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
     constexpr int DP = D16 * 16;        // padded head dim for QK^T
     constexpr int KSTR = DP + 8;        // K LDS row stride (elements)
     constexpr int NT = NW * 64;
+    constexpr int KTOT = KVT * (DP / 8), VTOT = DT * 32 * (KVT / 8);       // 16-byte chunks per K / V^T tile
+    constexpr int KCH = (KTOT + NT - 1) / NT, VCH = (VTOT + NT - 1) / NT;  // chunks per thread
+    // Staging: issue ALL of a thread's 16-byte global loads for the tile back-to-back (one latency per tile
+    // instead of one per chunk), then write them to LDS.  The registers are live only across the load, not
+    // across the MFMA/softmax phase, so occupancy is unaffected.  Very wide heads fall back to a streaming loop.
+    constexpr bool UNR = (KCH + VCH) <= 24;
     __shared__ __attribute__((aligned(16))) bf16_t Ks[KVT * KSTR];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[DT * 32 * VSTR];
 
@@ -91,32 +98,79 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
         float l_run = 0.f;
 
         for (int j0 = 0; j0 < p.Tk; j0 += KVT) {
-            // ---- stage K tile: KVT rows x DP cols, 16-byte chunks ----
-            for (int c = tid; c < KVT * (DP / 8); c += NT) {
-                int row = c / (DP / 8);
-                int cc = c - row * (DP / 8);
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (j0 + row < p.Tk && cc * 8 < d) v = *(const uint4*)(kbase + (long)(j0 + row) * p.ldk + cc * 8);
-                *(uint4*)(Ks + row * KSTR + cc * 8) = v;
-            }
-            // ---- stage V^T tile: DT*32 rows (head dims) x KVT kv, 16-byte chunks along kv ----
-            for (int c = tid; c < DT * 32 * (KVT / 8); c += NT) {
-                int row = c >> 3;
-                int cc = c & 7;
-                Frag8 v;
-                v.u = make_uint4(0, 0, 0, 0);
-                int kv0 = j0 + cc * 8;
-                if (row < d && kv0 < p.Tk) {
-                    v.u = *(const uint4*)(vbase + (long)row * p.ldv + kv0);
-                    if (kv0 + 8 > p.Tk) {
+            if constexpr (UNR) {
+                uint4 kreg[KCH];
+                Frag8 vreg[VCH];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (kv0 + e >= p.Tk) v.h[e] = 0;
+                for (int i = 0; i < KCH; ++i) {
+                    const int c = tid + i * NT;
+                    const int row = c / (DP / 8);
+                    const int cc = c - row * (DP / 8);
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (c < KTOT && j0 + row < p.Tk && cc * 8 < d) v = *(const uint4*)(kbase + (long)(j0 + row) * p.ldk + cc * 8);
+                    kreg[i] = v;
+                }
+#pragma unroll
+                for (int i = 0; i < VCH; ++i) {
+                    const int c = tid + i * NT;
+                    const int row = c >> 3;
+                    const int kv0 = j0 + (c & 7) * 8;
+                    Frag8 v;
+                    v.u = make_uint4(0, 0, 0, 0);
+                    if (c < VTOT && row < d && kv0 < p.Tk) v.u = *(const uint4*)(vbase + (long)row * p.ldv + kv0);
+                    vreg[i] = v;
+                }
+#pragma unroll
+                for (int i = 0; i < KCH; ++i) {
+                    const int c = tid + i * NT;
+                    const int row = c / (DP / 8);
+                    const int cc = c - row * (DP / 8);
+                    if (c < KTOT) *(uint4*)(Ks + row * KSTR + cc * 8) = kreg[i];
+                }
+#pragma unroll
+                for (int i = 0; i < VCH; ++i) {
+                    const int c = tid + i * NT;
+                    if (c < VTOT) {
+                        Frag8 v = vreg[i];
+                        const int kv0 = j0 + (c & 7) * 8;
+                        if (kv0 + 8 > p.Tk) {          // V^T pad columns may hold anything: zero kv >= Tk
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (kv0 + e >= p.Tk) v.h[e] = 0;
+                        }
+                        uint2* dst = (uint2*)(Vs + (c >> 3) * VSTR + (c & 7) * 8);
+                        dst[0] = v.d2[0];
+                        dst[1] = v.d2[1];
                     }
                 }
-                uint2* dst = (uint2*)(Vs + row * VSTR + cc * 8);
-                dst[0] = v.d2[0];
-                dst[1] = v.d2[1];
+            } else {
+                // ---- stage K tile: KVT rows x DP cols, 16-byte chunks ----
+                for (int c = tid; c < KVT * (DP / 8); c += NT) {
+                    int row = c / (DP / 8);
+                    int cc = c - row * (DP / 8);
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (j0 + row < p.Tk && cc * 8 < d) v = *(const uint4*)(kbase + (long)(j0 + row) * p.ldk + cc * 8);
+                    *(uint4*)(Ks + row * KSTR + cc * 8) = v;
+                }
+                // ---- stage V^T tile: DT*32 rows (head dims) x KVT kv, 16-byte chunks along kv ----
+                for (int c = tid; c < DT * 32 * (KVT / 8); c += NT) {
+                    int row = c >> 3;
+                    int cc = c & 7;
+                    Frag8 v;
+                    v.u = make_uint4(0, 0, 0, 0);
+                    int kv0 = j0 + cc * 8;
+                    if (row < d && kv0 < p.Tk) {
+                        v.u = *(const uint4*)(vbase + (long)row * p.ldv + kv0);
+                        if (kv0 + 8 > p.Tk) {
+    #pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (kv0 + e >= p.Tk) v.h[e] = 0;
+                        }
+                    }
+                    uint2* dst = (uint2*)(Vs + row * VSTR + cc * 8);
+                    dst[0] = v.d2[0];
+                    dst[1] = v.d2[1];
+                }
             }
             __syncthreads();
 
@@ -242,7 +296,11 @@ static int launch_attn_nw(const AttnParams& p, hipStream_t st) {
     // 4 waves (128 queries) per workgroup when there are enough rows to fill 256 CUs, else
     // smaller workgroups so short sequences (91, 28 tokens) still spread over the chip.
     long blocks4 = (long)((p.Tq + 127) / 128) * p.H * p.B;
-    if (p.Tq >= 256 && blocks4 >= 4096) return launch_attn<D16, 4>(p, st);
+    static const long thr4 = [] { const char* e = getenv("MDX_ATTN_NW4_BLOCKS"); return e ? atol(e) : 256L; }();
+    static const long thr8 = [] { const char* e = getenv("MDX_ATTN_NW8_BLOCKS"); return e ? atol(e) : (1L << 40); }();
+    long blocks8 = (long)((p.Tq + 255) / 256) * p.H * p.B;
+    if (p.Tq >= 512 && blocks8 >= thr8) return launch_attn<D16, 8>(p, st);
+    if (p.Tq >= 256 && blocks4 >= thr4) return launch_attn<D16, 4>(p, st);
     if (p.Tq >= 64) return launch_attn<D16, 2>(p, st);
     return launch_attn<D16, 1>(p, st);
 }

@@ -45,6 +45,8 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GCParams p) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if (p.timing) ts0 = __builtin_amdgcn_s_memtime();
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     long zb = 0;       // batch index
@@ -155,6 +157,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GCParams p) {
         store_tile(0);
     }
     __syncthreads();
+    if (p.timing) ts1 = __builtin_amdgcn_s_memtime();
 
     const int frow = lane & 31;
     const int fk = (lane >> 5) * 8;
@@ -180,7 +183,18 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GCParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds m = column (lane&31), n rows 8g + 4*(lane>>5) + (0..3) ----
+    // ---- epilogue ----
+    if (p.timing) ts2 = __builtin_amdgcn_s_memtime();
+    if (p.splitk <= 1 && !p.c_f32) {   // block-uniform: bf16 output goes through the LDS transpose
+        epilogue_coalesced<BM, BN, TM, TN, 256>(p, zb, m0, n0, wm * TM * 32, wn * TN * 32, lane, tid, acc, smem);
+        if (p.timing && tid == 0) {
+            unsigned long long* t = p.timing + 5 * ((long)blockIdx.y * gridDim.x + blockIdx.x);
+            t[0] = ts0; t[1] = ts1; t[2] = ts2; t[3] = __builtin_amdgcn_s_memtime();
+            t[4] = 0;
+        }
+        return;
+    }
+    // fp32 output / split-K slabs: lane holds m = column (lane&31), n rows 8g + 4*(lane>>5) + (0..3)
     const int half = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -298,6 +312,8 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
     if (splitk > 1 && !p.ws) return set_error(MDX_EINVAL, "split-K needs a workspace");
     p.splitk = splitk;
     p.kchunk = kchunk;
+    static const int timing = [] { const char* e = getenv("MDX_GEMM_TIMING"); return e ? atoi(e) : 0; }();
+    p.timing = (timing && p.ws && splitk == 1) ? (unsigned long long*)p.ws : nullptr;
     int rc;
     if (impl != 0) {
         rc = launch_gemm_dma(p, conv, tile, st);

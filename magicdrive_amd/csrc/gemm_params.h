@@ -15,6 +15,7 @@ struct GCParams {
     int rows_per_b;
     int epi, splitk, kchunk, c_f32, batch;
     long ws_bytes;
+    unsigned long long* timing;   // debug: per-block s_memtime stamps (MDX_GEMM_TIMING=1), else null
     // conv geometry (CONV only); lda doubles as the pixel stride of X
     int Hi, Wi, Cin, Ho, Wo, kh, kw, sh, sw, ph, pw;
 };
@@ -69,6 +70,135 @@ __device__ __forceinline__ void epilogue_store(const GCParams& p, long zb, int m
         uint2 ov; ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]);
         *(uint2*)c = ov;
     }
+}
+
+
+// Phase 2 of the coalesced epilogue: walk the LDS tile row-major and write 256 contiguous bytes per row.
+// ALL residual loads of a thread are issued before the first is consumed (they are independent; issuing them
+// one per loop iteration serialised 16 memory round trips = 33k cycles per tile, measured).  R may alias C
+// (in-place accumulate): a thread reads exactly the addresses it later writes, so load-all-then-store is safe.
+template <int BM, int BNO, int NTHR>
+__device__ __forceinline__ void store_tile_rows(const GCParams& p, long zb, int m0, int n0o, int Nout, int tid, const bf16_t* Cs) {
+    constexpr int CPR = BNO / 4;                       // 8-byte chunks per tile row
+    constexpr int IT = (BM * CPR + NTHR - 1) / NTHR;
+    constexpr int CSTR = BNO + 4;
+    bf16_t* Cg = (bf16_t*)p.C + zb * p.sC;
+    const bf16_t* Rg = p.R ? (const bf16_t*)p.R + zb * p.sR : nullptr;
+    uint2 rv[IT];
+    bool ok[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int idx = tid + i * NTHR;
+        const int row = idx / CPR;
+        const int c4 = (idx - row * CPR) * 4;
+        const int m = m0 + row, n = n0o + c4;
+        ok[i] = (idx < BM * CPR) && m < p.M && n < Nout;
+        rv[i] = make_uint2(0, 0);
+        if (Rg && ok[i]) rv[i] = *(const uint2*)(Rg + (long)m * p.ldr + n);
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int idx = tid + i * NTHR;
+        const int row = idx / CPR;
+        const int c4 = (idx - row * CPR) * 4;
+        if (!ok[i]) continue;
+        uint2 v = *(const uint2*)(Cs + row * CSTR + c4);
+        if (Rg) {
+            float a0 = bf2f((bf16_t)(v.x & 0xffff)) + bf2f((bf16_t)(rv[i].x & 0xffff));
+            float a1 = bf2f((bf16_t)(v.x >> 16)) + bf2f((bf16_t)(rv[i].x >> 16));
+            float a2 = bf2f((bf16_t)(v.y & 0xffff)) + bf2f((bf16_t)(rv[i].y & 0xffff));
+            float a3 = bf2f((bf16_t)(v.y >> 16)) + bf2f((bf16_t)(rv[i].y >> 16));
+            v.x = pack2bf(a0, a1); v.y = pack2bf(a2, a3);
+        }
+        *(uint2*)(Cg + (long)(m0 + row) * p.ldc + n0o + c4) = v;
+    }
+}
+
+// ---- coalesced epilogue ----------------------------------------------------------------
+// The MFMA accumulator layout gives a lane 4 consecutive n of ONE output row, so storing straight from
+// registers writes 8-byte pieces at a row stride: every wave store touches 32 different 128-byte lines and
+// fills 1/8 of each (measured: small-K GEMMs were bound by exactly this, not by their main loop).
+// Instead the bf16 tile is transposed through LDS (the A/B ring is dead after the main loop): phase 1 applies
+// bias / temb / activation in registers and writes the tile to LDS (row stride BNo+4 elements: conflict-free
+// ds_write_b64), phase 2 walks the tile row-major, 32 lanes x 8 B = 256 contiguous bytes per output row, adds
+// the residual (read with the same coalesced pattern) and stores.
+// Uniform control flow: every thread of the block must call it (it contains __syncthreads()).
+template <int BM, int BN, int TM, int TN, int NTHR>
+__device__ __forceinline__ void epilogue_coalesced(const GCParams& p, long zb, int m0, int n0, int wrow0, int wcol0, int lane,
+                                                   int tid, f32x16_t (&acc)[TM][TN], unsigned char* smem) {
+    const bool geglu = p.epi == 1;
+    const int BNo = geglu ? BN / 2 : BN;              // output columns of this tile
+    const int CSTR = BNo + 4;                          // LDS row stride (elements)
+    bf16_t* Cs = (bf16_t*)smem;
+    const int frow = lane & 31, half = lane >> 5;
+    // Per-column addends first, ALL loads issued before any use (one memory round trip, not one per element —
+    // element-wise `bias[n]` loads behind per-group branches cost ~30k cycles per tile, measured):
+    // bias is a function of the column only; temb of (batch row, column).
+    float4 bv[TN][4];
+    float4 tv[TM][TN][4];
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nb = n0 + wcol0 + j * 32 + 8 * g + 4 * half;
+            bv[j][g] = (p.bias && nb < p.N) ? *(const float4*)(p.bias + nb) : z4;
+        }
+    const bool has_t = p.temb != nullptr && !geglu;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wrow0 + i * 32 + frow;
+        const float* tb = nullptr;
+        if (has_t) {
+            const int sel = p.sel ? *p.sel : 0;
+            tb = p.temb + (long)sel * p.temb_sel_stride + (long)((m < p.M ? m : 0) / p.rows_per_b) * p.temb_b_stride;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nb = n0 + wcol0 + j * 32 + 8 * g + 4 * half;
+                tv[i][j][g] = (has_t && nb < p.N) ? *(const float4*)(tb + nb) : z4;
+            }
+    }
+    __syncthreads();                                   // all waves finished reading the operand slabs
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ml = wrow0 + i * 32 + frow;          // row inside the tile
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (geglu && (j & 1)) continue;            // gate tiles are consumed with their value tile
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = wcol0 + j * 32 + 8 * g + 4 * half;      // raw column inside the tile
+                const float bb[4] = {bv[j][g].x, bv[j][g].y, bv[j][g].z, bv[j][g].w};
+                const float tt[4] = {tv[i][j][g].x, tv[i][j][g].y, tv[i][j][g].z, tv[i][j][g].w};
+                const float4 bg4 = bv[(TN > 1) ? (j | 1) : j][g];
+                const float bgt[4] = {bg4.x, bg4.y, bg4.z, bg4.w};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[i][j][4 * g + e] + bb[e];
+                    if (geglu) {
+                        float gt = acc[i][(TN > 1) ? (j | 1) : j][4 * g + e] + bgt[e];
+                        x = x * gelu_erf_f(gt);
+                    } else {
+                        x += tt[e];
+                        if (p.epi == 2) x = silu_f(x);
+                    }
+                    o[e] = x;
+                }
+                const int cl = geglu ? ((nl >> 6) * 32 + (nl & 63)) : nl;   // output column inside the tile
+                uint2 ov; ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]);
+                *(uint2*)(Cs + ml * CSTR + cl) = ov;
+            }
+        }
+    }
+    __syncthreads();
+    const int n0o = geglu ? n0 / 2 : n0;
+    const int Nout = geglu ? p.N / 2 : p.N;
+    if (geglu) store_tile_rows<BM, BN / 2, NTHR>(p, zb, m0, n0o, Nout, tid, Cs);
+    else store_tile_rows<BM, BN, NTHR>(p, zb, m0, n0o, Nout, tid, Cs);
 }
 
 }  // namespace mdx
