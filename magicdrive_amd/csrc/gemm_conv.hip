@@ -47,8 +47,10 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GCParams p) {
     const int wm = wave & 1, wn = wave >> 1;
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
     if (p.timing) ts0 = __builtin_amdgcn_s_memtime();
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    int tile_m, tile_n;
+    if (!tile_coords(p, tile_m, tile_n)) return;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
     long zb = 0;       // batch index
     int kz = 0;        // split-K slice
     if (p.batch > 1) zb = blockIdx.z; else kz = blockIdx.z;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GCParams p) {
     if (p.splitk <= 1 && !p.c_f32) {   // block-uniform: bf16 output goes through the LDS transpose
         epilogue_coalesced<BM, BN, TM, TN, 256>(p, zb, m0, n0, wm * TM * 32, wn * TN * 32, lane, tid, acc, smem);
         if (p.timing && tid == 0) {
-            unsigned long long* t = p.timing + 5 * ((long)blockIdx.y * gridDim.x + blockIdx.x);
+            unsigned long long* t = p.timing + 5 * ((long)tile_n * p.mt + tile_m);
             t[0] = ts0; t[1] = ts1; t[2] = ts2; t[3] = __builtin_amdgcn_s_memtime();
             t[4] = 0;
         }
@@ -255,8 +257,13 @@ static int launch_one(const GCParams& p, hipStream_t st) {
         if (e != hipSuccess) return set_error(MDX_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, p.batch > 1 ? p.batch : p.splitk);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+    GCParams q = p;
+    q.mt = (p.M + BM - 1) / BM; q.nt = (p.N + BN - 1) / BN;
+    static const int swz = [] { const char* e = getenv("MDX_GEMM_SWZ"); return e ? atoi(e) : 1; }();
+    q.swz = swz && q.nt > 1 && q.mt >= 128;   // pays when A (activations) dwarfs W; mid-size M prefers W-tile reuse (measured)
+    const unsigned nblk = q.swz ? (unsigned)((q.mt + 7) / 8 * 8 * q.nt) : (unsigned)(q.mt * q.nt);
+    dim3 grid(nblk, 1, p.batch > 1 ? p.batch : p.splitk);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
     return check_launch("gemm_conv_kernel");
 }
 
@@ -294,8 +301,8 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
     int splitk = 1;
     if (p.splitk > 0) {
         splitk = p.splitk;  // caller forced
-    } else if (p.batch <= 1 && p.ws && tiles < 160 && p.K >= 1024 && (p.N % 4) == 0) {
-        long want = (512 + tiles - 1) / tiles;
+    } else if (p.batch <= 1 && p.ws && tiles < 384 && p.K >= 1024 && (p.N % 4) == 0) {
+        long want = (768 + tiles - 1) / tiles;
         long maxs = p.K / 512;  // keep >= 8 K-slabs per slice
         splitk = (int)min(min(want, maxs), 32L);
         if (splitk < 1) splitk = 1;

@@ -50,8 +50,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GCParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    int tile_m, tile_n;
+    if (!tile_coords(p, tile_m, tile_n)) return;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
     long zb = 0;
     int kz = 0;
     if (p.batch > 1) zb = blockIdx.z; else kz = blockIdx.z;
@@ -195,6 +197,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GCParams p) {
     }
 
     // ---- epilogue (same contract as gemm_conv.hip) ----
+    if (p.splitk <= 1 && !p.c_f32) {   // block-uniform: bf16 output goes through the LDS transpose (ring is dead now)
+        epilogue_coalesced<BM, BN, TM, TN, NWV * 64>(p, zb, m0, n0, wm * TM * 32, wn * TN * 32, lane, tid, acc, smem);
+        return;
+    }
     const int half = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -225,7 +231,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GCParams p) {
 
 template <int BM, int BN, int WM, int WN, int BK, int ST, bool CONV>
 static int launch_dma_one(const GCParams& p, hipStream_t st) {
-    constexpr size_t smem = (size_t)ST * (BM + BN) * BK * 2;
+    constexpr size_t ring = (size_t)ST * (BM + BN) * BK * 2, ctile = (size_t)BM * (BN + 4) * 2;   // the C tile reuses the ring
+    constexpr size_t smem = ring > ctile ? ring : ctile;
     static bool attr_done = false;
     auto kern = gemm_dma_kernel<BM, BN, WM, WN, BK, ST, CONV>;
     if (!attr_done) {
@@ -233,8 +240,10 @@ static int launch_dma_one(const GCParams& p, hipStream_t st) {
         if (e != hipSuccess) return set_error(MDX_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, p.batch > 1 ? p.batch : p.splitk);
-    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, p);
+    GCParams q = p;
+    q.mt = (p.M + BM - 1) / BM; q.nt = (p.N + BN - 1) / BN; q.swz = 0;
+    dim3 grid((unsigned)(q.mt * q.nt), 1, p.batch > 1 ? p.batch : p.splitk);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, q);
     return check_launch("gemm_dma_kernel");
 }
 

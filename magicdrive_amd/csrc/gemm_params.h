@@ -15,10 +15,26 @@ struct GCParams {
     int rows_per_b;
     int epi, splitk, kchunk, c_f32, batch;
     long ws_bytes;
+    int mt, nt, swz;              // tile counts along M / N; swz: XCD-aware tile order (1-D grid)
     unsigned long long* timing;   // debug: per-block s_memtime stamps (MDX_GEMM_TIMING=1), else null
     // conv geometry (CONV only); lda doubles as the pixel stride of X
     int Hi, Wi, Cin, Ho, Wo, kh, kw, sh, sw, ph, pw;
 };
+
+// ---- tile order ------------------------------------------------------------------------
+// 1-D grid -> (M-tile, N-tile).  Workgroup b lands on XCD b % 8 (observed dispatch rule, used for speed only).
+// With swz, XCD x owns M-tiles x, x+8, x+16, ... and walks all N-tiles of one M-tile back to back, so the
+// A rows of that M-tile (and, for conv, the overlapping rows of its 9 taps) are fetched into ONE XCD's L2 once
+// instead of N-tiles times into different L2s at different times (activations at b>=4 exceed the 4 MiB L2s;
+// without this the re-reads come from the Infinity Cache).  Returns false for padding blocks of a ragged grid.
+__device__ __forceinline__ bool tile_coords(const GCParams& p, int& tm, int& tn) {
+    const int bid = blockIdx.x;
+    if (!p.swz) { tm = bid % p.mt; tn = bid / p.mt; return true; }
+    const int xcd = bid & 7, local = bid >> 3;
+    tn = local % p.nt;
+    tm = (local / p.nt) * 8 + xcd;
+    return tm < p.mt;
+}
 
 // ---- shared epilogue ---------------------------------------------------------------
 // v[4] are raw accumulators for output row m, raw columns nb..nb+3 (nb % 4 == 0).

@@ -76,6 +76,13 @@ class PackedNet:
         b = self._get("geglub", [wkey, bkey], lambda w, b: PK.pack_geglu(w, b)[1])
         return w, b
 
+    def folded_affine(self, w2key, b2key, w1key, b1key, b1_scale: float = 1.0):
+        """y = W2 (W1 x + s b1) + b2  ->  (W2 W1) x + (W2 s b1 + b2), folded in fp32."""
+        keys = [w2key, b2key, w1key, b1key]
+        w = self._get(("foldw", b1_scale), keys, lambda w2, b2, w1, b1: (w2 @ w1).contiguous().to(BF16))
+        b = self._get(("foldb", b1_scale), keys, lambda w2, b2, w1, b1: (w2 @ (b1 * b1_scale) + b2).contiguous().to(F32))
+        return w, b
+
     def table(self, key):                              # 2-D bf16 table (class tokens)
         return self._get("table", [key], lambda t: t.contiguous().to(BF16))
 
@@ -252,10 +259,11 @@ class Builder:
             n4 = self.layernorm(net, pre + "norm4.", h2, name + ".norm4")
             ao4 = self.self_like_attention(net, pre + "attn4.", n4, B, T, C, heads, True, name + ".attn4")
             self.pool.put(n4)
-            t4 = self.gemm(ao4, net.lin(pre + "attn4.to_out.0.weight"), C, bias=net.vec(pre + "attn4.to_out.0.bias", 2.0), name=name + ".attn4.out")
-            self.pool.put(ao4)
-            h3 = self.gemm(t4, net.lin(pre + "connector.weight"), C, bias=net.vec(pre + "connector.bias"), R=h2, name=name + ".connector")
-            self.pool.put(t4); self.pool.put(h2)
+            # connector(to_out(o_l + o_r) + 2 b_o) is one affine map: fold it at pack time,
+            #   W = W_c W_o ,  b = W_c (2 b_o) + b_c     (one GEMM instead of two per block; fp32 fold, bf16 weights)
+            wf, bf_ = net.folded_affine(pre + "connector.weight", pre + "connector.bias", pre + "attn4.to_out.0.weight", pre + "attn4.to_out.0.bias", 2.0)
+            h3 = self.gemm(ao4, wf, C, bias=bf_, R=h2, name=name + ".attn4.out+connector")
+            self.pool.put(ao4); self.pool.put(h2)
         else:
             h3 = h2
         # 3. GEGLU feed-forward

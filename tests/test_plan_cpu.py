@@ -74,7 +74,8 @@ def test_sampler_plan_matches_golden_pipeline(tiny, do_cfg):
 
 
 def test_step_program_work_is_deduplicated():
-    """F_step(224x400, L=32, c=1) ~= 2.325 TF after removing the reference's redundant work."""
+    """SURVEY.md §8d: F_step(224x400, L=32, c=1) ~= 2.325 TF after removing the reference's redundant work;
+    folding connector o attn4.to_out into one matrix (engine.py) removes a further 16 C x C GEMMs = 0.027 TF."""
     cfg = spec.SD15_CONFIG
     z = lambda shapes: {k: torch.zeros(1).expand(s) for k, s in shapes.items()}      # shape-only weights
 
@@ -89,5 +90,5 @@ def test_step_program_work_is_deduplicated():
     sp = DN.SamplerPlan(cfg, un, cn, CPU, 1, False, 32, (28, 50), num_steps=50)
     f = flops.program_flops(sp.step_ops)["total"] / 1e12
     fp = flops.program_flops(sp.prologue_ops)["total"] / 1e12
-    assert abs(f - 2.325) < 0.01, f
+    assert abs(f - 2.298) < 0.01, f
     assert abs(fp - 0.045) < 0.005, fp
