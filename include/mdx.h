@@ -145,13 +145,15 @@ int mdx_attention_bf16(const MdxAttnDesc* d, void* stream);
 /*
  * mdx_groupnorm_bf16 — GroupNorm(+SiLU) over channels-last [B][HW][C]
  * (ATen native_group_norm + silu: resnet.py:596-598, 626-630; transformer_2d.py:278;
- *  unet_2d_condition_multiview.py:519-521).  stats in fp32, two-pass variance.
+ *  unet_2d_condition_multiview.py:519-521).  Statistics in fp32, pivot-shifted / Chan-combined (no E[x^2]-E[x]^2
+ * cancellation); with a workspace, large maps take a two-stage fully coalesced path (deterministic, no atomics).
  */
 typedef struct MdxGroupNormDesc {
     const void* X; void* Y; const float* gamma; const float* beta;
     int64_t B, HW, C, G, ldx, ldy;
     double eps;
     int64_t silu;
+    float* ws; int64_t ws_bytes;   /* optional scratch for the two-stage (coalesced) path: B*chunks*G*3 floats */
 } MdxGroupNormDesc;
 int mdx_groupnorm_bf16(const MdxGroupNormDesc* d, void* stream);
 

@@ -9,6 +9,7 @@
 //   row, 16-byte loads, shuffle reductions.
 #include "common.h"
 #include "launch.h"
+#include <cstdlib>
 
 namespace mdx {
 
@@ -136,6 +137,118 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_kernel(GNParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two-stage GroupNorm for the big (HBM/Infinity-Cache-bound) feature maps: every global access is a full
+// 16-byte-per-lane coalesced row segment (the one-workgroup-per-group kernel above reads 20-byte pieces at a
+// 640-byte stride when C/G = 10).  Deterministic: no atomics, partials combined in a fixed order (Chan).
+//   stage 1  gn_stats_kernel : grid (chunks, B); a chunk = PCH pixels x C staged in LDS; thread (g, s) reduces
+//            its group over pixels s, s+SUB, ... -> (n, mean, M2) per (b, chunk, g)
+//   stage 2  gn_apply_kernel : grid (chunks, B); combines the chunk partials of its b, builds per-channel
+//            scale/shift in LDS, then y = [silu](x * scale[c] + shift[c]) with 16-byte loads/stores.
+struct GN2Params {
+    const bf16_t* X; bf16_t* Y; const float* gamma; const float* beta; float* part;   // part: [B][nchunk][G][3]
+    int B, HW, C, G, PCH, nchunk; long ldx, ldy; float eps; int silu;
+};
+
+constexpr int GN2_TILE = 16384;   // elements staged per workgroup (32 KiB of LDS)
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(GN2Params p) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[GN2_TILE];
+    __shared__ float red[256 * 3];
+    const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int px0 = chunk * p.PCH;
+    const int npx = min(p.PCH, p.HW - px0);
+    const int C8 = p.C / 8;
+    const bf16_t* xb = p.X + ((long)b * p.HW + px0) * p.ldx;
+    for (int i = tid; i < npx * C8; i += 256) {
+        const int px = i / C8, cc = i - px * C8;
+        *(uint4*)(tile + px * p.C + cc * 8) = *(const uint4*)(xb + (long)px * p.ldx + cc * 8);
+    }
+    __syncthreads();
+    const int SUB = 256 / p.G;                 // pixel sub-slots per group
+    const int g = tid % p.G, sl = tid / p.G;
+    const int cpg = p.C / p.G;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (sl < SUB) {
+        const float pivot = bf2f(tile[g * cpg]);
+        float s1 = 0.f, s2 = 0.f;
+        int cnt = 0;
+        for (int px = sl; px < npx; px += SUB) {
+            const bf16_t* t = tile + px * p.C + g * cpg;
+            for (int c = 0; c < cpg; c += 2) {          // cpg is even for every shape routed here
+                const uint32_t u = *(const uint32_t*)(t + c);
+                const float a = bf2f((bf16_t)(u & 0xffff)) - pivot, d = bf2f((bf16_t)(u >> 16)) - pivot;
+                s1 += a + d; s2 += a * a + d * d;
+            }
+            cnt += cpg;
+        }
+        if (cnt > 0) { n = (float)cnt; mean = pivot + s1 / n; m2 = fmaxf(s2 - s1 * s1 / n, 0.f); }
+    }
+    red[tid * 3] = n; red[tid * 3 + 1] = mean; red[tid * 3 + 2] = m2;
+    __syncthreads();
+    if (tid < p.G) {                            // fixed-order Chan combine of the SUB sub-slots
+        float na = 0.f, ma = 0.f, qa = 0.f;
+        for (int s2i = 0; s2i < SUB; ++s2i) {
+            const float nb = red[(s2i * p.G + tid) * 3], mb = red[(s2i * p.G + tid) * 3 + 1], qb = red[(s2i * p.G + tid) * 3 + 2];
+            if (nb > 0.f) {
+                const float nn = na + nb, dl = mb - ma;
+                ma += dl * nb / nn; qa += qb + dl * dl * na * nb / nn; na = nn;
+            }
+        }
+        float* o = p.part + (((long)b * p.nchunk + chunk) * p.G + tid) * 3;
+        o[0] = na; o[1] = ma; o[2] = qa;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(GN2Params p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [G] mean, [G] rstd, [C] scale, [C] shift
+    float* gmean = sm; float* grstd = sm + p.G; float* sc = sm + 2 * p.G; float* sh = sc + p.C;
+    const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (tid < p.G) {
+        float na = 0.f, ma = 0.f, qa = 0.f;
+        const float* pp = p.part + ((long)b * p.nchunk * p.G + tid) * 3;
+        for (int k = 0; k < p.nchunk; ++k) {
+            const float nb = pp[(long)k * p.G * 3], mb = pp[(long)k * p.G * 3 + 1], qb = pp[(long)k * p.G * 3 + 2];
+            if (nb > 0.f) {
+                const float nn = na + nb, dl = mb - ma;
+                ma += dl * nb / nn; qa += qb + dl * dl * na * nb / nn; na = nn;
+            }
+        }
+        gmean[tid] = ma;
+        grstd[tid] = rsqrtf(qa / na + p.eps);
+    }
+    __syncthreads();
+    const int cpg = p.C / p.G;
+    for (int c = tid; c < p.C; c += 256) {
+        const int g = c / cpg;
+        const float s = grstd[g] * p.gamma[c];
+        sc[c] = s; sh[c] = p.beta[c] - gmean[g] * s;
+    }
+    __syncthreads();
+    const int px0 = chunk * p.PCH;
+    const int npx = min(p.PCH, p.HW - px0);
+    const int C8 = p.C / 8;
+    const bf16_t* xb = p.X + ((long)b * p.HW + px0) * p.ldx;
+    bf16_t* yb = p.Y + ((long)b * p.HW + px0) * p.ldy;
+    for (int i = tid; i < npx * C8; i += 256) {
+        const int px = i / C8, cc = i - px * C8;
+        Frag8 f; f.u = *(const uint4*)(xb + (long)px * p.ldx + cc * 8);
+        const float4 s0 = *(const float4*)(sc + cc * 8), s1 = *(const float4*)(sc + cc * 8 + 4);
+        const float4 h0 = *(const float4*)(sh + cc * 8), h1 = *(const float4*)(sh + cc * 8 + 4);
+        const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = bf2f(f.h[e]) * sv[e] + hv[e];
+            if (p.silu) y = silu_f(y);
+            o[e] = y;
+        }
+        uint4 u; u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]); u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
+        *(uint4*)(yb + (long)px * p.ldy + cc * 8) = u;
+    }
+}
+
 struct LNParams {
     const bf16_t* X; bf16_t* Y; const float* gamma; const float* beta;
     int M, C; long ldx, ldy; float eps;
@@ -200,13 +313,33 @@ extern "C" int mdx_groupnorm_bf16(const MdxGroupNormDesc* d, void* stream) {
     p.B = (int)d->B; p.HW = (int)d->HW; p.C = (int)d->C; p.G = (int)d->G; p.ldx = d->ldx; p.ldy = d->ldy;
     p.eps = (float)d->eps; p.silu = (int)d->silu;
     const int cpg = p.C / p.G;
+    hipStream_t st = (hipStream_t)stream;
+    // big maps: two-stage coalesced path (needs 16-byte rows, even cpg, G | 256, a partials workspace)
+    static const int two_stage = [] { const char* e = getenv("MDX_GN_TWO_STAGE"); return e ? atoi(e) : 1; }();
+    const long elems = (long)p.HW * p.C;
+    if (two_stage && d->ws && elems >= 32768 && p.C % 8 == 0 && p.C <= GN2_TILE && cpg % 2 == 0 && 256 % p.G == 0 && p.ldx % 8 == 0 && p.ldy % 8 == 0 &&
+        ((uintptr_t)p.X & 15) == 0 && ((uintptr_t)p.Y & 15) == 0) {
+        GN2Params q;
+        q.X = p.X; q.Y = p.Y; q.gamma = p.gamma; q.beta = p.beta; q.part = (float*)d->ws;
+        q.B = p.B; q.HW = p.HW; q.C = p.C; q.G = p.G; q.ldx = p.ldx; q.ldy = p.ldy; q.eps = p.eps; q.silu = p.silu;
+        q.PCH = GN2_TILE / p.C; if (q.PCH > p.HW) q.PCH = p.HW;
+        q.nchunk = (p.HW + q.PCH - 1) / q.PCH;
+        if ((long)p.B * q.nchunk * p.G * 3 * (long)sizeof(float) <= d->ws_bytes) {
+            dim3 grid2(q.nchunk, p.B);
+            hipLaunchKernelGGL(gn_stats_kernel, grid2, dim3(256), 0, st, q);
+            int rc = check_launch("gn_stats_kernel");
+            if (rc) return rc;
+            size_t sm = (size_t)(2 * p.G + 2 * p.C) * sizeof(float);
+            hipLaunchKernelGGL(gn_apply_kernel, grid2, dim3(256), sm, st, q);
+            return check_launch("gn_apply_kernel");
+        }
+    }
     // vector width limited by cpg and by the alignment of every group start / row stride
     int vec = 1;
     for (int v = 8; v > 1; v >>= 1) {
         if (cpg % v == 0 && p.ldx % v == 0 && p.ldy % v == 0 && ((uintptr_t)p.X % (2 * v)) == 0 && ((uintptr_t)p.Y % (2 * v)) == 0) { vec = v; break; }
     }
     dim3 grid(p.G, p.B);
-    hipStream_t st = (hipStream_t)stream;
     switch (vec) {
         case 8: hipLaunchKernelGGL(groupnorm_kernel<8>, grid, dim3(GN_THREADS), 0, st, p); break;
         case 4: hipLaunchKernelGGL(groupnorm_kernel<4>, grid, dim3(GN_THREADS), 0, st, p); break;

@@ -182,7 +182,7 @@ class Builder:
 
     def groupnorm(self, net, pre, x: Act, eps, silu, name) -> Act:
         y = self.new(x.B, x.H, x.W, x.C)
-        self.emit(O.GroupNorm(x.btc, y.btc, net.vec(pre + "weight"), net.vec(pre + "bias"), self.groups, eps, silu, name=name))
+        self.emit(O.GroupNorm(x.btc, y.btc, net.vec(pre + "weight"), net.vec(pre + "bias"), self.groups, eps, silu, ws=self.ws, name=name))
         return y
 
     def layernorm(self, net, pre, x: torch.Tensor, name) -> torch.Tensor:

@@ -220,6 +220,7 @@ class GroupNorm:
     groups: int
     eps: float
     silu: bool = False
+    ws: Optional[torch.Tensor] = None
     name: str = ""
     opcode = L.OP_GROUPNORM
 
@@ -232,6 +233,8 @@ class GroupNorm:
         d.X, d.Y, d.gamma, d.beta = _p(self.X), _p(self.Y), _p(self.gamma), _p(self.beta)
         d.B, d.HW, d.C, d.G, d.ldx, d.ldy = B, HW, Cc, self.groups, self.X.stride(1), self.Y.stride(1)
         d.eps, d.silu = float(self.eps), int(self.silu)
+        if self.ws is not None:
+            d.ws = _p(self.ws); d.ws_bytes = self.ws.numel() * self.ws.element_size()
         return self.opcode, d
 
 

@@ -258,10 +258,13 @@ def test_groupnorm(dev, B, HW, Cc, G, silu, eps):
     gam = rnd(Cc, seed=2, dtype=torch.float32); bet = rnd(Cc, seed=3, dtype=torch.float32)
     y = torch.zeros_like(x)
     O.run_ops([O.GroupNorm(x, y, gam, bet, groups=G, eps=eps, silu=silu)])
+    y2 = torch.zeros_like(x)      # with a workspace: the two-stage coalesced path for big maps
+    O.run_ops([O.GroupNorm(x, y2, gam, bet, groups=G, eps=eps, silu=silu, ws=ws_buf(dev, 4))])
     torch.cuda.synchronize()
     ref = F.group_norm(x.float().cpu().transpose(1, 2), G, gam.cpu(), bet.cpu(), eps)
     if silu: ref = F.silu(ref)
     close(y, ref.transpose(1, 2), name="groupnorm")
+    close(y2, ref.transpose(1, 2), name="groupnorm two-stage")
 
 
 def test_groupnorm_channel_slice_view(dev):
