@@ -30,13 +30,16 @@ namespace mdx {
 int launch_gemm_dma(const GCParams& p, bool conv, int tile, hipStream_t st);
 void dma_tile_dims(int tile, int* bm, int* bn);
 
-template <int BM, int BN, int BK, bool CONV>
-__global__ __launch_bounds__(256) void gemm_conv_kernel(GCParams p) {
+// WM x WN waves (NTH = 64 WM WN threads); each wave owns a (BM/WM) x (BN/WN) sub-tile of 32x32 MFMA tiles.
+template <int BM, int BN, int BK, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 1) void gemm_conv_kernel(GCParams p) {
+    constexpr int NTH = WM * WN * 64;
     constexpr int LSTR = BK + 8;  // LDS row stride in elements (+16 B pad: conflict-free ds_read_b128)
     constexpr int KCH = BK / 8;   // 16-byte chunks per row of a slab
-    constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int A_CH = BM * BK / 8 / 256;
-    constexpr int B_CH = BN * BK / 8 / 256;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int A_CH = BM * BK / 8 / NTH;
+    constexpr int B_CH = BN * BK / 8 / NTH;
+    static_assert(A_CH >= 1 && B_CH >= 1, "tile too small for the thread count");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* As = (bf16_t*)smem;              // [2][BM][LSTR]
     bf16_t* Bs = As + 2 * BM * LSTR;         // [2][BN][LSTR]
@@ -44,7 +47,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GCParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave % WM, wn = wave / WM;
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
     if (p.timing) ts0 = __builtin_amdgcn_s_memtime();
     int tile_m, tile_n;
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GCParams p) {
     const int kend = min(p.K, kbeg + p.kchunk);
     const int nt = (kend - kbeg + BK - 1) / BK;
 
-    constexpr int RSTEP = 256 / KCH;   // rows covered by one pass of the 256 threads
+    constexpr int RSTEP = NTH / KCH;   // rows covered by one pass of the workgroup's threads
     const int kc = tid % KCH;     // 16-byte chunk within the BK-wide k slab
     const int rbase = tid / KCH;
 
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GCParams p) {
     // ---- epilogue ----
     if (p.timing) ts2 = __builtin_amdgcn_s_memtime();
     if (p.splitk <= 1 && !p.c_f32) {   // block-uniform: bf16 output goes through the LDS transpose
-        epilogue_coalesced<BM, BN, TM, TN, 256>(p, zb, m0, n0, wm * TM * 32, wn * TN * 32, lane, tid, acc, smem);
+        epilogue_coalesced<BM, BN, TM, TN, NTH>(p, zb, m0, n0, wm * TM * 32, wn * TN * 32, lane, tid, acc, smem);
         if (p.timing && tid == 0) {
             unsigned long long* t = p.timing + 5 * ((long)tile_n * p.mt + tile_m);
             t[0] = ts0; t[1] = ts1; t[2] = ts2; t[3] = __builtin_amdgcn_s_memtime();
@@ -247,11 +250,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GCParams p) {
     epilogue_store(p, 0, m, nb, v, g);
 }
 
-template <int BM, int BN, int BK, bool CONV>
+template <int BM, int BN, int BK, int WM, int WN, bool CONV>
 static int launch_one(const GCParams& p, hipStream_t st) {
-    constexpr size_t smem = (size_t)2 * (BM + BN) * (BK + 8) * sizeof(bf16_t);
+    constexpr size_t ring = (size_t)2 * (BM + BN) * (BK + 8) * sizeof(bf16_t), ctile = (size_t)BM * (BN + 4) * 2;
+    constexpr size_t smem = ring > ctile ? ring : ctile;
     static bool attr_done = false;
-    auto kern = gemm_conv_kernel<BM, BN, BK, CONV>;
+    auto kern = gemm_conv_kernel<BM, BN, BK, WM, WN, CONV>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return set_error(MDX_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -263,7 +267,7 @@ static int launch_one(const GCParams& p, hipStream_t st) {
     q.swz = swz && q.nt > 1 && q.mt >= 128;   // pays when A (activations) dwarfs W; mid-size M prefers W-tile reuse (measured)
     const unsigned nblk = q.swz ? (unsigned)((q.mt + 7) / 8 * 8 * q.nt) : (unsigned)(q.mt * q.nt);
     dim3 grid(nblk, 1, p.batch > 1 ? p.batch : p.splitk);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, q);
     return check_launch("gemm_conv_kernel");
 }
 
@@ -281,6 +285,8 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
         BN = 128;
         if (!geglu && (p.N <= 64 || (p.N % 128 != 0 && p.N <= 192))) BN = 64;
         BM = p.M >= 2048 ? 128 : 64;
+        static const int big = [] { const char* e = getenv("MDX_GEMM_BM256"); return e ? atoi(e) : 0; }();
+        if (big && BN == 128 && p.M >= big) BM = 256;
     } else {
         if (impl >= 10) {
             tile = impl - 10;
@@ -326,12 +332,14 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
         rc = launch_gemm_dma(p, conv, tile, st);
     } else {
         static const int bk = [] { const char* e = getenv("MDX_GEMM_BK"); return e ? atoi(e) : 64; }();
-#define MDX_GC(BM_, BN_) (bk == 32 ? (conv ? launch_one<BM_, BN_, 32, true>(p, st) : launch_one<BM_, BN_, 32, false>(p, st)) \
-                                   : (conv ? launch_one<BM_, BN_, 64, true>(p, st) : launch_one<BM_, BN_, 64, false>(p, st)))
-        if (BM == 128 && BN == 128) rc = MDX_GC(128, 128);
+#define MDX_GC2(BM_, BN_, BK_, WM_, WN_) (conv ? launch_one<BM_, BN_, BK_, WM_, WN_, true>(p, st) : launch_one<BM_, BN_, BK_, WM_, WN_, false>(p, st))
+#define MDX_GC(BM_, BN_) (bk == 32 ? MDX_GC2(BM_, BN_, 32, 2, 2) : MDX_GC2(BM_, BN_, 64, 2, 2))
+        if (BM == 256 && BN == 128) rc = (bk == 32) ? MDX_GC2(256, 128, 32, 4, 2) : MDX_GC2(256, 128, 64, 4, 2);
+        else if (BM == 128 && BN == 128) rc = MDX_GC(128, 128);
         else if (BM == 128 && BN == 64) rc = MDX_GC(128, 64);
         else if (BM == 64 && BN == 128) rc = MDX_GC(64, 128);
         else rc = MDX_GC(64, 64);
+#undef MDX_GC2
 #undef MDX_GC
     }
     if (rc != MDX_OK) return rc;

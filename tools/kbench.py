@@ -87,7 +87,7 @@ def main():
     if "norm" in a.only:
         for (h, w, C) in [(28, 50, 320), (28, 50, 640), (14, 25, 640), (14, 25, 1920), (7, 13, 1280), (4, 7, 2560)]:
             x = r(B, h * w, C); y = torch.empty_like(x)
-            us = timeit(O.GroupNorm(x, y, torch.ones(C, device=dev), torch.zeros(C, device=dev), 32, 1e-5, True), a.reps)
+            us = timeit(O.GroupNorm(x, y, torch.ones(C, device=dev), torch.zeros(C, device=dev), 32, 1e-5, True, ws=ws), a.reps)
             rec("norm", f"GN {h}x{w} C={C}", us, 0)
         for (h, w, C) in lv[:3]:
             x = r(B * h * w, C); y = torch.empty_like(x)
