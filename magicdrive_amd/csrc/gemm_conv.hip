@@ -149,6 +149,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 1) void gemm_con
             *(uint4*)(bs + (rbase + RSTEP * i) * LSTR + kc * 8) = b_reg[i];
     };
 
+    EpiRegs<BM, BN, TN, NTH> er;
+    const bool coalesced_out = p.splitk <= 1 && !p.c_f32;   // block-uniform
+    if (coalesced_out) epi_prefetch<BM, BN, TN, NTH>(p, zb, m0, n0, wn * TN * 32, lane, tid, er);
+
     f32x16_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -190,8 +194,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 1) void gemm_con
 
     // ---- epilogue ----
     if (p.timing) ts2 = __builtin_amdgcn_s_memtime();
-    if (p.splitk <= 1 && !p.c_f32) {   // block-uniform: bf16 output goes through the LDS transpose
-        epilogue_coalesced<BM, BN, TM, TN, NTH>(p, zb, m0, n0, wm * TM * 32, wn * TN * 32, lane, tid, acc, smem);
+    if (coalesced_out) {   // block-uniform: bf16 output goes through the LDS transpose
+        epilogue_coalesced<BM, BN, TM, TN, NTH>(p, zb, m0, n0, wm * TM * 32, wn * TN * 32, lane, tid, acc, smem, er);
         if (p.timing && tid == 0) {
             unsigned long long* t = p.timing + 5 * ((long)tile_n * p.mt + tile_m);
             t[0] = ts0; t[1] = ts1; t[2] = ts2; t[3] = __builtin_amdgcn_s_memtime();

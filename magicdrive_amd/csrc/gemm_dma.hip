@@ -142,6 +142,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GCParams p) {
         }
     };
 
+    EpiRegs<BM, BN, TN, NWV * 64> er;
+    const bool coalesced_out = p.splitk <= 1 && !p.c_f32;   // block-uniform
+    if (coalesced_out) epi_prefetch<BM, BN, TN, NWV * 64>(p, zb, m0, n0, wn * TN * 32, lane, tid, er);
+
     f32x16_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -197,8 +201,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GCParams p) {
     }
 
     // ---- epilogue (same contract as gemm_conv.hip) ----
-    if (p.splitk <= 1 && !p.c_f32) {   // block-uniform: bf16 output goes through the LDS transpose (ring is dead now)
-        epilogue_coalesced<BM, BN, TM, TN, NWV * 64>(p, zb, m0, n0, wm * TM * 32, wn * TN * 32, lane, tid, acc, smem);
+    if (coalesced_out) {   // block-uniform: bf16 output goes through the LDS transpose (ring is dead now)
+        epilogue_coalesced<BM, BN, TM, TN, NWV * 64>(p, zb, m0, n0, wm * TM * 32, wn * TN * 32, lane, tid, acc, smem, er);
         return;
     }
     const int half = lane >> 5;

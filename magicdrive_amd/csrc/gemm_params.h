@@ -93,40 +93,71 @@ __device__ __forceinline__ void epilogue_store(const GCParams& p, long zb, int m
 // ALL residual loads of a thread are issued before the first is consumed (they are independent; issuing them
 // one per loop iteration serialised 16 memory round trips = 33k cycles per tile, measured).  R may alias C
 // (in-place accumulate): a thread reads exactly the addresses it later writes, so load-all-then-store is safe.
-template <int BM, int BNO, int NTHR>
-__device__ __forceinline__ void store_tile_rows(const GCParams& p, long zb, int m0, int n0o, int Nout, int tid, const bf16_t* Cs) {
+// Registers of the epilogue that do not depend on the accumulators: they are loaded BEFORE the main loop so
+// their memory latency (2-4k cycles each, three dependent round trips per tile when issued in the epilogue)
+// hides under the MFMA work.  bias: per column.  rv: the residual tile in the row-major order phase 2 walks
+// (R may alias C for in-place accumulation: a thread reads exactly the addresses it later writes, nobody else
+// writes them, so reading early is safe).
+template <int BM, int BN, int TN, int NTHR>
+struct EpiRegs {
+    static constexpr int IT = (BM * (BN / 4) + NTHR - 1) / NTHR;
+    float4 bv[TN][4];
+    uint2 rv[IT];
+};
+
+template <int BM, int BN, int TN, int NTHR>
+__device__ __forceinline__ void epi_prefetch(const GCParams& p, long zb, int m0, int n0, int wcol0, int lane, int tid,
+                                             EpiRegs<BM, BN, TN, NTHR>& er) {
+    const int half = lane >> 5;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nb = n0 + wcol0 + j * 32 + 8 * g + 4 * half;
+            er.bv[j][g] = (p.bias && nb < p.N) ? *(const float4*)(p.bias + nb) : z4;
+        }
+    const bool geglu = p.epi == 1;
+    const int cpr = (geglu ? BN / 2 : BN) / 4;
+    const int n0o = geglu ? n0 / 2 : n0, Nout = geglu ? p.N / 2 : p.N;
+    const bf16_t* Rg = p.R ? (const bf16_t*)p.R + zb * p.sR : nullptr;
+#pragma unroll
+    for (int i = 0; i < EpiRegs<BM, BN, TN, NTHR>::IT; ++i) {
+        const int idx = tid + i * NTHR;
+        const int row = idx / cpr;
+        const int c4 = (idx - row * cpr) * 4;
+        const int m = m0 + row, n = n0o + c4;
+        er.rv[i] = make_uint2(0, 0);
+        if (Rg && idx < BM * cpr && m < p.M && n < Nout) er.rv[i] = *(const uint2*)(Rg + (long)m * p.ldr + n);
+    }
+}
+
+// Phase 2 of the coalesced epilogue: walk the LDS tile row-major and write 256 contiguous bytes per row.
+template <int BM, int BNO, int NTHR, int ITMAX>
+__device__ __forceinline__ void store_tile_rows(const GCParams& p, long zb, int m0, int n0o, int Nout, int tid, const bf16_t* Cs,
+                                                const uint2 (&rv)[ITMAX]) {
     constexpr int CPR = BNO / 4;                       // 8-byte chunks per tile row
     constexpr int IT = (BM * CPR + NTHR - 1) / NTHR;
     constexpr int CSTR = BNO + 4;
+    static_assert(IT <= ITMAX, "residual register tile too small");
     bf16_t* Cg = (bf16_t*)p.C + zb * p.sC;
-    const bf16_t* Rg = p.R ? (const bf16_t*)p.R + zb * p.sR : nullptr;
-    uint2 rv[IT];
-    bool ok[IT];
+    const bool has_r = p.R != nullptr;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const int idx = tid + i * NTHR;
         const int row = idx / CPR;
         const int c4 = (idx - row * CPR) * 4;
         const int m = m0 + row, n = n0o + c4;
-        ok[i] = (idx < BM * CPR) && m < p.M && n < Nout;
-        rv[i] = make_uint2(0, 0);
-        if (Rg && ok[i]) rv[i] = *(const uint2*)(Rg + (long)m * p.ldr + n);
-    }
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-        const int idx = tid + i * NTHR;
-        const int row = idx / CPR;
-        const int c4 = (idx - row * CPR) * 4;
-        if (!ok[i]) continue;
+        if (!((idx < BM * CPR) && m < p.M && n < Nout)) continue;
         uint2 v = *(const uint2*)(Cs + row * CSTR + c4);
-        if (Rg) {
+        if (has_r) {
             float a0 = bf2f((bf16_t)(v.x & 0xffff)) + bf2f((bf16_t)(rv[i].x & 0xffff));
             float a1 = bf2f((bf16_t)(v.x >> 16)) + bf2f((bf16_t)(rv[i].x >> 16));
             float a2 = bf2f((bf16_t)(v.y & 0xffff)) + bf2f((bf16_t)(rv[i].y & 0xffff));
             float a3 = bf2f((bf16_t)(v.y >> 16)) + bf2f((bf16_t)(rv[i].y >> 16));
             v.x = pack2bf(a0, a1); v.y = pack2bf(a2, a3);
         }
-        *(uint2*)(Cg + (long)(m0 + row) * p.ldc + n0o + c4) = v;
+        *(uint2*)(Cg + (long)m * p.ldc + n) = v;
     }
 }
 
@@ -141,7 +172,8 @@ __device__ __forceinline__ void store_tile_rows(const GCParams& p, long zb, int 
 // Uniform control flow: every thread of the block must call it (it contains __syncthreads()).
 template <int BM, int BN, int TM, int TN, int NTHR>
 __device__ __forceinline__ void epilogue_coalesced(const GCParams& p, long zb, int m0, int n0, int wrow0, int wcol0, int lane,
-                                                   int tid, f32x16_t (&acc)[TM][TN], unsigned char* smem) {
+                                                   int tid, f32x16_t (&acc)[TM][TN], unsigned char* smem,
+                                                   const EpiRegs<BM, BN, TN, NTHR>& er) {
     const bool geglu = p.epi == 1;
     const int BNo = geglu ? BN / 2 : BN;              // output columns of this tile
     const int CSTR = BNo + 4;                          // LDS row stride (elements)
@@ -150,16 +182,8 @@ __device__ __forceinline__ void epilogue_coalesced(const GCParams& p, long zb, i
     // Per-column addends first, ALL loads issued before any use (one memory round trip, not one per element —
     // element-wise `bias[n]` loads behind per-group branches cost ~30k cycles per tile, measured):
     // bias is a function of the column only; temb of (batch row, column).
-    float4 bv[TN][4];
     float4 tv[TM][TN][4];
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int nb = n0 + wcol0 + j * 32 + 8 * g + 4 * half;
-            bv[j][g] = (p.bias && nb < p.N) ? *(const float4*)(p.bias + nb) : z4;
-        }
     const bool has_t = p.temb != nullptr && !geglu;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -187,9 +211,9 @@ __device__ __forceinline__ void epilogue_coalesced(const GCParams& p, long zb, i
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int nl = wcol0 + j * 32 + 8 * g + 4 * half;      // raw column inside the tile
-                const float bb[4] = {bv[j][g].x, bv[j][g].y, bv[j][g].z, bv[j][g].w};
+                const float bb[4] = {er.bv[j][g].x, er.bv[j][g].y, er.bv[j][g].z, er.bv[j][g].w};
                 const float tt[4] = {tv[i][j][g].x, tv[i][j][g].y, tv[i][j][g].z, tv[i][j][g].w};
-                const float4 bg4 = bv[(TN > 1) ? (j | 1) : j][g];
+                const float4 bg4 = er.bv[(TN > 1) ? (j | 1) : j][g];
                 const float bgt[4] = {bg4.x, bg4.y, bg4.z, bg4.w};
                 float o[4];
 #pragma unroll
@@ -213,8 +237,8 @@ __device__ __forceinline__ void epilogue_coalesced(const GCParams& p, long zb, i
     __syncthreads();
     const int n0o = geglu ? n0 / 2 : n0;
     const int Nout = geglu ? p.N / 2 : p.N;
-    if (geglu) store_tile_rows<BM, BN / 2, NTHR>(p, zb, m0, n0o, Nout, tid, Cs);
-    else store_tile_rows<BM, BN, NTHR>(p, zb, m0, n0o, Nout, tid, Cs);
+    if (geglu) store_tile_rows<BM, BN / 2, NTHR>(p, zb, m0, n0o, Nout, tid, Cs, er.rv);
+    else store_tile_rows<BM, BN, NTHR>(p, zb, m0, n0o, Nout, tid, Cs, er.rv);
 }
 
 }  // namespace mdx
