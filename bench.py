@@ -29,14 +29,14 @@ if ROOT not in sys.path:
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 
 
-def build_pipeline(cfg, device):
+def build_pipeline(cfg, device, scheduler="ddim"):
     from magicdrive_amd import schedulers
     from magicdrive_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiview
     from magicdrive_amd.networks.unet_addon_rawbox import BEVControlNetModel
     from magicdrive_amd.pipeline.pipeline_bev_controlnet import StableDiffusionBEVControlNetPipeline
     unet = UNet2DConditionModelMultiview.from_config(cfg, seed=0)
     cn = BEVControlNetModel.from_config(cfg, seed=1)
-    pipe = StableDiffusionBEVControlNetPipeline(unet=unet, controlnet=cn, scheduler=schedulers.DDIMScheduler())
+    pipe = StableDiffusionBEVControlNetPipeline(unet=unet, controlnet=cn, scheduler=schedulers.DDIMScheduler() if scheduler == "ddim" else schedulers.UniPCMultistepScheduler())
     return pipe.to(device), unet, cn
 
 
@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--scenes-per-gpu", type=int, default=32,
                     help="scenes sampled per rank per pipe() call (throughput grows with the batch: 3.2 / 3.8 / 4.2 scenes/s at 8 / 16 / 32)")
     ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--scheduler", choices=["ddim", "unipc"], default="ddim",
+                    help="ddim = the headline metric's sampler; unipc (with --ddim-steps 20) = what the reference's tools/test.py runs")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-profile", action="store_true")
@@ -122,7 +124,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     cfg = spec.SD15_CONFIG
-    pipe, unet, cn = build_pipeline(cfg, dev)
+    pipe, unet, cn = build_pipeline(cfg, dev, args.scheduler)
     pipe.use_graph = not args.no_graph
     b = args.scenes_per_gpu
     n_total = b * world
@@ -158,12 +160,12 @@ def main():
     f_pro = FL.program_flops(plan.prologue_ops)
     f_scene = (args.ddim_steps * f_step["total"] + f_pro["total"]) / b          # per scene, incl. CFG duplication if any
     out = {
-        "metric": "6-view scenes/sec at 224x400, 50-step DDIM", "value": scenes_per_s, "unit": "scenes/s",
+        "metric": "6-view scenes/sec at 224x400, 50-step DDIM" if (args.scheduler, args.ddim_steps) == ("ddim", 50) else f"6-view scenes/sec at 224x400, {args.ddim_steps}-step {args.scheduler}", "value": scenes_per_s, "unit": "scenes/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": ("configs[2]: 6-view 224x400, camera+32 boxes+BEV map, CFG 2.0" if args.full_cond else
                                 "configs[1]: 6-view 224x400, text-only conditioning (camera_param=None -> CFG off), 50-step DDIM, bf16"),
-                   "scenes_per_gpu": b, "ddim_steps": args.ddim_steps, "unet_params_M": round(unet.num_parameters() / 1e6, 1),
+                   "scenes_per_gpu": b, "ddim_steps": args.ddim_steps, "scheduler": args.scheduler, "unet_params_M": round(unet.num_parameters() / 1e6, 1),
                    "controlnet_params_M": round(cn.num_parameters() / 1e6, 1), "parallelism": f"scene-sharded x{world}",
                    "hipgraph": pipe.use_graph, "output_type": "latent",
                    "tflop_per_scene": round(f_scene / 1e12, 3),

@@ -238,6 +238,28 @@ typedef struct MdxDdimDesc {
 } MdxDdimDesc;
 int mdx_cfg_ddim_step(const MdxDdimDesc* d, void* stream);
 
+/*
+ * mdx_cfg_unipc_step — fused classifier-free-guidance combine + one UniPC (order <= 2, B(h), predict-x0)
+ * predictor-corrector update, fp32 (scheduling_unipc_multistep.py:256-300, 302-405, 407-516, 518-600 — the
+ * sampler tools/test.py really uses, misc/test_utils.py:129).  Every quantity of the update is a linear
+ * combination with per-step scalar coefficients, computed on the host from the timestep list:
+ *   e   = eps_u + g (eps_c - eps_u)
+ *   m_t = a x + b e                                   (x0 prediction)
+ *   x_c = corr ? cl x_last + c1 m1 + c2 m2 + ct m_t : x   (UniC with the previous step's order)
+ *   x  <- px x_c + pt m_t + p1 m1                      (UniP with this step's order)
+ *   x_last <- x_c ; m2 <- m1 ; m1 <- m_t
+ * coef: fp32 [n_steps][12] = {a, b, corr, cl, c1, c2, ct, px, pt, p1, 0, 0}; row = *step_ptr, incremented after.
+ * x_last, m1, m2: fp32 state buffers of n elements (zeroed by the caller before the first step).
+ * x_in / xin_c / xin_ld as in MdxDdimDesc.
+ */
+typedef struct MdxUniPCDesc {
+    float* x; const float* eps; const float* coef; int32_t* step_ptr; void* x_in; float* x_last; float* m1; float* m2;
+    int64_t n, cfg;
+    double guidance;
+    int64_t xin_c, xin_ld;
+} MdxUniPCDesc;
+int mdx_cfg_unipc_step(const MdxUniPCDesc* d, void* stream);
+
 /* ---- program = array of ops, executed in order on one stream ------------ */
 #define MDX_OP_GEMM 1
 #define MDX_OP_CONV 2
@@ -250,6 +272,7 @@ int mdx_cfg_ddim_step(const MdxDdimDesc* d, void* stream);
 #define MDX_OP_GATHER 9
 #define MDX_OP_TIMEEMB 10
 #define MDX_OP_DDIM 11
+#define MDX_OP_UNIPC 12
 
 #define MDX_OP_BYTES 512
 typedef struct MdxOp {

@@ -17,7 +17,7 @@ ABI_VERSION = 1
 
 # opcodes (mdx.h)
 OP_GEMM, OP_CONV, OP_CONV_DIRECT, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM = 1, 2, 3, 4, 5, 6
-OP_EW, OP_FOURIER, OP_GATHER, OP_TIMEEMB, OP_DDIM = 7, 8, 9, 10, 11
+OP_EW, OP_FOURIER, OP_GATHER, OP_TIMEEMB, OP_DDIM, OP_UNIPC = 7, 8, 9, 10, 11, 12
 OP_BYTES = 512
 
 EPI_NONE, EPI_GEGLU, EPI_SILU = 0, 1, 2
@@ -49,16 +49,18 @@ MdxFourierDesc = _struct("MdxFourierDesc", _f(P, "X Y mask null_feat") + _f(I, "
 MdxGatherDesc = _struct("MdxGatherDesc", _f(P, "T Y idx mask null_row reserved_p") + _f(I, "n C ldt ldy n_rows reserved0"))
 MdxTimeEmbDesc = _struct("MdxTimeEmbDesc", _f(P, "t Y") + _f(I, "n dim flip_sin_to_cos ldy") + _f(D, "freq_shift max_period"))
 MdxDdimDesc = _struct("MdxDdimDesc", _f(P, "x eps coef step_ptr x_in reserved_p") + _f(I, "n cfg") + _f(D, "guidance") + _f(I, "xin_c xin_ld"))
+MdxUniPCDesc = _struct("MdxUniPCDesc", _f(P, "x eps coef step_ptr x_in x_last m1 m2") + _f(I, "n cfg") + _f(D, "guidance") + _f(I, "xin_c xin_ld"))
 
 DESC_OF_OP = {
     OP_GEMM: MdxGemmDesc, OP_CONV: MdxConvDesc, OP_CONV_DIRECT: MdxConvDirectDesc, OP_ATTN: MdxAttnDesc,
     OP_GROUPNORM: MdxGroupNormDesc, OP_LAYERNORM: MdxLayerNormDesc, OP_EW: MdxEwDesc, OP_FOURIER: MdxFourierDesc,
-    OP_GATHER: MdxGatherDesc, OP_TIMEEMB: MdxTimeEmbDesc, OP_DDIM: MdxDdimDesc,
+    OP_GATHER: MdxGatherDesc, OP_TIMEEMB: MdxTimeEmbDesc, OP_DDIM: MdxDdimDesc, OP_UNIPC: MdxUniPCDesc,
 }
 ENTRY_OF_OP = {
     OP_GEMM: "mdx_gemm_bf16", OP_CONV: "mdx_conv2d_bf16", OP_CONV_DIRECT: "mdx_conv2d_direct", OP_ATTN: "mdx_attention_bf16",
     OP_GROUPNORM: "mdx_groupnorm_bf16", OP_LAYERNORM: "mdx_layernorm_bf16", OP_EW: "mdx_elementwise",
     OP_FOURIER: "mdx_fourier_embed", OP_GATHER: "mdx_gather_rows", OP_TIMEEMB: "mdx_timestep_embedding", OP_DDIM: "mdx_cfg_ddim_step",
+    OP_UNIPC: "mdx_cfg_unipc_step",
 }
 # every symbol include/mdx.h declares
 EXPORTS = sorted(set(ENTRY_OF_OP.values()) | {

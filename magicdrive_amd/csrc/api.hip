@@ -31,6 +31,7 @@ static int run_op(const MdxOp* op, hipStream_t st) {
         case MDX_OP_GATHER: return mdx_gather_rows((const MdxGatherDesc*)d, st);
         case MDX_OP_TIMEEMB: return mdx_timestep_embedding((const MdxTimeEmbDesc*)d, st);
         case MDX_OP_DDIM: return mdx_cfg_ddim_step((const MdxDdimDesc*)d, st);
+        case MDX_OP_UNIPC: return mdx_cfg_unipc_step((const MdxUniPCDesc*)d, st);
         default: return set_error(MDX_EINVAL, "unknown opcode %ld", (long)op->opcode);
     }
 }

@@ -316,6 +316,43 @@ __global__ __launch_bounds__(256) void ddim_kernel(DdimParams p) {
         }
     }
 }
+struct UniPCParams { float* x; const float* eps; const float* coef; int* step; void* x_in; float* x_last; float* m1; float* m2; long n; int cfg; float g; int xin_c, xin_ld; };
+
+__global__ __launch_bounds__(256) void unipc_kernel(UniPCParams p) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int step = *p.step;
+    if (i >= p.n) return;
+    const float* c = p.coef + 12 * step;
+    float e;
+    if (p.cfg) {
+        float eu = p.eps[i], ec = p.eps[p.n + i];
+        e = eu + p.g * (ec - eu);
+    } else {
+        e = p.eps[i];
+    }
+    const float x = p.x[i];
+    const float m1 = p.m1[i], m2 = p.m2[i];
+    const float mt = c[0] * x + c[1] * e;
+    float xc = x;
+    if (c[2] != 0.f) xc = c[3] * p.x_last[i] + c[4] * m1 + c[5] * m2 + c[6] * mt;
+    const float xn = c[7] * xc + c[8] * mt + c[9] * m1;
+    p.x[i] = xn; p.x_last[i] = xc; p.m2[i] = m1; p.m1[i] = mt;
+    if (p.x_in) {
+        if (p.xin_ld > 0) {
+            long px = i / p.xin_c;
+            int ch = (int)(i - px * p.xin_c);
+            bf16_t* xi = (bf16_t*)p.x_in;
+            bf16_t v = f2bf(xn);
+            xi[px * p.xin_ld + ch] = v;
+            if (p.cfg) xi[(p.n / p.xin_c + px) * p.xin_ld + ch] = v;
+        } else {
+            float* xi = (float*)p.x_in;
+            xi[i] = xn;
+            if (p.cfg) xi[p.n + i] = xn;
+        }
+    }
+}
+
 // Separate 1-thread launch so every block of ddim_kernel has read *step before it changes.
 __global__ void step_inc_kernel(int* step) { *step += 1; }
 
@@ -416,6 +453,20 @@ extern "C" int mdx_cfg_ddim_step(const MdxDdimDesc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(ddim_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
     int rc = check_launch("ddim_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, p.step);
+    return check_launch("step_inc_kernel");
+}
+
+extern "C" int mdx_cfg_unipc_step(const MdxUniPCDesc* d, void* stream) {
+    if (!d || !d->x || !d->eps || !d->coef || !d->step_ptr || !d->x_last || !d->m1 || !d->m2)
+        return set_error(MDX_EINVAL, "mdx_cfg_unipc_step: null operand");
+    UniPCParams p{d->x, d->eps, d->coef, d->step_ptr, d->x_in, d->x_last, d->m1, d->m2, d->n, (int)d->cfg, (float)d->guidance, (int)d->xin_c, (int)d->xin_ld};
+    if (p.xin_ld > 0 && (p.xin_c <= 0 || p.xin_ld < p.xin_c || p.n % p.xin_c)) return set_error(MDX_EINVAL, "unipc: bad x_in channel layout");
+    if (p.n <= 0) return MDX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(unipc_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
+    int rc = check_launch("unipc_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, p.step);
     return check_launch("step_inc_kernel");

@@ -165,8 +165,11 @@ class SamplerPlan:
     """Everything the DDIM loop needs for `b` scenes (x `n_cam` views, x2 with CFG) on one GPU."""
 
     def __init__(self, cfg, unet: PackedNet, cn: PackedNet, device, b: int, do_cfg: bool, L_box: int, latent_hw=(28, 50),
-                 num_steps: int = 50, guidance_scale: float = 2.0, conditioning_scale: float = 1.0, n_text: int = 77):
+                 num_steps: int = 50, guidance_scale: float = 2.0, conditioning_scale: float = 1.0, n_text: int = 77,
+                 scheduler_kind: str = "ddim"):
         self.cfg, self.device = cfg, device
+        assert scheduler_kind in ("ddim", "unipc")
+        self.scheduler_kind = scheduler_kind
         n_cam = len(cfg["neighboring_view_pair"])
         self.b, self.n_cam, self.c = b, n_cam, (2 if do_cfg else 1)
         self.do_cfg = do_cfg
@@ -182,7 +185,9 @@ class SamplerPlan:
         self.x = torch.zeros(b * n_cam, h, w, Cl, dtype=F32, device=device)            # latents, NHWC
         self.x_in = torch.zeros(B, h, w, CIN_PAD, dtype=BF16, device=device)            # model input ([uncond|cond] copies), channels padded
         self.eps = torch.zeros(B, h, w, cfg["out_channels"], dtype=F32, device=device)
-        self.coef = torch.zeros(num_steps, 4, dtype=F32, device=device)
+        self.coef = torch.zeros(num_steps, 4 if scheduler_kind == "ddim" else 12, dtype=F32, device=device)
+        if scheduler_kind == "unipc":       # multistep history of the fused UniPC update (scheduling_unipc_multistep.py:518-600)
+            self.x_last = torch.zeros_like(self.x); self.m1 = torch.zeros_like(self.x); self.m2 = torch.zeros_like(self.x)
         self.step_ctr = torch.zeros(1, dtype=torch.int32, device=device)
         # ---------------- prologue ----------------
         self.cond = ConditioningBuffers(bld, cn, cfg, self.c * b, n_cam, L_box, latent_hw, n_text)
@@ -216,8 +221,12 @@ class SamplerPlan:
         y = bld.decoder(unet, u_mid, u_skips, self.temb_un, self.kv_un, "unet")
         bld.emit(O.Conv(y.bhwc, unet.conv("conv_out.weight"), self.eps, bias=unet.vec("conv_out.bias"), direct=True, name="unet.conv_out"))
         bld.free(y)
-        bld.emit(O.DdimStep(self.x.view(-1), self.eps.view(-1), self.coef, self.step_ctr, x_in=self.x_in.view(-1, CIN_PAD), cfg=do_cfg,
-                            guidance=guidance_scale, xin_c=Cl, name="cfg+ddim"))
+        if scheduler_kind == "ddim":
+            bld.emit(O.DdimStep(self.x.view(-1), self.eps.view(-1), self.coef, self.step_ctr, x_in=self.x_in.view(-1, CIN_PAD), cfg=do_cfg,
+                                guidance=guidance_scale, xin_c=Cl, name="cfg+ddim"))
+        else:
+            bld.emit(O.UniPCStep(self.x.view(-1), self.eps.view(-1), self.coef, self.step_ctr, self.x_last.view(-1), self.m1.view(-1),
+                                 self.m2.view(-1), x_in=self.x_in.view(-1, CIN_PAD), cfg=do_cfg, guidance=guidance_scale, xin_c=Cl, name="cfg+unipc"))
         self.step_ops = bld.ops
         bld.ops = []
         self.prologue: Optional[L.Program] = None
@@ -241,6 +250,8 @@ class SamplerPlan:
         self.temb_cn.t.copy_(t); self.temb_un.t.copy_(t)
         self.coef.copy_(coef.to(self.device, F32))
         self.step_ctr.zero_()
+        if self.scheduler_kind == "unipc":
+            self.x_last.zero_(); self.m1.zero_(); self.m2.zero_()
 
     def run(self, use_graph: bool = True) -> torch.Tensor:
         """prologue + num_steps denoising steps on the current stream; returns latents (b, n_cam, C, h, w) fp32."""

@@ -422,6 +422,40 @@ class DdimStep:
         return self.opcode, d
 
 
+@dataclass
+class UniPCStep:
+    """Fused CFG + UniPC (order <= 2) predictor-corrector step; state buffers x_last / m1 / m2 are fp32 [n]."""
+    x: torch.Tensor
+    eps: torch.Tensor
+    coef: torch.Tensor                   # fp32 [steps, 12]
+    step: torch.Tensor
+    x_last: torch.Tensor
+    m1: torch.Tensor
+    m2: torch.Tensor
+    x_in: Optional[torch.Tensor] = None
+    cfg: bool = False
+    guidance: float = 1.0
+    xin_c: int = 0
+    name: str = ""
+    opcode = L.OP_UNIPC
+
+    def lower(self):
+        n = self.x.numel()
+        _chk(self.eps.numel() == n * (2 if self.cfg else 1) and all(t.numel() == n and t.dtype == F32 and t.is_contiguous() for t in (self.x, self.x_last, self.m1, self.m2)), "unipc: sizes")
+        _chk(self.coef.dtype == F32 and self.coef.shape[1] == 12 and self.step.dtype == torch.int32, "unipc: coef/step")
+        d = L.MdxUniPCDesc()
+        d.x, d.eps, d.coef, d.step_ptr, d.x_in = _p(self.x), _p(self.eps), _p(self.coef), _p(self.step), _p(self.x_in)
+        d.x_last, d.m1, d.m2 = _p(self.x_last), _p(self.m1), _p(self.m2)
+        if self.x_in is not None:
+            if self.x_in.dtype == F32:
+                _chk(self.x_in.numel() == self.eps.numel(), "unipc: x_in")
+            else:
+                _chk(self.x_in.dtype == BF16 and self.x_in.dim() == 2 and self.xin_c > 0 and self.x_in.shape[0] * self.xin_c == self.eps.numel(), "unipc: bf16 x_in")
+                d.xin_c, d.xin_ld = self.xin_c, self.x_in.shape[1]
+        d.n, d.cfg, d.guidance = n, int(self.cfg), float(self.guidance)
+        return self.opcode, d
+
+
 def build_program(ops) -> L.Program:
     return L.Program([op.lower() for op in ops])
 

@@ -8,7 +8,7 @@ timestep-independent runs once in a prologue program.
 
 Scope notes: CLIP text encoding and the VAE decode are outside the built hot path; they are
 used as ordinary torch modules when the caller supplies them (`prompt_embeds=` / `output_type="latent"`
-bypass them).  The fused scheduler is DDIM eta=0 (the north-star config); other schedulers raise.
+bypass them).  Fused schedulers: DDIM eta=0 (the north-star config) and UniPC (what tools/test.py installs); others raise.
 """
 from __future__ import annotations
 
@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from ..denoiser import SamplerPlan
-from ..schedulers import DDIMScheduler
+from ..schedulers import DDIMScheduler, UniPCMultistepScheduler
 
 
 @dataclass
@@ -181,9 +181,13 @@ class StableDiffusionBEVControlNetPipeline:
         if guess_mode:
             raise NotImplementedError("guess_mode is outside the built hot path")
         if eta != 0.0:
-            raise NotImplementedError("the fused sampler is deterministic DDIM (eta = 0)")
-        if not isinstance(self.scheduler, DDIMScheduler):
-            raise NotImplementedError(f"{type(self.scheduler).__name__}: only magicdrive_amd.schedulers.DDIMScheduler has a fused step (UniPC is the next row, SURVEY.md §8f.2)")
+            raise NotImplementedError("the fused samplers are deterministic (DDIM eta = 0, UniPC)")
+        if isinstance(self.scheduler, DDIMScheduler):
+            sched_kind = "ddim"
+        elif isinstance(self.scheduler, UniPCMultistepScheduler):
+            sched_kind = "unipc"
+        else:
+            raise NotImplementedError(f"{type(self.scheduler).__name__}: fused steps exist for magicdrive_amd.schedulers.DDIMScheduler and UniPCMultistepScheduler")
         if self._device.type != "cuda":
             raise RuntimeError("pipeline.to('cuda') first: the sampler has no CPU path")
         device = self._device
@@ -227,12 +231,13 @@ class StableDiffusionBEVControlNetPipeline:
             raise NotImplementedError("bbox_max_length padding without CFG")
         L_box = 0 if boxes is None else int(boxes["bboxes"].shape[2])
         h, w = latents.shape[-2:]
-        key = (b, do_cfg, L_box, h, w, num_inference_steps, float(guidance_scale), float(controlnet_conditioning_scale), text.shape[1])
+        n_steps = len(timesteps)
+        key = (b, do_cfg, L_box, h, w, n_steps, float(guidance_scale), float(controlnet_conditioning_scale), text.shape[1], sched_kind)
         plan = self._plans.get(key)
         if plan is None:
             plan = SamplerPlan(self.unet.cfg, self.unet.packed(), self.controlnet.packed(), device, b, do_cfg, L_box, (h, w),
-                               num_steps=num_inference_steps, guidance_scale=guidance_scale,
-                               conditioning_scale=float(controlnet_conditioning_scale), n_text=text.shape[1])
+                               num_steps=n_steps, guidance_scale=guidance_scale,
+                               conditioning_scale=float(controlnet_conditioning_scale), n_text=text.shape[1], scheduler_kind=sched_kind)
             plan.compile()
             self._plans[key] = plan
         plan.load_inputs(latents, camera_param, text, image, boxes, timesteps, self.scheduler.coefficient_table())

@@ -172,9 +172,32 @@ def run_ddim(op: O.DdimStep):
     op.step += 1
 
 
+def run_unipc(op: O.UniPCStep):
+    n = op.x.numel()
+    c = op.coef[int(op.step.item())]
+    e = op.eps[:n] + op.guidance * (op.eps[n:] - op.eps[:n]) if op.cfg else op.eps
+    x = op.x.clone(); m1 = op.m1.clone(); m2 = op.m2.clone()
+    mt = c[0] * x + c[1] * e
+    xc = c[3] * op.x_last + c[4] * m1 + c[5] * m2 + c[6] * mt if c[2] != 0 else x
+    xn = c[7] * xc + c[8] * mt + c[9] * m1
+    op.x.copy_(xn); op.x_last.copy_(xc); op.m2.copy_(m1); op.m1.copy_(mt)
+    if op.x_in is not None:
+        if op.x_in.dtype == torch.float32:
+            op.x_in[:n].copy_(xn)
+            if op.cfg:
+                op.x_in[n:].copy_(xn)
+        else:
+            npx = n // op.xin_c
+            v = xn.view(npx, op.xin_c).to(op.x_in.dtype)
+            op.x_in[:npx, :op.xin_c].copy_(v)
+            if op.cfg:
+                op.x_in[npx:, :op.xin_c].copy_(v)
+    op.step += 1
+
+
 DISPATCH = {O.Gemm: run_gemm, O.Conv: run_conv, O.Attn: run_attn, O.GroupNorm: run_groupnorm, O.LayerNorm: run_layernorm,
             O.Ew: run_ew, O.Upsample: run_upsample, O.Layout: run_layout, O.Fourier: run_fourier, O.Gather: run_gather,
-            O.TimeEmb: run_timeemb, O.DdimStep: run_ddim}
+            O.TimeEmb: run_timeemb, O.DdimStep: run_ddim, O.UniPCStep: run_unipc}
 
 
 def run(ops, lower_check: bool = True):

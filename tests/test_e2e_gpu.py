@@ -138,6 +138,30 @@ def test_pipeline_call_matches_reference_goldens(dev):
     assert e1 < 5e-2 and e2 < 5e-2
 
 
+def test_pipeline_call_unipc_matches_reference_golden(dev):
+    """Same drop-in call with the scheduler tools/test.py installs (UniPCMultistepScheduler.from_config(pipe.scheduler.config),
+    magicdrive/misc/test_utils.py:129) vs the reference pipeline's latents (tests/golden/tiny_pipeline_unipc.pt)."""
+    import os
+    from magicdrive_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiview
+    from magicdrive_amd.networks.unet_addon_rawbox import BEVControlNetModel
+    from magicdrive_amd.pipeline.pipeline_bev_controlnet import StableDiffusionBEVControlNetPipeline
+    from magicdrive_amd.schedulers import UniPCMultistepScheduler
+    G = torch.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_pipeline_unipc.pt"))
+    cfg = spec.TINY_CONFIG
+    pipe = StableDiffusionBEVControlNetPipeline(unet=UNet2DConditionModelMultiview.from_config(cfg, 0), controlnet=BEVControlNetModel.from_config(cfg, 1)).to(dev)
+    pipe.scheduler = UniPCMultistepScheduler.from_config(pipe.scheduler.config)
+    sc = scene(cfg, 2, 5)
+    kw = dict(prompt=None, image=sc["bev_map"], camera_param=sc["camera_param"], height=224, width=400, num_inference_steps=G["steps"],
+              guidance_scale=G["guidance"], latents=sc["latents"], prompt_embeds=sc["prompt_embeds"], negative_prompt_embeds=sc["negative_prompt_embeds"],
+              output_type="latent", bev_controlnet_kwargs={"bboxes_3d_data": sc["bboxes_3d_data"]})
+    out = pipe(**kw).images.clone()
+    out_again = pipe(**kw).images                       # reused plan: history must be reset, result bit-identical
+    torch.cuda.synchronize()
+    e1 = rel_l2(out, G["latents_cfg"])
+    print(f"[pipeline UniPC vs reference golden] {e1:.4f}")
+    assert e1 < 5e-2 and torch.equal(out, out_again)
+
+
 def test_module_api_forward(dev):
     """BEVControlNetModel.forward / UNet2DConditionModelMultiview.forward through the reference signatures vs goldens."""
     import os

@@ -43,6 +43,29 @@ def test_ddim_table_matches_oracle_scheduler():
         assert torch.allclose(tab[i], exp, atol=1e-6)
 
 
+@pytest.mark.parametrize("n,kw", [(20, {}), (5, {}), (3, dict(solver_type="bh1")), (10, dict(solver_order=1)), (2, {}), (1, {})])
+def test_unipc_table_reproduces_oracle_scheduler(n, kw):
+    """The fused UniPC step is a per-step linear recurrence over (x, eps, x_last, m1, m2); the host table must
+    reproduce the oracle's multistep predictor-corrector for every order/warm-up case."""
+    s = schedulers.UniPCMultistepScheduler(**kw); o = D.UniPC(**kw)
+    ts = s.set_timesteps(n); assert torch.equal(ts, o.set_timesteps(n))
+    tab = s.coefficient_table().double()
+    assert tab.shape == (len(ts), 12)
+    g = torch.Generator().manual_seed(1)
+    x = xo = torch.randn(64, generator=g, dtype=torch.float64)
+    xl = m1 = m2 = torch.zeros_like(x)
+    for i, t in enumerate(ts.tolist()):
+        e = torch.sin(x * 1.3 + i); eo = torch.sin(xo * 1.3 + i)
+        a, b, corr, cl, c1, c2, ct, px, pt, p1 = tab[i, :10]
+        mt = a * x + b * e
+        xc = cl * xl + c1 * m1 + c2 * m2 + ct * mt if corr > 0.5 else x
+        x, xl, m2, m1 = px * xc + pt * mt + p1 * m1, xc, m1, mt
+        xo = o.step(eo.float(), t, xo.float()).double()
+        assert torch.allclose(x, xo, atol=2e-5, rtol=2e-5), (i, t)
+    with pytest.raises(NotImplementedError):
+        s.step(x, ts[0], x)
+
+
 def test_checkpoint_layout_roundtrip(tmp_path):
     cfg = spec.TINY_CONFIG
     u = UNet2DConditionModelMultiview.from_config(cfg, seed=0)

@@ -379,6 +379,35 @@ def test_cfg_ddim_and_graph_replay(dev):
     assert torch.allclose(x.cpu(), ref_step(r1, coef[1].cpu()), atol=1e-5) and step.item() == 2
 
 
+def test_cfg_unipc_matches_oracle_scheduler(dev):
+    """mdx_cfg_unipc_step driven for a whole 8-step trajectory (warm-up, order 2, lower-order final) against
+    oracle.denoiser.UniPC with the same per-step eps; also checks the bf16 padded model-input copy."""
+    from magicdrive_amd import schedulers
+    from oracle import denoiser as D
+    npx, Cc = 6 * 28 * 50, 4
+    n = npx * Cc
+    sch = schedulers.UniPCMultistepScheduler(); ts = sch.set_timesteps(8)
+    o = D.UniPC(); o.set_timesteps(8)
+    x = rnd(n, seed=1, dtype=torch.float32); xo = x.cpu().clone()
+    eps = torch.zeros(2 * n, dtype=torch.float32, device=dev)
+    coef = sch.coefficient_table().to(dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    xl, m1, m2 = (torch.zeros(n, dtype=torch.float32, device=dev) for _ in range(3))
+    xin = torch.full((2 * npx, 8), 7.0, dtype=BF, device=dev)
+    prog = O.build_program([O.UniPCStep(x, eps, coef, step, xl, m1, m2, x_in=xin, cfg=True, guidance=2.0, xin_c=Cc)])
+    st = torch.cuda.current_stream().cuda_stream
+    for i, t in enumerate(ts.tolist()):
+        e = torch.randn(2 * n, generator=torch.Generator().manual_seed(100 + i))
+        eps.copy_(e)
+        (prog.run if i == 0 else prog.launch)(st)          # eager once, then hipGraph replays picking row i by the device counter
+        torch.cuda.synchronize()
+        xo = o.step(e[:n] + 2.0 * (e[n:] - e[:n]), t, xo)
+        assert torch.allclose(x.cpu(), xo, atol=3e-5 * float(xo.abs().max()), rtol=1e-5), (i, (x.cpu() - xo).abs().max())
+    assert step.item() == 8
+    exp = x.cpu().view(npx, Cc).to(BF)
+    assert torch.equal(xin[:npx, :Cc].cpu(), exp) and torch.equal(xin[npx:, :Cc].cpu(), exp) and (xin[:, Cc:].float() == 7.0).all()
+
+
 def test_error_paths(dev):
     A = rnd(16, 12, seed=1); W = rnd(8, 12, seed=2); C = torch.zeros(16, 8, dtype=BF, device=dev)
     with pytest.raises(L.MdxError):

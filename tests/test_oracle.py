@@ -110,6 +110,21 @@ def test_kat_ddim():
     assert abs(sample.abs().sum().item() - 172.0067) < 1e-2 and abs(sample.abs().mean().item() - 0.223967) < 1e-3
 
 
+def test_kat_unipc():
+    # third_party/diffusers/tests/schedulers/test_scheduler_unipc.py:19-30 (config: linear betas, order 2, bh1), :205-209
+    # test_full_loop_no_noise -> mean |x| = 0.2521; dummy model = sample * t / (t + 1), test_schedulers.py:222-241
+    s = D.UniPC(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", solver_order=2, solver_type="bh1")
+    n = 4 * 3 * 8 * 8
+    sample = (torch.arange(n).reshape(3, 8, 8, 4) / n).permute(3, 0, 1, 2)
+    for t in s.set_timesteps(10):
+        sample = s.step(sample * t / (t + 1), int(t), sample)
+    assert abs(sample.abs().mean().item() - 0.2521) < 1e-3
+    # tools/test.py's sampler: 20 steps over SD-1.5's betas (configs/runner/default.yaml:54-57)
+    s = D.UniPC()
+    ts = s.set_timesteps(20)
+    assert ts[0] == 999 and ts[-1] == 50 and len(ts) == 20
+
+
 def test_sd15_sampler_timesteps():
     # 50 steps, steps_offset 1 -> 981, 961, ..., 1; final alpha_prev = alphas_cumprod[0]
     s = D.DDIM()
@@ -162,6 +177,18 @@ def test_golden_pipeline(tiny):
     assert rel_l2(out2, G["latents_textonly"]) < 2e-4, rel_l2(out2, G["latents_textonly"])
 
 
+def test_golden_pipeline_unipc(tiny):
+    """The oracle loop with the restated UniPC vs the REAL reference pipeline running diffusers' UniPCMultistepScheduler."""
+    cfg, usd, csd = tiny
+    G = torch.load(os.path.join(GOLD, "tiny_pipeline_unipc.pt"))
+    assert abs(_checksum(usd) - G["meta"]["unet_checksum"]) < 1e-3 * G["meta"]["unet_checksum"]
+    sc = scene(cfg, 2, 5)
+    with torch.no_grad():
+        out = D.sample_loop(usd, csd, cfg, sc["latents"], sc["prompt_embeds"], sc["negative_prompt_embeds"], sc["bev_map"],
+                            sc["camera_param"], sc["bboxes_3d_data"], num_steps=G["steps"], guidance_scale=G["guidance"], scheduler=D.UniPC())
+    assert rel_l2(out, G["latents_cfg"]) < 2e-4, rel_l2(out, G["latents_cfg"])
+
+
 # ---------------------------------------------------------------- live reference (authoring container only)
 needs_ref = pytest.mark.skipif(not refshim.available(), reason="/root/reference not present")
 
@@ -174,6 +201,26 @@ def test_param_shapes_match_reference_modules():
         ns, unet, cnet = ref_models.build_reference(cfg, usd, csd)       # strict load_state_dict inside
         assert {k: tuple(v.shape) for k, v in unet.state_dict().items()} == dict(spec.unet_param_shapes(cfg))
         assert {k: tuple(v.shape) for k, v in cnet.state_dict().items()} == dict(spec.controlnet_param_shapes(cfg))
+
+
+@needs_ref
+@pytest.mark.parametrize("n,order,stype", [(20, 2, "bh2"), (7, 2, "bh1"), (5, 1, "bh2"), (9, 3, "bh2")])
+def test_unipc_restatement_matches_live_reference(n, order, stype):
+    """The restated UniPC against the reference environment's own UniPCMultistepScheduler (what
+    magicdrive/misc/test_utils.py:129 installs), driven by a fixed pseudo-model."""
+    from oracle import refshim
+    r = refshim.load().UniPCMultistepScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", solver_order=order, solver_type=stype)
+    o = D.UniPC(solver_order=order, solver_type=stype)
+    r.set_timesteps(n)
+    assert torch.equal(o.set_timesteps(n), r.timesteps.cpu().long())
+    g = torch.Generator().manual_seed(3)
+    xr = xo = torch.randn(2, 4, 6, 5, generator=g)
+    for t in r.timesteps:
+        er = torch.tanh(xr * 0.7) + 0.1 * torch.cos(xr * float(t) / 300)
+        eo = torch.tanh(xo * 0.7) + 0.1 * torch.cos(xo * float(t) / 300)
+        xr = r.step(er, t, xr).prev_sample
+        xo = o.step(eo, int(t), xo)
+    assert (xr - xo).abs().max() < 5e-5 * max(1.0, float(xr.abs().max()))
 
 
 @needs_ref

@@ -73,6 +73,28 @@ def test_sampler_plan_matches_golden_pipeline(tiny, do_cfg):
     assert all(v for v in sp.bld.pool.free_list.values())
 
 
+def test_unipc_sampler_plan_matches_golden_pipeline(tiny):
+    """The UniPC step program (one fused cfg+unipc op with device-resident multistep history) vs the reference
+    pipeline's latents under diffusers' UniPCMultistepScheduler (tests/golden/tiny_pipeline_unipc.pt)."""
+    cfg, usd, csd, un, cn = tiny
+    G = torch.load(os.path.join(GOLD, "tiny_pipeline_unipc.pt"))
+    sc = scene(cfg, 2, 5)
+    steps = G["steps"]
+    sch = schedulers.UniPCMultistepScheduler(); ts = sch.set_timesteps(steps)
+    cam, text, bev, boxes = cfg_inputs(D, csd, sc)
+    sp = DN.SamplerPlan(cfg, un, cn, CPU, 2, True, 5, (28, 50), num_steps=steps, guidance_scale=G["guidance"], scheduler_kind="unipc")
+    assert sp.step_ops[-1].name == "cfg+unipc"
+    sp.load_inputs(torch.stack([sc["latents"]] * 6, 1), cam, text, bev, boxes, ts, sch.coefficient_table())
+    plan_interp.run(sp.prologue_ops)
+    for _ in range(steps):
+        plan_interp.run(sp.step_ops, lower_check=False)
+    assert sp.step_ctr.item() == steps
+    assert rel_l2(sp.latents(), G["latents_cfg"]) < 4e-2, rel_l2(sp.latents(), G["latents_cfg"])
+    # a second load_inputs must reset the multistep history (a reused plan starts a fresh trajectory)
+    sp.load_inputs(torch.stack([sc["latents"]] * 6, 1), cam, text, bev, boxes, ts, sch.coefficient_table())
+    assert sp.step_ctr.item() == 0 and not sp.m1.any() and not sp.x_last.any()
+
+
 def test_step_program_work_is_deduplicated():
     """SURVEY.md §8d: F_step(224x400, L=32, c=1) ~= 2.325 TF after removing the reference's redundant work;
     folding connector o attn4.to_out into one matrix (engine.py) removes a further 16 C x C GEMMs = 0.027 TF."""

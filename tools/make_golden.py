@@ -11,6 +11,10 @@ Fixtures
                     2 scenes x 6 views with DISTINCT noise per view, 5 boxes/view, two different timesteps.
   tiny_pipeline.pt  StableDiffusionBEVControlNetPipeline.__call__ (reference pipeline, generator-free DDIM subclass,
                     SURVEY.md §0.2), 5 steps, guidance 2.0, output_type="latent"; and the camera_param=None path.
+  tiny_pipeline_unipc.pt  the same call with the scheduler tools/test.py really installs (UniPCMultistepScheduler,
+                    magicdrive/misc/test_utils.py:129), 6 steps (warm-up, order-2 and lower-order-final steps all occur).
+
+`python tools/make_golden.py unipc` regenerates only the last fixture.
 """
 import os
 import sys
@@ -30,12 +34,26 @@ def checksum(sd):
     return float(sum(v.double().abs().sum() for v in sd.values()))
 
 
+def unipc_fixture(out_dir, cfg, usd, csd, meta, hw=(28, 50)):
+    ns, pipe = ref_models.build_reference_pipeline(cfg, usd, csd, scheduler="unipc")
+    sc = scene(cfg, 2, 5, hw)
+    with torch.no_grad():
+        out = pipe(prompt=None, image=sc["bev_map"], camera_param=sc["camera_param"], height=224, width=400, num_inference_steps=6,
+                   guidance_scale=2.0, latents=sc["latents"].clone(), prompt_embeds=sc["prompt_embeds"],
+                   negative_prompt_embeds=sc["negative_prompt_embeds"], output_type="latent",
+                   bev_controlnet_kwargs={"bboxes_3d_data": sc["bboxes_3d_data"]}).images
+    torch.save({"meta": meta, "steps": 6, "guidance": 2.0, "latents_cfg": out.clone()}, os.path.join(out_dir, "tiny_pipeline_unipc.pt"))
+    print("tiny_pipeline_unipc: |x|", out.abs().mean().item())
+
+
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     cfg = spec.TINY_CONFIG
     usd, csd = state_dicts(cfg)
     meta = {"unet_checksum": checksum(usd), "cn_checksum": checksum(csd), "torch": str(torch.__version__)}
+    if sys.argv[1:] == ["unipc"]:
+        return unipc_fixture(out_dir, cfg, usd, csd, meta)
 
     # ---- module-level forwards
     ns, unet, cnet = ref_models.build_reference(cfg, usd, csd)
@@ -68,6 +86,7 @@ def main():
     torch.save({"meta": meta, "steps": 5, "guidance": 2.0, "latents_cfg": out.clone(), "latents_textonly": out_nocam.clone()},
                os.path.join(out_dir, "tiny_pipeline.pt"))
     print("tiny_pipeline: |x|", out.abs().mean().item(), out_nocam.abs().mean().item())
+    unipc_fixture(out_dir, cfg, usd, csd, meta, hw)
     for f in os.listdir(out_dir):
         print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")
 
