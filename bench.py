@@ -164,7 +164,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": ("configs[2]: 6-view 224x400, camera+32 boxes+BEV map, CFG 2.0" if args.full_cond else
-                                "configs[1]: 6-view 224x400, text-only conditioning (camera_param=None -> CFG off), 50-step DDIM, bf16"),
+                                f"configs[1]: 6-view 224x400, text-only conditioning (camera_param=None -> CFG off), {args.ddim_steps}-step {args.scheduler.upper() if args.scheduler == 'ddim' else 'UniPC'}, bf16"),
                    "scenes_per_gpu": b, "ddim_steps": args.ddim_steps, "scheduler": args.scheduler, "unet_params_M": round(unet.num_parameters() / 1e6, 1),
                    "controlnet_params_M": round(cn.num_parameters() / 1e6, 1), "parallelism": f"scene-sharded x{world}",
                    "hipgraph": pipe.use_graph, "output_type": "latent",
