@@ -29,6 +29,9 @@ namespace mdx {
 
 int launch_gemm_dma(const GCParams& p, bool conv, int tile, hipStream_t st);
 void dma_tile_dims(int tile, int* bm, int* bn);
+int launch_gemm_pp(const GCParams& p, bool conv, int cfg, hipStream_t st);      // gemm_pp.hip: 256-row ping-pong tiles
+bool pp_supported(const GCParams& p, int cfg);
+void pp_tile_dims(int cfg, int* bm, int* bn);
 
 // WM x WN waves (NTH = 64 WM WN threads); each wave owns a (BM/WM) x (BN/WN) sub-tile of 32x32 MFMA tiles.
 template <int BM, int BN, int BK, int WM, int WN, bool CONV>
@@ -98,18 +101,27 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 1) void gemm_con
     }
     // conv tap tracking for this thread's k chunk
     int ky = 0, kx = 0, ci = 0;
+    const bool cim = CONV && p.cimajor;
     if (CONV) {
-        int kk = kbeg + kc * 8;
-        int tap = kk / p.Cin;
-        ci = kk - tap * p.Cin;
-        ky = tap / p.kw;
-        kx = tap - ky * p.kw;
+        if (cim) {          // slab T = kbeg / BK + t  ->  tap T % ntaps, channel block (T / ntaps) * BK
+            const int T0 = kbeg / BK, ntaps = p.kh * p.kw;
+            const int tap = T0 % ntaps;
+            ci = (T0 / ntaps) * BK + kc * 8;
+            ky = tap / p.kw;
+            kx = tap - ky * p.kw;
+        } else {
+            int kk = kbeg + kc * 8;
+            int tap = kk / p.Cin;
+            ci = kk - tap * p.Cin;
+            ky = tap / p.kw;
+            kx = tap - ky * p.kw;
+        }
     }
 
     uint4 a_reg[A_CH], b_reg[B_CH];
     auto load_tile = [&](int t) {
-        const int kk = kbeg + t * BK + kc * 8;
-        const bool kok = kk < kend;
+        const int kk = cim ? (ky * p.kw + kx) * p.Cin + ci : kbeg + t * BK + kc * 8;
+        const bool kok = cim ? (kbeg + t * BK < kend) : kk < kend;
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
             uint4 v = make_uint4(0, 0, 0, 0);
@@ -131,10 +143,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 1) void gemm_con
             b_reg[i] = v;
         }
         if (CONV) {  // advance the tap cursor by one K slab
-            ci += BK;
-            while (ci >= p.Cin) {
-                ci -= p.Cin;
-                if (++kx == p.kw) { kx = 0; ++ky; }
+            if (cim) {
+                if (++kx == p.kw) { kx = 0; if (++ky == p.kh) { ky = 0; ci += BK; } }
+            } else {
+                ci += BK;
+                while (ci >= p.Cin) {
+                    ci -= p.Cin;
+                    if (++kx == p.kw) { kx = 0; ++ky; }
+                }
             }
         }
     };
@@ -331,6 +347,28 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
     p.kchunk = kchunk;
     static const int timing = [] { const char* e = getenv("MDX_GEMM_TIMING"); return e ? atoi(e) : 0; }();
     p.timing = (timing && p.ws && splitk == 1) ? (unsigned long long*)p.ws : nullptr;
+    // Large shapes: the 256-row ping-pong kernel (gemm_pp.hip).  MDX_GEMM_PP: 0 off, 1 cost model (default), 2 whenever supported.
+    // Cost model: rounds of tiles over the 256 CUs x tile area / relative per-tile efficiency.  Measured (tools/kbench.py, 96 views):
+    // the 256 x 256 tile is 1.16-1.25x the 128 x 128 kernel per FLOP when N % 256 == 0 and K >= 1024 (N = 1280 convs 763 -> 888,
+    // 612 -> 764 TFLOP/s); the 256 x 320 tile (N = 320 / 640) spills and loses, so it is opt-in (MDX_PP_CFG1=1).
+    static const int pp_mode = [] { const char* e = getenv("MDX_GEMM_PP"); return e ? atoi(e) : 1; }();
+    static const double pp_gain = [] { const char* e = getenv("MDX_PP_GAIN"); return e ? atof(e) : 1.18; }();
+    static const int pp_cfg1 = [] { const char* e = getenv("MDX_PP_CFG1"); return e ? atoi(e) : 0; }();
+    if (impl == 0 && pp_mode > 0 && splitk == 1) {
+        const double cost_old = (double)((tiles + 511) / 512) * 2.0 * BM * BN;   // two co-resident workgroups share a CU
+        int best = -1;
+        double best_cost = pp_mode >= 2 ? 1e300 : cost_old;
+        for (int cfg = 0; cfg < 2; ++cfg) {
+            if (!pp_supported(p, cfg)) continue;
+            if (pp_mode < 2 && (p.K < 1024 || p.M < 4096 || (cfg == 0 && p.N % 256) || (cfg == 1 && !pp_cfg1))) continue;
+            int bm, bn;
+            pp_tile_dims(cfg, &bm, &bn);
+            const long t = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+            const double c = (double)((t + 255) / 256) * bm * bn / pp_gain;
+            if (c < best_cost) { best_cost = c; best = cfg; }
+        }
+        if (best >= 0) return launch_gemm_pp(p, conv, best, st);
+    }
     int rc;
     if (impl != 0) {
         rc = launch_gemm_dma(p, conv, tile, st);
@@ -412,5 +450,7 @@ extern "C" int mdx_conv2d_bf16(const MdxConvDesc* d, void* stream) {
     p.epi = (int)d->epilogue; p.splitk = (int)d->splitk; p.c_f32 = 0; p.ws_bytes = d->ws_bytes;
     p.Hi = (int)d->Hi; p.Wi = (int)d->Wi; p.Cin = (int)d->Cin; p.Ho = (int)d->Ho; p.Wo = (int)d->Wo;
     p.kh = (int)d->kh; p.kw = (int)d->kw; p.sh = (int)d->sh; p.sw = (int)d->sw; p.ph = (int)d->ph; p.pw = (int)d->pw;
+    static const int cim = [] { const char* e = getenv("MDX_CONV_CIMAJOR"); return e ? atoi(e) : 1; }();
+    p.cimajor = (cim && d->kh * d->kw > 1 && d->Cin % 64 == 0) ? 1 : 0;
     return launch_gemm_conv(p, true, (hipStream_t)stream);
 }

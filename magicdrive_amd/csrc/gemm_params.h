@@ -19,6 +19,13 @@ struct GCParams {
     unsigned long long* timing;   // debug: per-block s_memtime stamps (MDX_GEMM_TIMING=1), else null
     // conv geometry (CONV only); lda doubles as the pixel stride of X
     int Hi, Wi, Cin, Ho, Wo, kh, kw, sh, sw, ph, pw;
+    // conv K order: 0 = (ky, kx, ci) as the weights are stored; 1 = channel-block major: slab T covers tap T % (kh kw) of the
+    // 64-channel block T / (kh kw), so the kh*kw consecutive slabs of a block re-read the SAME input lines (shifted by a pixel / a row)
+    // while they are still in L2 — in storage order the reuse distance is Cin/64 slabs x every resident tile, which evicts them
+    // (measured: 28x50 convs ran at half the per-tile rate of 14x25 ones once the activations outgrew the Infinity Cache).
+    // Only a permutation of the reduction order; needs Cin % 64 == 0.
+    int cimajor;
+    int dbg;                      // debug knobs of gemm_pp.hip (MDX_PP_DBG): 1 skip LDS stores, 2 skip global loads, 4 skip MFMAs
 };
 
 // ---- tile order ------------------------------------------------------------------------
