@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GCParams p) {
 
 template <int BM, int BN, int BK, int WM, int WN, bool CONV>
 static int launch_one(const GCParams& p, hipStream_t st) {
-    constexpr size_t ring = (size_t)2 * (BM + BN) * (BK + 8) * sizeof(bf16_t), ctile = (size_t)BM * (BN + 4) * 2;
+    constexpr size_t ring = (size_t)2 * (BM + BN) * (BK + 8) * sizeof(bf16_t), ctile = (size_t)BM * (BN + 8) * 2;
     constexpr size_t smem = ring > ctile ? ring : ctile;
     static bool attr_done = false;
     auto kern = gemm_conv_kernel<BM, BN, BK, WM, WN, CONV>;
@@ -298,6 +298,12 @@ static int launch_one(const GCParams& p, hipStream_t st) {
 int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MDX_OK;
     const bool geglu = p.epi == 1;
+    {   // 16-byte epilogue accesses need 16-byte aligned rows of C and R and whole 8-column chunks
+        const long nout = geglu ? p.N / 2 : p.N;
+        static const int wide_on = [] { const char* e = getenv("MDX_EPI_WIDE"); return e ? atoi(e) : 1; }();
+        p.wide = wide_on && !p.c_f32 && (nout % 8) == 0 && (p.ldc % 8) == 0 && (p.sC % 8) == 0 && (((uintptr_t)p.C) & 15) == 0 &&
+                 (!p.R || ((p.ldr % 8) == 0 && (p.sR % 8) == 0 && (((uintptr_t)p.R) & 15) == 0));
+    }
     if (geglu && (p.N % 64) != 0) return set_error(MDX_EINVAL, "GEGLU needs packed N %% 64 == 0 (N=%d)", p.N);
     static const int impl = [] { const char* e = getenv("MDX_GEMM_IMPL"); return e ? atoi(e) : 0; }();
     int BM, BN, tile = -1;

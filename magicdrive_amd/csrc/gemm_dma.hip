@@ -235,7 +235,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(GCParams p) {
 
 template <int BM, int BN, int WM, int WN, int BK, int ST, bool CONV>
 static int launch_dma_one(const GCParams& p, hipStream_t st) {
-    constexpr size_t ring = (size_t)ST * (BM + BN) * BK * 2, ctile = (size_t)BM * (BN + 4) * 2;   // the C tile reuses the ring
+    constexpr size_t ring = (size_t)ST * (BM + BN) * BK * 2, ctile = (size_t)BM * (BN + 8) * 2;   // the C tile reuses the ring
     constexpr size_t smem = ring > ctile ? ring : ctile;
     static bool attr_done = false;
     auto kern = gemm_dma_kernel<BM, BN, WM, WN, BK, ST, CONV>;

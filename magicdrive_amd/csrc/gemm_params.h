@@ -25,6 +25,7 @@ struct GCParams {
     // (measured: 28x50 convs ran at half the per-tile rate of 14x25 ones once the activations outgrew the Infinity Cache).
     // Only a permutation of the reduction order; needs Cin % 64 == 0.
     int cimajor;
+    int wide;                     // epilogue may use 16-byte global accesses for C / R (alignment + N % 8 checked by the launcher)
     int dbg;                      // debug knobs of gemm_pp.hip (MDX_PP_DBG): 1 skip LDS stores, 2 skip global loads, 4 skip MFMAs
 };
 
@@ -107,9 +108,9 @@ __device__ __forceinline__ void epilogue_store(const GCParams& p, long zb, int m
 // writes them, so reading early is safe).
 template <int BM, int BN, int TN, int NTHR>
 struct EpiRegs {
-    static constexpr int IT = (BM * (BN / 4) + NTHR - 1) / NTHR;
+    static constexpr int IT = (BM * (BN / 8) + NTHR - 1) / NTHR;      // 16-byte chunks of the tile per thread
     float4 bv[TN][4];
-    uint2 rv[IT];
+    uint4 rv[IT];
 };
 
 template <int BM, int BN, int TN, int NTHR>
@@ -125,46 +126,75 @@ __device__ __forceinline__ void epi_prefetch(const GCParams& p, long zb, int m0,
             er.bv[j][g] = (p.bias && nb < p.N) ? *(const float4*)(p.bias + nb) : z4;
         }
     const bool geglu = p.epi == 1;
-    const int cpr = (geglu ? BN / 2 : BN) / 4;
+    const int cpr = (geglu ? BN / 2 : BN) / 8;
     const int n0o = geglu ? n0 / 2 : n0, Nout = geglu ? p.N / 2 : p.N;
-    const bf16_t* Rg = p.R ? (const bf16_t*)p.R + zb * p.sR : nullptr;
+    const bf16_t* Rg = (p.R && p.wide) ? (const bf16_t*)p.R + zb * p.sR : nullptr;    // narrow path loads R in the store loop
 #pragma unroll
     for (int i = 0; i < EpiRegs<BM, BN, TN, NTHR>::IT; ++i) {
         const int idx = tid + i * NTHR;
         const int row = idx / cpr;
-        const int c4 = (idx - row * cpr) * 4;
-        const int m = m0 + row, n = n0o + c4;
-        er.rv[i] = make_uint2(0, 0);
-        if (Rg && idx < BM * cpr && m < p.M && n < Nout) er.rv[i] = *(const uint2*)(Rg + (long)m * p.ldr + n);
+        const int c8 = (idx - row * cpr) * 8;
+        const int m = m0 + row, n = n0o + c8;
+        er.rv[i] = make_uint4(0, 0, 0, 0);
+        if (Rg && idx < BM * cpr && m < p.M && n < Nout) er.rv[i] = *(const uint4*)(Rg + (long)m * p.ldr + n);
     }
 }
 
-// Phase 2 of the coalesced epilogue: walk the LDS tile row-major and write 256 contiguous bytes per row.
+__device__ __forceinline__ unsigned add2bf(unsigned a, unsigned b) {
+    return pack2bf(bf2f((bf16_t)(a & 0xffff)) + bf2f((bf16_t)(b & 0xffff)), bf2f((bf16_t)(a >> 16)) + bf2f((bf16_t)(b >> 16)));
+}
+
+// Phase 2 of the coalesced epilogue: walk the LDS tile row-major.  Wide path: 16 bytes per lane (a wave instruction covers
+// 1 KiB = full 256-byte row segments; the 8-byte form was store-ISSUE bound: twice the instructions for the same bytes), the
+// residual comes from the registers prefetched before the main loop.  Narrow path (N % 8 != 0 or unaligned pitch): 8 bytes
+// per lane, residual loaded here in batches of four.
 template <int BM, int BNO, int NTHR, int ITMAX>
 __device__ __forceinline__ void store_tile_rows(const GCParams& p, long zb, int m0, int n0o, int Nout, int tid, const bf16_t* Cs,
-                                                const uint2 (&rv)[ITMAX]) {
-    constexpr int CPR = BNO / 4;                       // 8-byte chunks per tile row
-    constexpr int IT = (BM * CPR + NTHR - 1) / NTHR;
-    constexpr int CSTR = BNO + 4;
-    static_assert(IT <= ITMAX, "residual register tile too small");
+                                                const uint4 (&rv)[ITMAX]) {
+    constexpr int CSTR = BNO + 8;
     bf16_t* Cg = (bf16_t*)p.C + zb * p.sC;
     const bool has_r = p.R != nullptr;
+    if (p.wide) {
+        constexpr int CPR = BNO / 8;                       // 16-byte chunks per tile row
+        constexpr int IT = (BM * CPR + NTHR - 1) / NTHR;
+        static_assert(IT <= ITMAX, "residual register tile too small");
 #pragma unroll
-    for (int i = 0; i < IT; ++i) {
-        const int idx = tid + i * NTHR;
-        const int row = idx / CPR;
-        const int c4 = (idx - row * CPR) * 4;
-        const int m = m0 + row, n = n0o + c4;
-        if (!((idx < BM * CPR) && m < p.M && n < Nout)) continue;
-        uint2 v = *(const uint2*)(Cs + row * CSTR + c4);
-        if (has_r) {
-            float a0 = bf2f((bf16_t)(v.x & 0xffff)) + bf2f((bf16_t)(rv[i].x & 0xffff));
-            float a1 = bf2f((bf16_t)(v.x >> 16)) + bf2f((bf16_t)(rv[i].x >> 16));
-            float a2 = bf2f((bf16_t)(v.y & 0xffff)) + bf2f((bf16_t)(rv[i].y & 0xffff));
-            float a3 = bf2f((bf16_t)(v.y >> 16)) + bf2f((bf16_t)(rv[i].y >> 16));
-            v.x = pack2bf(a0, a1); v.y = pack2bf(a2, a3);
+        for (int i = 0; i < IT; ++i) {
+            const int idx = tid + i * NTHR;
+            const int row = idx / CPR;
+            const int c8 = (idx - row * CPR) * 8;
+            const int m = m0 + row, n = n0o + c8;
+            if (!((idx < BM * CPR) && m < p.M && n < Nout)) continue;
+            uint4 v = *(const uint4*)(Cs + row * CSTR + c8);
+            if (has_r) { v.x = add2bf(v.x, rv[i].x); v.y = add2bf(v.y, rv[i].y); v.z = add2bf(v.z, rv[i].z); v.w = add2bf(v.w, rv[i].w); }
+            *(uint4*)(Cg + (long)m * p.ldc + n) = v;
         }
-        *(uint2*)(Cg + (long)m * p.ldc + n) = v;
+        return;
+    }
+    constexpr int CPR = BNO / 4;                           // 8-byte chunks per tile row
+    constexpr int IT = (BM * CPR + NTHR - 1) / NTHR;
+    const bf16_t* Rg = has_r ? (const bf16_t*)p.R + zb * p.sR : nullptr;
+#pragma unroll 1
+    for (int i0 = 0; i0 < IT; i0 += 4) {
+        uint2 r2[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + (i0 + u) * NTHR;
+            const int row = idx / CPR, c4 = (idx - row * CPR) * 4;
+            ok[u] = (i0 + u) < IT && idx < BM * CPR && m0 + row < p.M && n0o + c4 < Nout;
+            r2[u] = make_uint2(0, 0);
+            if (Rg && ok[u]) r2[u] = *(const uint2*)(Rg + (long)(m0 + row) * p.ldr + n0o + c4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
+            const int idx = tid + (i0 + u) * NTHR;
+            const int row = idx / CPR, c4 = (idx - row * CPR) * 4;
+            uint2 v = *(const uint2*)(Cs + row * CSTR + c4);
+            if (has_r) { v.x = add2bf(v.x, r2[u].x); v.y = add2bf(v.y, r2[u].y); }
+            *(uint2*)(Cg + (long)(m0 + row) * p.ldc + n0o + c4) = v;
+        }
     }
 }
 
@@ -173,8 +203,8 @@ __device__ __forceinline__ void store_tile_rows(const GCParams& p, long zb, int 
 // registers writes 8-byte pieces at a row stride: every wave store touches 32 different 128-byte lines and
 // fills 1/8 of each (measured: small-K GEMMs were bound by exactly this, not by their main loop).
 // Instead the bf16 tile is transposed through LDS (the A/B ring is dead after the main loop): phase 1 applies
-// bias / temb / activation in registers and writes the tile to LDS (row stride BNo+4 elements: conflict-free
-// ds_write_b64), phase 2 walks the tile row-major, 32 lanes x 8 B = 256 contiguous bytes per output row, adds
+// bias / temb / activation in registers and writes the tile to LDS (row stride BNo+8 elements: conflict-free
+// ds_write_b64), phase 2 walks the tile row-major, 16 lanes x 16 B = 256 contiguous bytes per output row, adds
 // the residual (read with the same coalesced pattern) and stores.
 // Uniform control flow: every thread of the block must call it (it contains __syncthreads()).
 template <int BM, int BN, int TM, int TN, int NTHR>
@@ -183,7 +213,7 @@ __device__ __forceinline__ void epilogue_coalesced(const GCParams& p, long zb, i
                                                    const EpiRegs<BM, BN, TN, NTHR>& er) {
     const bool geglu = p.epi == 1;
     const int BNo = geglu ? BN / 2 : BN;              // output columns of this tile
-    const int CSTR = BNo + 4;                          // LDS row stride (elements)
+    const int CSTR = BNo + 8;                          // LDS row stride (elements): 16-byte aligned rows, conflict-free ds_write_b64
     bf16_t* Cs = (bf16_t*)smem;
     const int frow = lane & 31, half = lane >> 5;
     // Per-column addends first, ALL loads issued before any use (one memory round trip, not one per element —

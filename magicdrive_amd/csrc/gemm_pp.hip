@@ -278,9 +278,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GCParams p) {
         }
     }
     constexpr int BNO_MAX = BN;
-    bf16_t* Cs = (bf16_t*)smem;                    // 128 x (BNo + 4) bf16 staging, aliases the (dead) operand ring
+    bf16_t* Cs = (bf16_t*)smem;                    // 128 x (BNo + 8) bf16 staging, aliases the (dead) operand ring
     const int BNo = geglu ? BN / 2 : BN;
-    const int CSTR = BNo + 4;
+    const int CSTR = BNo + 8;
     const int n0o = geglu ? n0 / 2 : n0, Nout = geglu ? p.N / 2 : p.N;
     const bf16_t* Rg = p.R ? (const bf16_t*)p.R : nullptr;
     bf16_t* Cg = (bf16_t*)p.C;
@@ -334,36 +334,57 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GCParams p) {
             }
         }
         __syncthreads();
-        // row-major walk of the half: 8-byte pieces, consecutive lanes -> consecutive columns of one output row
-        const int cpr = BNo >> 2;
-        const int total = 128 * cpr;
+        // row-major walk of the half: consecutive lanes -> consecutive 16-byte (wide) / 8-byte pieces of one output row
         const int mh = m0 + h * 128;
+        if (p.wide) {
+            const int cpr = BNo >> 3;
+            const int total = 128 * cpr;
 #pragma unroll 1
-        for (int i0 = 0; i0 < total; i0 += 4 * NTH) {
-            uint2 rv[4];
-            int row[4], c4[4];
-            bool ok[4];
+            for (int i0 = 0; i0 < total; i0 += 4 * NTH) {
+                uint4 rv[4];
+                int row[4], c8[4];
+                bool ok[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = i0 + u * NTH + tid;
-                row[u] = idx / cpr;
-                c4[u] = (idx - row[u] * cpr) * 4;
-                ok[u] = idx < total && mh + row[u] < p.M && n0o + c4[u] < Nout;
-                rv[u] = make_uint2(0, 0);
-                if (Rg && ok[u]) rv[u] = *(const uint2*)(Rg + (long)(mh + row[u]) * p.ldr + n0o + c4[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (!ok[u]) continue;
-                uint2 v = *(const uint2*)(Cs + row[u] * CSTR + c4[u]);
-                if (Rg) {
-                    const float a0 = bf2f((bf16_t)(v.x & 0xffff)) + bf2f((bf16_t)(rv[u].x & 0xffff));
-                    const float a1 = bf2f((bf16_t)(v.x >> 16)) + bf2f((bf16_t)(rv[u].x >> 16));
-                    const float a2 = bf2f((bf16_t)(v.y & 0xffff)) + bf2f((bf16_t)(rv[u].y & 0xffff));
-                    const float a3 = bf2f((bf16_t)(v.y >> 16)) + bf2f((bf16_t)(rv[u].y >> 16));
-                    v.x = pack2bf(a0, a1); v.y = pack2bf(a2, a3);
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = i0 + u * NTH + tid;
+                    row[u] = idx / cpr;
+                    c8[u] = (idx - row[u] * cpr) * 8;
+                    ok[u] = idx < total && mh + row[u] < p.M && n0o + c8[u] < Nout;
+                    rv[u] = make_uint4(0, 0, 0, 0);
+                    if (Rg && ok[u]) rv[u] = *(const uint4*)(Rg + (long)(mh + row[u]) * p.ldr + n0o + c8[u]);
                 }
-                *(uint2*)(Cg + (long)(mh + row[u]) * p.ldc + n0o + c4[u]) = v;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (!ok[u]) continue;
+                    uint4 v = *(const uint4*)(Cs + row[u] * CSTR + c8[u]);
+                    if (Rg) { v.x = add2bf(v.x, rv[u].x); v.y = add2bf(v.y, rv[u].y); v.z = add2bf(v.z, rv[u].z); v.w = add2bf(v.w, rv[u].w); }
+                    *(uint4*)(Cg + (long)(mh + row[u]) * p.ldc + n0o + c8[u]) = v;
+                }
+            }
+        } else {
+            const int cpr = BNo >> 2;
+            const int total = 128 * cpr;
+#pragma unroll 1
+            for (int i0 = 0; i0 < total; i0 += 4 * NTH) {
+                uint2 rv[4];
+                int row[4], c4[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = i0 + u * NTH + tid;
+                    row[u] = idx / cpr;
+                    c4[u] = (idx - row[u] * cpr) * 4;
+                    ok[u] = idx < total && mh + row[u] < p.M && n0o + c4[u] < Nout;
+                    rv[u] = make_uint2(0, 0);
+                    if (Rg && ok[u]) rv[u] = *(const uint2*)(Rg + (long)(mh + row[u]) * p.ldr + n0o + c4[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (!ok[u]) continue;
+                    uint2 v = *(const uint2*)(Cs + row[u] * CSTR + c4[u]);
+                    if (Rg) { v.x = add2bf(v.x, rv[u].x); v.y = add2bf(v.y, rv[u].y); }
+                    *(uint2*)(Cg + (long)(mh + row[u]) * p.ldc + n0o + c4[u]) = v;
+                }
             }
         }
     }
@@ -374,7 +395,7 @@ static int launch_pp(const GCParams& p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr size_t smem = (size_t)2 * (BM + BN) * 64 * sizeof(bf16_t) + (size_t)PP_SLOTS * BN * sizeof(float);
     static_assert(smem <= 163840, "LDS budget");
-    static_assert((size_t)128 * (BN + 4) * 2 <= (size_t)2 * (BM + BN) * 64 * 2, "C staging must fit the operand ring");
+    static_assert((size_t)128 * (BN + 8) * 2 <= (size_t)2 * (BM + BN) * 64 * 2, "C staging must fit the operand ring");
     static bool attr_done = false;
     auto kern = gemm_pp_kernel<WM, WN, TM, TN, CONV, EARLY>;
     if (!attr_done) {
