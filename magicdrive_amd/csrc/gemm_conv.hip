@@ -31,6 +31,8 @@ int launch_gemm_dma(const GCParams& p, bool conv, int tile, hipStream_t st);
 void dma_tile_dims(int tile, int* bm, int* bn);
 int launch_gemm_pp(const GCParams& p, bool conv, int cfg, hipStream_t st);      // gemm_pp.hip: 256-row ping-pong tiles
 bool pp_supported(const GCParams& p, int cfg);
+int launch_gemm_ws(const GCParams& p, hipStream_t st);                          // gemm_ws.hip: weight-stationary K = 320 GEMM
+bool ws_supported(const GCParams& p);
 void pp_tile_dims(int cfg, int* bm, int* bn);
 
 // WM x WN waves (NTH = 64 WM WN threads); each wave owns a (BM/WM) x (BN/WN) sub-tile of 32x32 MFMA tiles.
@@ -306,6 +308,11 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
     }
     if (geglu && (p.N % 64) != 0) return set_error(MDX_EINVAL, "GEGLU needs packed N %% 64 == 0 (N=%d)", p.N);
     static const int impl = [] { const char* e = getenv("MDX_GEMM_IMPL"); return e ? atoi(e) : 0; }();
+    // K = 320 projections with many rows: weights in registers, activations streamed (gemm_ws.hip).  MDX_GEMM_WS: 0 off, 1 when
+    // M >= 8192 (default), 2 whenever supported.
+    static const int ws_mode = [] { const char* e = getenv("MDX_GEMM_WS"); return e ? atoi(e) : 1; }();
+    if (impl == 0 && !conv && ws_mode > 0 && p.splitk <= 1 && ws_supported(p) && (ws_mode >= 2 || p.M >= 8192))
+        return launch_gemm_ws(p, st);
     int BM, BN, tile = -1;
     if (impl == 0) {
         BN = 128;

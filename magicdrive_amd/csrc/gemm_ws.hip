@@ -1,0 +1,286 @@
+// gemm_ws.hip — weight-stationary bf16 MFMA GEMM for K = 320 (the level-0 transformer projections and GEGLU) on gfx950.
+//
+// Why: the 128x128 GEMM of gemm_conv.hip is bound by the L2 -> LDS load path (measured ~32 B/clk per CU with two resident
+// workgroups: 160 KB of operand slabs per 128x128x320 tile = 5 k cycles against 2.5 k cycles of MFMA issue) and, at K = 320,
+// spends two thirds of a tile in its prologue and epilogue.  Here
+//   * each wave keeps ITS 32 weight rows x 320 k in registers (20 MFMA B-fragments = 80 VGPRs) for the whole launch; only the
+//     activations stream through LDS (80 KB per tile: half the load-path bytes, half the LDS stores, no W fragment reads);
+//   * a workgroup is persistent: it owns one 128-column N-tile and walks M-tiles, so the slab stream never drains — the next
+//     tile's first slabs are already in flight / in LDS while this tile's epilogue runs (no per-tile prologue);
+//   * workgroups that share an M range (one per N-tile) sit on the same XCD and walk it at the same pace: the activation tile
+//     is fetched into that L2 once.
+// Tile: 128 x 128, 4 waves side by side along N (each 128 rows x 32 columns: 4 accumulator tiles, A fragments shared), K slabs of
+// 64 through a 3-stage LDS ring filled by LDS-DMA, one barrier per slab.  GEGLU: a wave's 32 weight rows are 16 value rows + their
+// 16 gate rows of the packed [32 value | 32 gate] layout (packing.py: pack_geglu), so value and gate of one output meet in one lane
+// (accumulator registers r and r + 8).
+// Epilogue through LDS (separate staging, so the ring keeps streaming): bias / GEGLU in registers, 16-byte row-major stores,
+// residual added from 16-byte loads.  Same arithmetic per output element as gemm_conv.hip (k ascending, fp32 accumulation).
+#include "common.h"
+#include "launch.h"
+#include "gemm_params.h"
+#include <cstdlib>
+
+namespace mdx {
+
+constexpr unsigned WS_OOB = 0xFFFFFF00u;       // >= num_records: the buffer load returns 0 and the DMA writes zeros
+constexpr unsigned WS_RECORDS = 0x80000000u;   // 2 GiB window over A
+
+template <int N>
+__device__ __forceinline__ void ws_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ST-stage LDS ring filled by LDS-DMA (buffer_load_dwordx4 ... lds): ST-1 slabs of the activation stream are in flight while
+// one is multiplied — a K = 320 slab is only 16 MFMAs per wave, far shorter than a memory round trip, and with register staging
+// (one slab ahead) every slab waited on its loads (measured: 25 k cycles per tile for 2.6 k cycles of MFMA work).
+// LDS rows are 128 B, unpadded (the DMA writes 1 KiB linearly: 8 rows per wave instruction); the 16-byte chunk index is
+// XOR-swizzled by (row >> 1) & 7 on the SOURCE side and again on the fragment reads: conflict-free ds_read_b128.
+template <bool GEGLU, int ST>
+__global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
+    constexpr int BM = 128, BN = 128, BK = 64, KS = 20, NSLAB = 5;
+    constexpr int BNO = GEGLU ? BN / 2 : BN;
+    constexpr int CSTR = BNO + 8;
+    constexpr int ROWS_PASS = GEGLU ? 128 : 64;                  // epilogue staging holds this many rows (keeps LDS <= 80 KB: 2 WG/CU)
+    constexpr int STAGE = BM * BK * 2;                           // 16 KiB
+    constexpr int PPW = 4;                                       // 1-KiB DMA pieces per wave per slab
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Cs = (bf16_t*)(smem + ST * STAGE);                   // [ROWS_PASS][CSTR]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, half = lane >> 5;
+    // block -> (N-tile, M-walker): blocks b, b+8, ... land on one XCD; all N-tiles of a walker share it
+    const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+    const int tn = kq % p.nt;
+    const int walker = (kq / p.nt) * 8 + xcd;
+    const int nwalk = p.swz;                                     // walkers per N-tile (multiple of 8), set by the launcher
+    const int n0 = tn * BN;
+    const int mt = p.mt;
+    const int ntiles = walker < mt ? (mt - walker + nwalk - 1) / nwalk : 0;
+    if (ntiles == 0) return;
+
+    // ---- this wave's weight rows -> registers ----
+    int wrow, ocol;                                              // W row of this lane's n position; first output column of the wave
+    if (GEGLU) {
+        const int grp = wave >> 1, hv = wave & 1;
+        wrow = n0 + grp * 64 + (frow < 16 ? 16 * hv + frow : 32 + 16 * hv + (frow - 16));
+        ocol = grp * 32 + 16 * hv;                               // within the tile's 64 output columns
+    } else {
+        wrow = n0 + 32 * wave + frow;
+        ocol = 32 * wave;
+    }
+    Frag8 wf[KS];
+    {
+        const bf16_t* wp = p.W + (long)min(wrow, p.N - 1) * p.ldw + half * 8;
+        const bool ok = wrow < p.N;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const uint4 v = *(const uint4*)(wp + ks * 16);
+            wf[ks].u = ok ? v : make_uint4(0, 0, 0, 0);
+        }
+    }
+    // bias of this lane's output positions (fixed for the whole launch)
+    float4 bA[4];                                                // GEGLU: {value g0, value g1, gate g0, gate g1}; else g = 0..3
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        int col;
+        if (GEGLU) col = n0 + (wave >> 1) * 64 + 16 * (wave & 1) + 8 * (g & 1) + 4 * half + 32 * (g >> 1);
+        else col = n0 + ocol + 8 * g + 4 * half;
+        bA[g] = (p.bias && col < p.N) ? *(const float4*)(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    // ---- activation stream: DMA cursor (runs ST-1 slabs ahead of the multiply) ----
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, WS_RECORDS, 0x00020000);
+    const int crow = lane >> 3, cphys = lane & 7;
+    unsigned r_row[PPW], r_coff[PPW];                            // row inside the tile; byte offset of the (swizzled) source chunk
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int row = (wave * PPW + j) * 8 + crow;
+        r_row[j] = row;
+        r_coff[j] = (unsigned)(((cphys ^ ((row >> 1) & 7)) * 8) * 2);
+    }
+    const unsigned ldab = (unsigned)(p.lda * 2);
+    int f_tile = walker, f_slab = 0, f_cnt = 0;
+    const int total = ntiles * NSLAB;
+    // One 1-KiB piece of the cursor's slab -> ring stage f_cnt % ST.  (All four pieces of a slab are issued right after the
+    // barrier; spreading them between the k-steps' MFMAs measured 30-50 % slower.)
+#define WS_ISSUE_PIECE(j)                                                                                                       \
+    {                                                                                                                           \
+        const unsigned m = (unsigned)(f_tile * BM) + r_row[j];                                                                  \
+        const unsigned off = (f_cnt < total && m < (unsigned)p.M) ? m * ldab + (unsigned)(f_slab * BK * 2) + r_coff[j] : WS_OOB; \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                               \
+            rsA, (__attribute__((address_space(3))) void*)(smem + (f_cnt % ST) * STAGE + (wave * PPW + (j)) * 1024), 16, off, 0, 0, 0); \
+    }
+#define WS_ADVANCE()                                                                                                            \
+    {                                                                                                                           \
+        ++f_cnt;                                                                                                                \
+        if (++f_slab == NSLAB) { f_slab = 0; f_tile += nwalk; }                                                                 \
+    }
+
+    f32x16_t acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < ST - 1; ++s) {                           // past-the-end slabs are zero fills: the wait counts stay uniform
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) WS_ISSUE_PIECE(j)
+        WS_ADVANCE()
+    }
+
+    const int x0 = half ^ ((frow >> 1) & 7);                     // swizzled chunk of k-step 0; k-step ks flips bits 1-2
+    const unsigned char* const a_rd = smem + frow * 128;
+    const bf16_t* Rg = p.R ? (const bf16_t*)p.R : nullptr;
+    bf16_t* Cg = (bf16_t*)p.C;
+    const int n0o = GEGLU ? n0 / 2 : n0, Nout = GEGLU ? p.N / 2 : p.N;
+    int q = 0;                                                   // slab counter (ring stage = q % ST)
+    for (int t = 0; t < ntiles; ++t) {
+        const int m0 = (walker + t * nwalk) * BM;
+#pragma unroll
+        for (int s = 0; s < NSLAB; ++s, ++q) {
+            // slab q has landed once at most the ST-2 younger slabs are outstanding (an epilogue's younger loads / stores only
+            // make this wait conservative); the barrier also frees stage (q-1) % ST for the refill below
+            ws_wait_vmcnt<(ST - 2) * PPW>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) WS_ISSUE_PIECE(j)      // refill of the stage freed by this iteration's barrier
+            WS_ADVANCE()
+            const unsigned char* as = a_rd + (q % ST) * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int co = (x0 ^ (ks << 1)) << 4;
+                Frag8 af[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i].u = *(const uint4*)(as + i * 32 * 128 + co);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s * 4 + ks].v, af[i].v, acc[i], 0, 0, 0);
+            }
+        }
+        // ---- epilogue of tile t: staging is separate from the ring, which keeps streaming ----
+#pragma unroll
+        for (int pass = 0; pass < BM / ROWS_PASS; ++pass) {
+            if (pass > 0) __syncthreads();                       // previous pass's row walk is done with Cs
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i * 32 / ROWS_PASS != pass) continue;
+                const int ml = i * 32 + frow - pass * ROWS_PASS;
+                if (GEGLU) {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const float bvv[4] = {bA[g].x, bA[g].y, bA[g].z, bA[g].w};
+                        const float bgg[4] = {bA[2 + g].x, bA[2 + g].y, bA[2 + g].z, bA[2 + g].w};
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x = acc[i][4 * g + e] + bvv[e];
+                            const float gt = acc[i][8 + 4 * g + e] + bgg[e];
+                            o[e] = x * gelu_erf_f(gt);
+                        }
+                        uint2 ov; ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]);
+                        *(uint2*)(Cs + ml * CSTR + ocol + 8 * g + 4 * half) = ov;
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        uint2 ov;
+                        ov.x = pack2bf(acc[i][4 * g] + bA[g].x, acc[i][4 * g + 1] + bA[g].y);
+                        ov.y = pack2bf(acc[i][4 * g + 2] + bA[g].z, acc[i][4 * g + 3] + bA[g].w);
+                        *(uint2*)(Cs + ml * CSTR + ocol + 8 * g + 4 * half) = ov;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            }
+            __syncthreads();
+            const int mp = m0 + pass * ROWS_PASS;
+            if (p.wide) {
+                constexpr int CPR = BNO / 8, IT = ROWS_PASS * CPR / 256;     // 16-byte chunks per row; per thread: 4
+                static_assert(IT == 4, "row walk batch");
+                uint4 rv[IT];
+                bool ok[IT];
+#pragma unroll
+                for (int u = 0; u < IT; ++u) {
+                    const int idx = tid + u * 256;
+                    const int row = idx / CPR, c8 = (idx - row * CPR) * 8;
+                    ok[u] = mp + row < p.M && n0o + c8 < Nout;
+                    rv[u] = make_uint4(0, 0, 0, 0);
+                    if (Rg && ok[u]) rv[u] = *(const uint4*)(Rg + (long)(mp + row) * p.ldr + n0o + c8);
+                }
+#pragma unroll
+                for (int u = 0; u < IT; ++u) {
+                    if (!ok[u]) continue;
+                    const int idx = tid + u * 256;
+                    const int row = idx / CPR, c8 = (idx - row * CPR) * 8;
+                    uint4 v = *(const uint4*)(Cs + row * CSTR + c8);
+                    if (Rg) { v.x = add2bf(v.x, rv[u].x); v.y = add2bf(v.y, rv[u].y); v.z = add2bf(v.z, rv[u].z); v.w = add2bf(v.w, rv[u].w); }
+                    *(uint4*)(Cg + (long)(mp + row) * p.ldc + n0o + c8) = v;
+                }
+            } else {
+                constexpr int CPR = BNO / 4, IT = ROWS_PASS * CPR / 256;     // 8
+#pragma unroll 1
+                for (int i0 = 0; i0 < IT; i0 += 4) {
+                    uint2 rv[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int idx = tid + (i0 + u) * 256;
+                        const int row = idx / CPR, c4 = (idx - row * CPR) * 4;
+                        ok[u] = mp + row < p.M && n0o + c4 < Nout;
+                        rv[u] = make_uint2(0, 0);
+                        if (Rg && ok[u]) rv[u] = *(const uint2*)(Rg + (long)(mp + row) * p.ldr + n0o + c4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (!ok[u]) continue;
+                        const int idx = tid + (i0 + u) * 256;
+                        const int row = idx / CPR, c4 = (idx - row * CPR) * 4;
+                        uint2 v = *(const uint2*)(Cs + row * CSTR + c4);
+                        if (Rg) { v.x = add2bf(v.x, rv[u].x); v.y = add2bf(v.y, rv[u].y); }
+                        *(uint2*)(Cg + (long)(mp + row) * p.ldc + n0o + c4) = v;
+                    }
+                }
+            }
+        }
+        // the next tile's first Cs write is >= NSLAB barriers away: no extra barrier needed here
+    }
+#undef WS_ISSUE_PIECE
+#undef WS_ADVANCE
+    ws_wait_vmcnt<0>();                                          // drain the zero-fill tail before the LDS is released
+}
+
+// Whether the weight-stationary kernel can run this problem (the caller decides whether it should).
+bool ws_supported(const GCParams& p) {
+    return p.K == 320 && p.batch <= 1 && p.splitk <= 1 && !p.c_f32 && !p.temb && (p.epi == 0 || p.epi == 1) && (p.N % 4) == 0 &&
+           (p.epi != 1 || (p.N % 64) == 0);
+}
+
+int launch_gemm_ws(const GCParams& p, hipStream_t st) {
+    const bool geglu = p.epi == 1;
+    constexpr int ST = 3;
+    const size_t smem = (size_t)ST * 128 * 64 * 2 + (size_t)(geglu ? 128 * (64 + 8) : 64 * (128 + 8)) * 2;
+    static bool attr_done[2] = {false, false};
+    const void* kern = geglu ? (const void*)gemm_ws_kernel<true, ST> : (const void*)gemm_ws_kernel<false, ST>;
+    if (!attr_done[geglu]) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return set_error(MDX_ELAUNCH, "hipFuncSetAttribute(ws): %s", hipGetErrorString(e));
+        attr_done[geglu] = true;
+    }
+    if ((long)p.M * p.lda * 2 >= 0x7FFF0000L) return set_error(MDX_EINVAL, "gemm_ws: A exceeds the 2 GiB buffer window");
+    GCParams q = p;
+    q.mt = (p.M + 127) / 128; q.nt = (p.N + 127) / 128;
+    // walkers per N-tile: fill the 512 workgroup slots (2 per CU), multiple of 8 (one XCD per walker), at most one per M-tile
+    static const int slots = [] { const char* e = getenv("MDX_WS_SLOTS"); return e ? atoi(e) : 512; }();
+    int nwalk = slots / q.nt / 8 * 8;
+    if (nwalk < 8) nwalk = 8;
+    const int mt8 = (q.mt + 7) / 8 * 8;
+    if (nwalk > mt8) nwalk = mt8;
+    q.swz = nwalk;
+    const unsigned nblk = (unsigned)(nwalk * q.nt);
+    if (geglu) hipLaunchKernelGGL((gemm_ws_kernel<true, ST>), dim3(nblk), dim3(256), smem, st, q);
+    else hipLaunchKernelGGL((gemm_ws_kernel<false, ST>), dim3(nblk), dim3(256), smem, st, q);
+    return check_launch("gemm_ws_kernel");
+}
+
+}  // namespace mdx

@@ -64,6 +64,39 @@ def test_gemm(dev, M, N, K, bias, res, f32out):
     close(C, ref, name=f"gemm {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,res,inplace", [(8200, 640, False, False), (9001, 100, True, False), (8333, 320, True, True), (16384, 1280, False, False)])
+def test_gemm_weight_stationary(dev, M, N, res, inplace):
+    """K = 320, M >= 8192 takes gemm_ws.hip (weights in registers, persistent M walk): ragged M, N not a multiple of the
+    128-column tile, N % 8 != 0 (narrow epilogue), strided C view, residual aliased with C (in-place accumulate)."""
+    K = 320
+    A = rnd(M, K, seed=1); W = rnd(N, K, scale=K ** -0.5, seed=2); b = rnd(N, seed=3, dtype=torch.float32)
+    Cbig = torch.full((M, N + 24), float("nan"), dtype=BF, device=dev)
+    C = Cbig[:, 8:8 + N]
+    R = None
+    if res:
+        R0 = rnd(M, N, seed=4)
+        if inplace: C.copy_(R0); R = C
+        else: R = R0
+    O.run_ops([O.Gemm(A, W, C, bias=b, R=R, ws=ws_buf(dev))])
+    torch.cuda.synchronize()
+    ref = A.float().cpu() @ W.float().cpu().T + b.cpu()
+    if res: ref += R0.float().cpu()
+    close(C, ref, name=f"ws gemm {M}x{N}")
+    assert torch.isnan(Cbig[:, :8].float()).all() and torch.isnan(Cbig[:, 8 + N:].float()).all(), "wrote outside the C view"
+
+
+def test_gemm_weight_stationary_geglu_ragged(dev):
+    M, F_, K = 8250, 320, 320
+    A = rnd(M, K, seed=1); W = rnd(2 * F_, K, scale=K ** -0.5, seed=2, dtype=torch.float32, dev="cpu")
+    b = rnd(2 * F_, seed=3, dtype=torch.float32, dev="cpu")
+    Wp, bp = PK.pack_geglu(W, b)
+    C = torch.zeros(M, F_, dtype=BF, device=dev)
+    O.run_ops([O.Gemm(A, Wp.to(dev), C, bias=bp.to(dev), epilogue=L.EPI_GEGLU)])
+    torch.cuda.synchronize()
+    h, g = (A.float().cpu() @ W.to(BF).float().T + b).chunk(2, dim=-1)
+    close(C, h * F.gelu(g), name="ws geglu ragged")
+
+
 def test_gemm_forced_splitk_matches(dev):
     M, N, K = 546, 640, 5760
     A = rnd(M, K, seed=1); W = rnd(N, K, scale=K ** -0.5, seed=2); b = rnd(N, seed=3, dtype=torch.float32)
