@@ -153,12 +153,15 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
                 Frag8 af[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) af[i].u = *(const uint4*)(as + i * 32 * 128 + co);
+                if (!(p.dbg & 4)) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s * 4 + ks].v, af[i].v, acc[i], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s * 4 + ks].v, af[i].v, acc[i], 0, 0, 0);
+                }
             }
         }
         // ---- epilogue of tile t: staging is separate from the ring, which keeps streaming ----
+        if (p.dbg & 2) continue;                                 // debug: main loop only
 #pragma unroll
         for (int pass = 0; pass < BM / ROWS_PASS; ++pass) {
             if (pass > 0) __syncthreads();                       // previous pass's row walk is done with Cs
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
                         for (int e = 0; e < 4; ++e) {
                             const float x = acc[i][4 * g + e] + bvv[e];
                             const float gt = acc[i][8 + 4 * g + e] + bgg[e];
-                            o[e] = x * gelu_erf_f(gt);
+                            o[e] = (p.dbg & 1) ? x * gt : x * gelu_erf_f(gt);
                         }
                         uint2 ov; ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]);
                         *(uint2*)(Cs + ml * CSTR + ocol + 8 * g + 4 * half) = ov;
@@ -277,6 +280,8 @@ int launch_gemm_ws(const GCParams& p, hipStream_t st) {
     const int mt8 = (q.mt + 7) / 8 * 8;
     if (nwalk > mt8) nwalk = mt8;
     q.swz = nwalk;
+    static const int dbg = [] { const char* e = getenv("MDX_WS_DBG"); return e ? atoi(e) : 0; }();
+    q.dbg = dbg;
     const unsigned nblk = (unsigned)(nwalk * q.nt);
     if (geglu) hipLaunchKernelGGL((gemm_ws_kernel<true, ST>), dim3(nblk), dim3(256), smem, st, q);
     else hipLaunchKernelGGL((gemm_ws_kernel<false, ST>), dim3(nblk), dim3(256), smem, st, q);
