@@ -31,6 +31,8 @@ int launch_gemm_dma(const GCParams& p, bool conv, int tile, hipStream_t st);
 void dma_tile_dims(int tile, int* bm, int* bn);
 int launch_gemm_pp(const GCParams& p, bool conv, int cfg, hipStream_t st);      // gemm_pp.hip: 256-row ping-pong tiles
 bool pp_supported(const GCParams& p, int cfg);
+int launch_conv3x3(const GCParams& p, hipStream_t st);                          // conv3x3.hip: 3x3/s1/p1 conv, A slab shared by 3 taps
+bool conv3x3_supported(const GCParams& p);
 int launch_gemm_ws(const GCParams& p, hipStream_t st);                          // gemm_ws.hip: weight-stationary K = 320 GEMM
 bool ws_supported(const GCParams& p);
 void pp_tile_dims(int cfg, int* bm, int* bn);
@@ -381,6 +383,12 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
             if (c < best_cost) { best_cost = c; best = cfg; }
         }
         if (best >= 0) return launch_gemm_pp(p, conv, best, st);
+    }
+    // 3x3 / stride 1 / pad 1 convs with enough rows for 128-row tiles: conv3x3.hip.  MDX_CONV3: 0 off, 1 when M >= 4096 (default).
+    // Runs after the ping-pong cost model: N % 256 == 0 convs with K >= 1024 stay on gemm_pp.hip (927 vs 851 TFLOP/s measured).
+    static const int c3_mode = [] { const char* e = getenv("MDX_CONV3"); return e ? atoi(e) : 1; }();
+    if (impl == 0 && conv && c3_mode > 0 && splitk == 1 && conv3x3_supported(p) && p.M >= 4096 && (p.N % 4) == 0) {
+        return launch_conv3x3(p, st);                                              // (small grids were given split-K above)
     }
     int rc;
     if (impl != 0) {

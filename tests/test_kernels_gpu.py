@@ -157,6 +157,9 @@ def test_gemm_batched_vt(dev, Bt, T, Cc):
     (1, 41, 40, 16, 32, 3, (2, 2), (2, 1), False, False),        # map-encoder style asymmetric pad
     (1, 22, 20, 96, 256, 3, (2, 1), (2, 1), False, False),
     (2, 14, 25, 640, 640, 1, (1, 1), (0, 0), True, False),       # 1x1
+    (4, 28, 50, 320, 320, 3, (1, 1), (1, 1), True, True),        # M >= 4096: conv3x3.hip (3 taps share one A slab)
+    (13, 14, 25, 640, 192, 3, (1, 1), (1, 1), False, True),      # tiles straddle images (350 px each), ragged M and N
+    (48, 7, 13, 128, 320, 3, (1, 1), (1, 1), True, False),       # 91-pixel images: a 128-row tile covers 2-3 of them
 ])
 def test_conv_mfma(dev, B, H, W, Cin, Cout, k, stride, pad, res, temb):
     x = rnd(B, H, W, Cin, seed=1)
