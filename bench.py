@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scenes-per-gpu", type=int, default=32,
+    ap.add_argument("--scenes-per-gpu", type=int, default=64,
                     help="scenes sampled per rank per pipe() call (throughput grows with the batch: 3.2 / 3.8 / 4.2 scenes/s at 8 / 16 / 32)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--scheduler", choices=["ddim", "unipc"], default="ddim",

@@ -38,7 +38,7 @@ bool ws_supported(const GCParams& p);
 void pp_tile_dims(int cfg, int* bm, int* bn);
 
 // WM x WN waves (NTH = 64 WM WN threads); each wave owns a (BM/WM) x (BN/WN) sub-tile of 32x32 MFMA tiles.
-template <int BM, int BN, int BK, int WM, int WN, bool CONV>
+template <int BM, int BN, int BK, int WM, int WN, bool CONV, bool PIPE>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 1) void gemm_conv_kernel(GCParams p) {
     constexpr int NTH = WM * WN * 64;
     constexpr int LSTR = BK + 8;  // LDS row stride in elements (+16 B pad: conflict-free ds_read_b128)
@@ -195,18 +195,51 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 1) void gemm_con
         if (t + 1 < nt) load_tile(t + 1);
         const bf16_t* as = As + buf * BM * LSTR + (wm * TM * 32 + frow) * LSTR + fk;
         const bf16_t* bs = Bs + buf * BN * LSTR + (wn * TN * 32 + frow) * LSTR + fk;
+        if constexpr (PIPE && TM == 2 && TN == 2) {
+            // Fragment reads run one k-step ahead of the MFMAs (second register set), pinned between them with
+            // sched_group_barrier: left alone every ds_read sits right before its first use and each k-step exposes an LDS
+            // round trip (conv3x3.hip measured +7 % from this alone).
+            Frag8 af[2][TM], bfr[2][TN];
+#define GC_READ(set, ks_)                                                                                             \
+            {                                                                                                         \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i) af[set][i].u = *(const uint4*)(as + i * 32 * LSTR + (ks_) * 16);  \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) bfr[set][j].u = *(const uint4*)(bs + j * 32 * LSTR + (ks_) * 16); \
+            }
+            GC_READ(0, 0)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            Frag8 af[TM], bfr[TN];
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks + 1 < BK / 16) GC_READ(nxt, ks + 1)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i].u = *(const uint4*)(as + i * 32 * LSTR + ks * 16);
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j].u = *(const uint4*)(bs + j * 32 * LSTR + ks * 16);
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][j].v, af[cur][i].v, acc[i][j], 0, 0, 0);
+                if (ks + 1 < BK / 16) {                              // {1 MFMA, 1 ds_read} x 4 (PIPE is only instantiated for TM = TN = 2)
+                    static_assert(TM == 2 && TN == 2, "interleave pattern");
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef GC_READ
+        } else {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                Frag8 af[TM], bfr[TN];
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j].v, af[i].v, acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i) af[i].u = *(const uint4*)(as + i * 32 * LSTR + ks * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[j].u = *(const uint4*)(bs + j * 32 * LSTR + ks * 16);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j].v, af[i].v, acc[i][j], 0, 0, 0);
+            }
         }
         if (t + 1 < nt) store_tile(buf ^ 1);
         __syncthreads();
@@ -274,12 +307,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GCParams p) {
     epilogue_store(p, 0, m, nb, v, g);
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool CONV>
-static int launch_one(const GCParams& p, hipStream_t st) {
+template <int BM, int BN, int BK, int WM, int WN, bool CONV, bool PIPE>
+static int launch_one_(const GCParams& p, hipStream_t st) {
     constexpr size_t ring = (size_t)2 * (BM + BN) * (BK + 8) * sizeof(bf16_t), ctile = (size_t)BM * (BN + 8) * 2;
     constexpr size_t smem = ring > ctile ? ring : ctile;
     static bool attr_done = false;
-    auto kern = gemm_conv_kernel<BM, BN, BK, WM, WN, CONV>;
+    auto kern = gemm_conv_kernel<BM, BN, BK, WM, WN, CONV, PIPE>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return set_error(MDX_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -293,6 +326,16 @@ static int launch_one(const GCParams& p, hipStream_t st) {
     dim3 grid(nblk, 1, p.batch > 1 ? p.batch : p.splitk);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, q);
     return check_launch("gemm_conv_kernel");
+}
+
+// MDX_GEMM_PIPE (default 1): software-pipelined fragment reads for the 128x128x64 GEMM tile (the one with registers to spare).
+template <int BM, int BN, int BK, int WM, int WN, bool CONV>
+static int launch_one(const GCParams& p, hipStream_t st) {
+    static const int pipe = [] { const char* e = getenv("MDX_GEMM_PIPE"); return e ? atoi(e) : 1; }();
+    if constexpr (BM == 128 && BN == 128 && BK == 64 && WM == 2 && WN == 2) {
+        if (pipe) return launch_one_<BM, BN, BK, WM, WN, CONV, true>(p, st);
+    }
+    return launch_one_<BM, BN, BK, WM, WN, CONV, false>(p, st);
 }
 
 // Tile / split-K choice.  The chip has 256 CUs.
@@ -365,9 +408,10 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
     // Large shapes: the 256-row ping-pong kernel (gemm_pp.hip).  MDX_GEMM_PP: 0 off, 1 cost model (default), 2 whenever supported.
     // Cost model: rounds of tiles over the 256 CUs x tile area / relative per-tile efficiency.  Measured (tools/kbench.py, 96 views):
     // the 256 x 256 tile is 1.16-1.25x the 128 x 128 kernel per FLOP when N % 256 == 0 and K >= 1024 (N = 1280 convs 763 -> 888,
+    // end to end at 64 scenes/GPU: +3.2 % with gain 1.18, +3.8 % with 1.5 — the default);
     // 612 -> 764 TFLOP/s); the 256 x 320 tile (N = 320 / 640) spills and loses, so it is opt-in (MDX_PP_CFG1=1).
     static const int pp_mode = [] { const char* e = getenv("MDX_GEMM_PP"); return e ? atoi(e) : 1; }();
-    static const double pp_gain = [] { const char* e = getenv("MDX_PP_GAIN"); return e ? atof(e) : 1.18; }();
+    static const double pp_gain = [] { const char* e = getenv("MDX_PP_GAIN"); return e ? atof(e) : 1.5; }();
     static const int pp_cfg1 = [] { const char* e = getenv("MDX_PP_CFG1"); return e ? atoi(e) : 0; }();
     if (impl == 0 && pp_mode > 0 && splitk == 1) {
         const double cost_old = (double)((tiles + 511) / 512) * 2.0 * BM * BN;   // two co-resident workgroups share a CU
