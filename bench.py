@@ -47,24 +47,28 @@ def per_op_profile(plan, reps=3):
     lowered = [op.lower() for op in plan.step_ops]
     n = len(lowered)
     best = [float("inf")] * n
+    kname = [""] * n
+    last_kernel = L.lib().mdx_last_kernel
     for _ in range(reps):
         plan.step_ctr.zero_()
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
         evs[0].record()
         for i, (code, desc) in enumerate(lowered):
             L.call_op(code, desc, st)
+            kname[i] = (last_kernel() or b"").decode()          # which kernel the library routed this op to
             evs[i + 1].record()
         torch.cuda.synchronize()
         for i in range(n):
             best[i] = min(best[i], evs[i].elapsed_time(evs[i + 1]))
-    fam = {}
+    fam, kern = {}, {}
     rows = []
-    for op, ms in zip(plan.step_ops, best):
+    for op, ms, kn in zip(plan.step_ops, best, kname):
         k = FL.kernel_family(op)
-        f = fam.setdefault(k, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
-        f["ms"] += ms; f["flops"] += FL.op_flops(op); f["bytes"] += FL.op_bytes(op); f["launches"] += 1
-        rows.append({"name": getattr(op, "name", ""), "family": k, "ms": ms, "gflop": FL.op_flops(op) / 1e9})
-    return fam, rows
+        for d, key in ((fam, k), (kern, kn)):
+            f = d.setdefault(key, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "mfma": k.startswith(("gemm_conv", "attn"))})
+            f["ms"] += ms; f["flops"] += FL.op_flops(op); f["bytes"] += FL.op_bytes(op); f["launches"] += 1
+        rows.append({"name": getattr(op, "name", ""), "family": k, "kernel": kn, "ms": ms, "gflop": FL.op_flops(op) / 1e9})
+    return fam, kern, rows
 
 
 def cpu_baseline(cfg, n_steps_timed=2):
@@ -172,11 +176,11 @@ def main():
                    "mfma_frac_end_to_end": round(f_scene * scenes_per_s / world / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
     }
     if not args.no_op_profile:
-        fam, rows = per_op_profile(plan)
-        dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
-        name, d = dom
+        fam, kern, rows = per_op_profile(plan)
+        # dominant KERNEL (the name rocprofv3 --kernel-trace --stats reports, template arguments abbreviated) by time in a step
+        name, d = max(kern.items(), key=lambda kv: kv[1]["ms"])
         compute = {k: v for k, v in fam.items() if v["flops"] > 0 and k.startswith(("gemm_conv", "attn"))}
-        if name.startswith(("gemm_conv", "attn")):
+        if d["mfma"] and d["flops"] > 0:
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
@@ -185,6 +189,10 @@ def main():
             ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                                "traffic": None, "launches_per_step": d["launches"], "avg_launch_us": 1e3 * d["ms"] / d["launches"]}
+        top = sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:10]
+        out["roofline"]["per_kernel"] = {k: {"ms_per_step": round(v["ms"], 3), "launches": v["launches"], "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 1),
+                                             "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["mfma"] and v["flops"] else None}
+                                         for k, v in top}
         out["roofline"]["per_family"] = {k: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"],
                                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None}
                                          for k, v in fam.items()}

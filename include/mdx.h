@@ -294,6 +294,10 @@ int mdx_graph_destroy(void* graph);
 
 int mdx_abi_version(void);
 const char* mdx_last_error(void);
+/* Name of the kernel the calling thread's last op launched (the one doing the op's work; which GEMM / conv main loop a
+ * descriptor is routed to is decided inside the library by shape).  Measurement aid: bench.py groups its per-launch HIP-event
+ * timings by this name so they can be compared with rocprofv3's kernel statistics. */
+const char* mdx_last_kernel(void);
 /* Device facts for bench/roofline bookkeeping: out[0]=CU count, out[1]=clock kHz, out[2]=HBM bytes. */
 int mdx_device_info(int64_t* out3);
 

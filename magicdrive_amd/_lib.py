@@ -65,7 +65,7 @@ ENTRY_OF_OP = {
 # every symbol include/mdx.h declares
 EXPORTS = sorted(set(ENTRY_OF_OP.values()) | {
     "mdx_program_run", "mdx_graph_create", "mdx_graph_launch", "mdx_graph_destroy",
-    "mdx_abi_version", "mdx_last_error", "mdx_device_info"})
+    "mdx_abi_version", "mdx_last_error", "mdx_last_kernel", "mdx_device_info"})
 
 
 class MdxOp(C.Structure):
@@ -111,6 +111,7 @@ def lib() -> C.CDLL:
     l.mdx_graph_destroy.argtypes = [C.c_void_p]
     l.mdx_abi_version.restype = C.c_int
     l.mdx_last_error.restype = C.c_char_p
+    l.mdx_last_kernel.restype = C.c_char_p
     l.mdx_device_info.restype = C.c_int
     l.mdx_device_info.argtypes = [C.POINTER(C.c_int64)]
     if l.mdx_abi_version() != ABI_VERSION:

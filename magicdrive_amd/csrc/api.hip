@@ -13,6 +13,10 @@ char* error_buffer() {
     static thread_local char buf[512] = {0};
     return buf;
 }
+char* kernel_tag_buffer() {
+    static thread_local char buf[128] = {0};
+    return buf;
+}
 }  // namespace mdx
 
 using namespace mdx;
@@ -95,6 +99,8 @@ extern "C" int mdx_graph_destroy(void* graph) {
 
 extern "C" int mdx_abi_version(void) { return MDX_ABI_VERSION; }
 extern "C" const char* mdx_last_error(void) { return error_buffer(); }
+
+extern "C" const char* mdx_last_kernel(void) { return kernel_tag_buffer(); }
 
 extern "C" int mdx_device_info(int64_t* out3) {
     if (!out3) return set_error(MDX_EINVAL, "mdx_device_info: null out");

@@ -307,7 +307,9 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
         hipLaunchKernelGGL((attn_kernel<D16, NW, true>), grid, dim3(NW * 64), 0, st, q);
     else
         hipLaunchKernelGGL((attn_kernel<D16, NW, false>), grid, dim3(NW * 64), 0, st, q);
-    return check_launch("attn_kernel");
+    char tag[64];
+    snprintf(tag, sizeof tag, "attn_kernel<%d,%d,%s>", D16, NW, p.nsrc == 2 ? "xview" : "self");
+    return check_launch(tag);
 }
 
 template <int D16>

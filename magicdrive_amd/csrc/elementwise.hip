@@ -455,7 +455,7 @@ extern "C" int mdx_cfg_ddim_step(const MdxDdimDesc* d, void* stream) {
     int rc = check_launch("ddim_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, p.step);
-    return check_launch("step_inc_kernel");
+    return check_launch("step_inc_kernel", false);
 }
 
 extern "C" int mdx_cfg_unipc_step(const MdxUniPCDesc* d, void* stream) {
@@ -469,5 +469,5 @@ extern "C" int mdx_cfg_unipc_step(const MdxUniPCDesc* d, void* stream) {
     int rc = check_launch("unipc_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, p.step);
-    return check_launch("step_inc_kernel");
+    return check_launch("step_inc_kernel", false);
 }

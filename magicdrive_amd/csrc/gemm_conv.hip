@@ -325,7 +325,9 @@ static int launch_one_(const GCParams& p, hipStream_t st) {
     const unsigned nblk = q.swz ? (unsigned)((q.mt + 7) / 8 * 8 * q.nt) : (unsigned)(q.mt * q.nt);
     dim3 grid(nblk, 1, p.batch > 1 ? p.batch : p.splitk);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, q);
-    return check_launch("gemm_conv_kernel");
+    char tag[96];
+    snprintf(tag, sizeof tag, "gemm_conv_kernel<%d,%d,%d,%d,%d,%s>", BM, BN, BK, WM, WN, CONV ? "conv" : "gemm");
+    return check_launch(tag);
 }
 
 // MDX_GEMM_PIPE (default 1): software-pipelined fragment reads for the 128x128x64 GEMM tile (the one with registers to spare).
@@ -453,7 +455,7 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
     if (splitk > 1) {
         long n = (long)p.M * (p.N / 4);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
-        return check_launch("splitk_reduce_kernel");
+        return check_launch("splitk_reduce_kernel", false);
     }
     return MDX_OK;
 }

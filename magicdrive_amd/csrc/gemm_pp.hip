@@ -411,7 +411,9 @@ static int launch_pp(const GCParams& p, hipStream_t st) {
     q.swz = swz && q.nt > 1 && q.mt >= 64;
     const unsigned nblk = q.swz ? (unsigned)((q.mt + 7) / 8 * 8 * q.nt) : (unsigned)(q.mt * q.nt);
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), smem, st, q);
-    return check_launch("gemm_pp_kernel");
+    char tag[96];
+    snprintf(tag, sizeof tag, "gemm_pp_kernel<%dx%d,%s>", BM, BN, CONV ? "conv" : "gemm");
+    return check_launch(tag);
 }
 
 // cfg 0: 256 x 256 tile (waves 2 x 4, 128 x 64 each) — GEGLU and N % 256 == 0;  cfg 1: 256 x 320 (waves 4 x 2, 64 x 160 each).

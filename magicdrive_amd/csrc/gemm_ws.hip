@@ -285,7 +285,7 @@ int launch_gemm_ws(const GCParams& p, hipStream_t st) {
     const unsigned nblk = (unsigned)(nwalk * q.nt);
     if (geglu) hipLaunchKernelGGL((gemm_ws_kernel<true, ST>), dim3(nblk), dim3(256), smem, st, q);
     else hipLaunchKernelGGL((gemm_ws_kernel<false, ST>), dim3(nblk), dim3(256), smem, st, q);
-    return check_launch("gemm_ws_kernel");
+    return check_launch(geglu ? "gemm_ws_kernel<geglu>" : "gemm_ws_kernel<plain>");
 }
 
 }  // namespace mdx

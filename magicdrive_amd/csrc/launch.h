@@ -8,6 +8,7 @@
 namespace mdx {
 
 char* error_buffer();  // thread-local, 512 bytes (api.hip)
+char* kernel_tag_buffer();  // thread-local, 128 bytes (api.hip): name of the last primary kernel launched (mdx_last_kernel)
 
 inline int set_error(int code, const char* fmt, ...) {
     va_list ap;
@@ -18,7 +19,9 @@ inline int set_error(int code, const char* fmt, ...) {
 }
 
 // Launch errors (bad configuration) surface through hipGetLastError without a sync.
-inline int check_launch(const char* what) {
+// `primary` = the kernel that does the op's work (reduce / finalise helpers pass false and keep the previous tag).
+inline int check_launch(const char* what, bool primary = true) {
+    if (primary) snprintf(kernel_tag_buffer(), 128, "%s", what);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(MDX_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
     return MDX_OK;

@@ -327,11 +327,11 @@ extern "C" int mdx_groupnorm_bf16(const MdxGroupNormDesc* d, void* stream) {
         if ((long)p.B * q.nchunk * p.G * 3 * (long)sizeof(float) <= d->ws_bytes) {
             dim3 grid2(q.nchunk, p.B);
             hipLaunchKernelGGL(gn_stats_kernel, grid2, dim3(256), 0, st, q);
-            int rc = check_launch("gn_stats_kernel");
+            int rc = check_launch("gn_stats_kernel", false);
             if (rc) return rc;
             size_t sm = (size_t)(2 * p.G + 2 * p.C) * sizeof(float);
             hipLaunchKernelGGL(gn_apply_kernel, grid2, dim3(256), sm, st, q);
-            return check_launch("gn_apply_kernel");
+            return check_launch("gn_stats_kernel+gn_apply_kernel");
         }
     }
     // vector width limited by cpg and by the alignment of every group start / row stride
