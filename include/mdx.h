@@ -42,7 +42,7 @@ extern "C" {
 #define MDX_ELAUNCH (-2)     /* hip launch / runtime error */
 #define MDX_EUNSUPPORTED (-3)
 
-#define MDX_ABI_VERSION 1
+#define MDX_ABI_VERSION 2
 
 /* ---- epilogue flags shared by GEMM / conv ------------------------------- */
 #define MDX_EPI_NONE 0
@@ -76,6 +76,13 @@ typedef struct MdxGemmDesc {
     int64_t epilogue, splitk;
     int64_t c_is_f32;           /* 1: C (and R) are fp32 instead of bf16 */
     int64_t ws_bytes;           /* size of ws; split-K is reduced (or disabled) to fit */
+    /* Optional transposed second output (fused q/k/v projection: the attention kernel wants V^T[view][channel][token]):
+     * raw columns n >= vt_from are NOT written to C but to Vt[b][n - vt_from][t] with b = m / vt_T, t = m % vt_T
+     * (element strides vt_stride per view, vt_ld per channel).  C then has vt_from columns.  Needs K == 320, vt_from % 128 == 0,
+     * vt_T % 8 == 0, M % 8 == 0, 16-byte aligned Vt rows, no bias / epilogue on those columns (diffusers' to_v has none) —
+     * it is implemented by the weight-stationary kernel only; anything else is rejected with MDX_EINVAL.  Vt = NULL: off. */
+    void* Vt;
+    int64_t vt_from, vt_T, vt_ld, vt_stride;
 } MdxGemmDesc;
 int mdx_gemm_bf16(const MdxGemmDesc* d, void* stream);
 

@@ -495,6 +495,15 @@ extern "C" int mdx_gemm_bf16(const MdxGemmDesc* d, void* stream) {
     p.temb_sel_stride = d->temb_sel_stride; p.temb_b_stride = d->temb_b_stride;
     p.rows_per_b = d->rows_per_b > 0 ? (int)d->rows_per_b : 1;
     p.epi = (int)d->epilogue; p.splitk = (int)d->splitk; p.c_f32 = (int)d->c_is_f32; p.ws_bytes = d->ws_bytes;
+    if (d->Vt) {   // fused q/k/v projection with a transposed V output: weight-stationary kernel only
+        p.Vt = (bf16_t*)d->Vt; p.vt_from = (int)d->vt_from; p.vt_T = (int)d->vt_T; p.vt_ld = d->vt_ld; p.vt_stride = d->vt_stride;
+        if (!ws_supported(p) || d->epilogue || d->bias || d->R || (d->vt_from % 128) || d->vt_from <= 0 || d->vt_from >= d->N || d->vt_T <= 0 ||
+            (d->vt_T % 8) || (d->M % d->vt_T) || (d->vt_ld % 8) || (d->vt_stride % 8) || ((uintptr_t)d->Vt & 15))
+            return set_error(MDX_EINVAL, "mdx_gemm_bf16: transposed V output needs K=320, plain epilogue, vt_from %% 128 == 0, vt_T %% 8 == 0, aligned Vt");
+        { GCParams q = p; const long nout = d->vt_from;      // wide-path check of the C part
+          q.wide = (nout % 8) == 0 && (p.ldc % 8) == 0 && (((uintptr_t)p.C) & 15) == 0;
+          return launch_gemm_ws(q, (hipStream_t)stream); }
+    }
     return launch_gemm_conv(p, false, (hipStream_t)stream);
 }
 

@@ -26,6 +26,8 @@ struct GCParams {
     // Only a permutation of the reduction order; needs Cin % 64 == 0.
     int cimajor;
     int wide;                     // epilogue may use 16-byte global accesses for C / R (alignment + N % 8 checked by the launcher)
+    // fused q/k/v projection (MdxGemmDesc.Vt): raw columns >= vt_from are stored transposed to Vt[m / vt_T][n - vt_from][m % vt_T]
+    bf16_t* Vt; int vt_from, vt_T; long vt_ld, vt_stride;
     int dbg;                      // debug knobs of gemm_pp.hip (MDX_PP_DBG): 1 skip LDS stores, 2 skip global loads, 4 skip MFMAs
 };
 

@@ -33,12 +33,15 @@ __device__ __forceinline__ void ws_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(
 // (one slab ahead) every slab waited on its loads (measured: 25 k cycles per tile for 2.6 k cycles of MFMA work).
 // LDS rows are 128 B, unpadded (the DMA writes 1 KiB linearly: 8 rows per wave instruction); the 16-byte chunk index is
 // XOR-swizzled by (row >> 1) & 7 on the SOURCE side and again on the fragment reads: conflict-free ds_read_b128.
-template <bool GEGLU, int ST>
+// VT: every tile of the launch is stored transposed to p.Vt (the V part of a fused q/k/v projection is its own launch over the
+// V rows of the weight: one kernel carrying both operand orders spilled 89 VGPRs).
+template <bool GEGLU, int ST, bool VT>
 __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
     constexpr int BM = 128, BN = 128, BK = 64, KS = 20, NSLAB = 5;
     constexpr int BNO = GEGLU ? BN / 2 : BN;
     constexpr int CSTR = BNO + 8;
     constexpr int ROWS_PASS = GEGLU ? 128 : 64;                  // epilogue staging holds this many rows (keeps LDS <= 80 KB: 2 WG/CU)
+    constexpr int CSTR_T = ROWS_PASS + 8;                        // transposed staging (V tiles): [128 channels][ROWS_PASS tokens]
     constexpr int STAGE = BM * BK * 2;                           // 16 KiB
     constexpr int PPW = 4;                                       // 1-KiB DMA pieces per wave per slab
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
     const unsigned char* const a_rd = smem + frow * 128;
     const bf16_t* Rg = p.R ? (const bf16_t*)p.R : nullptr;
     bf16_t* Cg = (bf16_t*)p.C;
+    constexpr bool vtile = VT;
     const int n0o = GEGLU ? n0 / 2 : n0, Nout = GEGLU ? p.N / 2 : p.N;
     int q = 0;                                                   // slab counter (ring stage = q % ST)
     for (int t = 0; t < ntiles; ++t) {
@@ -154,9 +158,15 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) af[i].u = *(const uint4*)(as + i * 32 * 128 + co);
                 if (!(p.dbg & 4)) {
+                    if (vtile) {          // operands swapped: the accumulator comes out transposed (lane = channel, registers = tokens)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s * 4 + ks].v, af[i].v, acc[i], 0, 0, 0);
+                        for (int i = 0; i < 4; ++i)
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i].v, wf[s * 4 + ks].v, acc[i], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s * 4 + ks].v, af[i].v, acc[i], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -165,6 +175,37 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
 #pragma unroll
         for (int pass = 0; pass < BM / ROWS_PASS; ++pass) {
             if (pass > 0) __syncthreads();                       // previous pass's row walk is done with Cs
+            if constexpr (VT) {
+                // V tile: lane = channel 32 wave + frow, accumulator register r = token (r&3) + 8 (r>>2) + 4 half of m-tile i
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i * 32 / ROWS_PASS != pass) continue;
+                    const float bch = (p.bias && wrow < p.N) ? p.bias[wrow] : 0.f;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int tl = i * 32 + 8 * g + 4 * half - pass * ROWS_PASS;       // token inside the pass
+                        uint2 ov;
+                        ov.x = pack2bf(acc[i][4 * g] + bch, acc[i][4 * g + 1] + bch);
+                        ov.y = pack2bf(acc[i][4 * g + 2] + bch, acc[i][4 * g + 3] + bch);
+                        *(uint2*)(Cs + (32 * wave + frow) * CSTR_T + tl) = ov;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+                }
+                __syncthreads();
+                const int mp = m0 + pass * ROWS_PASS;
+                constexpr int CPRT = ROWS_PASS / 8;                                    // 16-byte token chunks per channel row
+#pragma unroll
+                for (int u = 0; u < 128 * CPRT / 256; ++u) {
+                    const int idx = tid + u * 256;
+                    const int ch = idx / CPRT, c8 = (idx - ch * CPRT) * 8;
+                    const int m = mp + c8, cv = n0 + ch;
+                    if (m >= p.M || cv >= p.N) continue;
+                    const int b = m / p.vt_T, t = m - b * p.vt_T;
+                    *(uint4*)(p.Vt + (long)b * p.vt_stride + (long)cv * p.vt_ld + t) = *(const uint4*)(Cs + ch * CSTR_T + c8);
+                }
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (i * 32 / ROWS_PASS != pass) continue;
@@ -259,18 +300,17 @@ bool ws_supported(const GCParams& p) {
            (p.epi != 1 || (p.N % 64) == 0);
 }
 
-int launch_gemm_ws(const GCParams& p, hipStream_t st) {
-    const bool geglu = p.epi == 1;
+template <bool GEGLU, bool VT>
+static int launch_ws_one(const GCParams& p, hipStream_t st) {
     constexpr int ST = 3;
-    const size_t smem = (size_t)ST * 128 * 64 * 2 + (size_t)(geglu ? 128 * (64 + 8) : 64 * (128 + 8)) * 2;
-    static bool attr_done[2] = {false, false};
-    const void* kern = geglu ? (const void*)gemm_ws_kernel<true, ST> : (const void*)gemm_ws_kernel<false, ST>;
-    if (!attr_done[geglu]) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const size_t smem = (size_t)ST * 128 * 64 * 2 + (size_t)128 * (64 + 8) * 2;   // ring + staging (also holds 64 x 136 and the transposed 128 x 72)
+    static bool attr_done = false;
+    auto kern = gemm_ws_kernel<GEGLU, ST, VT>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return set_error(MDX_ELAUNCH, "hipFuncSetAttribute(ws): %s", hipGetErrorString(e));
-        attr_done[geglu] = true;
+        attr_done = true;
     }
-    if ((long)p.M * p.lda * 2 >= 0x7FFF0000L) return set_error(MDX_EINVAL, "gemm_ws: A exceeds the 2 GiB buffer window");
     GCParams q = p;
     q.mt = (p.M + 127) / 128; q.nt = (p.N + 127) / 128;
     // walkers per N-tile: fill the 512 workgroup slots (2 per CU), multiple of 8 (one XCD per walker), at most one per M-tile
@@ -282,10 +322,22 @@ int launch_gemm_ws(const GCParams& p, hipStream_t st) {
     q.swz = nwalk;
     static const int dbg = [] { const char* e = getenv("MDX_WS_DBG"); return e ? atoi(e) : 0; }();
     q.dbg = dbg;
-    const unsigned nblk = (unsigned)(nwalk * q.nt);
-    if (geglu) hipLaunchKernelGGL((gemm_ws_kernel<true, ST>), dim3(nblk), dim3(256), smem, st, q);
-    else hipLaunchKernelGGL((gemm_ws_kernel<false, ST>), dim3(nblk), dim3(256), smem, st, q);
-    return check_launch(geglu ? "gemm_ws_kernel<geglu>" : "gemm_ws_kernel<plain>");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nwalk * q.nt)), dim3(256), smem, st, q);
+    return check_launch(GEGLU ? "gemm_ws_kernel<geglu>" : (VT ? "gemm_ws_kernel<vT>" : "gemm_ws_kernel<plain>"));
+}
+
+int launch_gemm_ws(const GCParams& p, hipStream_t st) {
+    if ((long)p.M * p.lda * 2 >= 0x7FFF0000L) return set_error(MDX_EINVAL, "gemm_ws: A exceeds the 2 GiB buffer window");
+    if (p.epi == 1) return launch_ws_one<true, false>(p, st);
+    if (!p.Vt) return launch_ws_one<false, false>(p, st);
+    // fused q/k/v: the C columns [0, vt_from) and the transposed V columns [vt_from, N) are two launches over two row ranges of W
+    GCParams c = p;
+    c.N = p.vt_from; c.Vt = nullptr;
+    int rc = launch_ws_one<false, false>(c, st);
+    if (rc != MDX_OK) return rc;
+    GCParams v = p;
+    v.W = p.W + (long)p.vt_from * p.ldw; v.N = p.N - p.vt_from; v.bias = p.bias ? p.bias + p.vt_from : nullptr; v.R = nullptr; v.C = nullptr;
+    return launch_ws_one<false, true>(v, st);
 }
 
 }  // namespace mdx

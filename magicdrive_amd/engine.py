@@ -224,10 +224,17 @@ class Builder:
     def self_like_attention(self, net, pre, n: torch.Tensor, B, T, C, heads, cross_view: bool, name) -> torch.Tensor:
         """q,k fused projection + V^T projection + fused attention over the same token set (attn1) or over the
         two neighbour views (attn4).  n: normalised tokens [B*T, C]."""
-        qk = self.gemm(n, net.cat_lin([pre + "to_q.weight", pre + "to_k.weight"]), 2 * C, name=name + ".qk")
         ldv = PK.round_up(T, 8)
         vt = self.pool.get((B, C, ldv))
-        self.emit(O.Gemm(net.lin(pre + "to_v.weight"), n.view(B, T, C), vt[:, :, :T], name=name + ".vT"))
+        if C == 320 and T % 8 == 0 and B * T >= 8192:
+            # level 0: ONE weight-stationary launch pair reads the tokens for q, k and v; the V columns are stored transposed
+            # (gemm_ws.hip) — replaces the batched V^T GEMM (245 TFLOP/s, 2 % of the step)
+            qk = self.pool.get((B * T, 2 * C))
+            self.emit(O.Gemm(n, net.cat_lin([pre + "to_q.weight", pre + "to_k.weight", pre + "to_v.weight"]), qk, Vt=vt, vt_from=2 * C, vt_T=T,
+                             ws=self.ws, name=name + ".qkv"))
+        else:
+            qk = self.gemm(n, net.cat_lin([pre + "to_q.weight", pre + "to_k.weight"]), 2 * C, name=name + ".qk")
+            self.emit(O.Gemm(net.lin(pre + "to_v.weight"), n.view(B, T, C), vt[:, :, :T], name=name + ".vT"))
         ao = self.pool.get((B * T, C))
         qk3 = qk.view(B, T, 2 * C)
         self.emit(O.Attn(qk3[:, :, :C], qk3[:, :, C:], vt, ao.view(B, T, C), heads=heads, Tk=T, scale=(C // heads) ** -0.5,

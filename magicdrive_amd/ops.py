@@ -61,6 +61,11 @@ class Gemm:
     splitk: int = 0
     ws: Optional[torch.Tensor] = None
     name: str = ""
+    # fused q/k/v projection: raw columns >= vt_from go, transposed, to Vt [Bv, N - vt_from, >= vt_T] (token m -> view m // vt_T,
+    # position m % vt_T); C then has vt_from columns (include/mdx.h: MdxGemmDesc.Vt)
+    Vt: Optional[torch.Tensor] = None
+    vt_from: int = 0
+    vt_T: int = 0
     opcode = L.OP_GEMM
 
     def lower(self):
@@ -81,7 +86,13 @@ class Gemm:
         N, K2, ldw = _rows2d(W)
         Mc, No, ldc = _rows2d(C2)
         _chk(K == K2 and M == Mc, f"gemm {self.name}: shape mismatch A{tuple(A.shape)} W{tuple(W.shape)} C{tuple(C2.shape)}")
-        _chk(No == (N // 2 if self.epilogue == L.EPI_GEGLU else N), f"gemm {self.name}: C has {No} cols for N={N}")
+        if self.Vt is not None:
+            _chk(self.epilogue == L.EPI_NONE and batch == 1 and No == self.vt_from and 0 < self.vt_from < N and self.vt_T > 0,
+                 f"gemm {self.name}: fused V^T output needs a plain epilogue and C with vt_from columns")
+            _chk(self.Vt.dim() == 3 and self.Vt.dtype == BF16 and self.Vt.stride(2) == 1 and self.Vt.shape[1] == N - self.vt_from
+                 and self.Vt.shape[0] * self.vt_T == M and self.Vt.shape[2] >= self.vt_T, f"gemm {self.name}: Vt shape {tuple(self.Vt.shape)}")
+        else:
+            _chk(No == (N // 2 if self.epilogue == L.EPI_GEGLU else N), f"gemm {self.name}: C has {No} cols for N={N}")
         _chk(A.dtype == BF16 and W.dtype == BF16 and Cm.dtype in (BF16, F32), f"gemm {self.name}: dtypes")
         d = L.MdxGemmDesc()
         d.A, d.W, d.C = _p(A), _p(W), _p(C2)
@@ -109,6 +120,9 @@ class Gemm:
         d.batch, d.sA, d.sW, d.sC, d.sR = batch, sA, sW, sC, sR
         d.temb_sel_stride, d.temb_b_stride, d.rows_per_b = self.temb_sel_stride, self.temb_b_stride, self.rows_per_b
         d.epilogue, d.splitk, d.c_is_f32 = self.epilogue, self.splitk, int(Cm.dtype == F32)
+        if self.Vt is not None:
+            d.Vt = _p(self.Vt)
+            d.vt_from, d.vt_T, d.vt_ld, d.vt_stride = self.vt_from, self.vt_T, self.Vt.stride(1), self.Vt.stride(0)
         return self.opcode, d
 
 

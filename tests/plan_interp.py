@@ -43,6 +43,11 @@ def run_gemm(op: O.Gemm):
         raw = (r[..., 0, :] * F.gelu(r[..., 1, :])).reshape(*raw.shape[:-1], N // 2)
     elif op.epilogue == L.EPI_SILU:
         raw = F.silu(raw)
+    if op.Vt is not None:                     # fused q/k/v: columns >= vt_from go transposed to Vt[view][channel][token]
+        Bv, Cv = op.Vt.shape[0], op.Vt.shape[1]
+        v = raw[:, op.vt_from:].reshape(Bv, op.vt_T, Cv).transpose(1, 2)
+        op.Vt[:, :, :op.vt_T].copy_(v.to(op.Vt.dtype))
+        raw = raw[:, :op.vt_from]
     if op.R is not None:
         raw = raw + op.R.float()
     C.copy_(raw.to(C.dtype))

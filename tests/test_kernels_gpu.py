@@ -85,6 +85,24 @@ def test_gemm_weight_stationary(dev, M, N, res, inplace):
     assert torch.isnan(Cbig[:, :8].float()).all() and torch.isnan(Cbig[:, 8 + N:].float()).all(), "wrote outside the C view"
 
 
+@pytest.mark.parametrize("Bv,T", [(6, 1400), (7, 1176)])
+def test_gemm_fused_qkv_transposed_v(dev, Bv, T):
+    """Fused q/k/v projection (MdxGemmDesc.Vt): columns [0, 2C) to C row-major, columns [2C, 3C) transposed to V^T[view][channel][token]
+    — what the attention kernel consumes; ragged last M tile, views that do not align with the 128-row tiles."""
+    Cc = 320
+    M = Bv * T
+    X = rnd(M, Cc, seed=1); W = rnd(3 * Cc, Cc, scale=Cc ** -0.5, seed=2)
+    qk = torch.full((M, 2 * Cc), float("nan"), dtype=BF, device=dev)
+    Vt = torch.full((Bv, Cc, T), float("nan"), dtype=BF, device=dev)
+    O.run_ops([O.Gemm(X, W, qk, Vt=Vt, vt_from=2 * Cc, vt_T=T)])
+    torch.cuda.synchronize()
+    ref = X.float().cpu() @ W.float().cpu().T
+    close(qk, ref[:, :2 * Cc], name="fused qk")
+    close(Vt, ref[:, 2 * Cc:].reshape(Bv, T, Cc).transpose(1, 2), name="fused V^T")
+    with pytest.raises(L.MdxError):          # not expressible outside the weight-stationary kernel: loud, no fallback
+        O.run_ops([O.Gemm(rnd(M, 640, seed=3), rnd(3 * Cc, 640, seed=4), qk, Vt=Vt, vt_from=2 * Cc, vt_T=T)])
+
+
 def test_gemm_weight_stationary_geglu_ragged(dev):
     M, F_, K = 8250, 320, 320
     A = rnd(M, K, seed=1); W = rnd(2 * F_, K, scale=K ** -0.5, seed=2, dtype=torch.float32, dev="cpu")

@@ -95,6 +95,20 @@ def test_unipc_sampler_plan_matches_golden_pipeline(tiny):
     assert sp.step_ctr.item() == 0 and not sp.m1.any() and not sp.x_last.any()
 
 
+def test_fused_qkv_op_equals_separate_projections():
+    """The level-0 fused q/k/v op (engine.self_like_attention) in the CPU interpreter == the q/k GEMM + batched V^T GEMM it replaces."""
+    import magicdrive_amd.ops as O
+    g = torch.Generator().manual_seed(0)
+    Bv, T, C = 3, 16, 32
+    x = torch.randn(Bv * T, C, generator=g).to(torch.bfloat16)
+    w = (torch.randn(3 * C, C, generator=g) * C ** -0.5).to(torch.bfloat16)
+    qk1 = torch.zeros(Bv * T, 2 * C, dtype=torch.bfloat16); vt1 = torch.zeros(Bv, C, T, dtype=torch.bfloat16)
+    qk2 = torch.zeros_like(qk1); vt2 = torch.zeros_like(vt1)
+    plan_interp.run([O.Gemm(x, w, qk1, Vt=vt1, vt_from=2 * C, vt_T=T)], lower_check=False)
+    plan_interp.run([O.Gemm(x, w[:2 * C], qk2), O.Gemm(w[2 * C:], x.view(Bv, T, C), vt2)], lower_check=False)
+    assert torch.equal(qk1, qk2) and torch.equal(vt1, vt2)
+
+
 def test_step_program_work_is_deduplicated():
     """SURVEY.md §8d: F_step(224x400, L=32, c=1) ~= 2.325 TF after removing the reference's redundant work;
     folding connector o attn4.to_out into one matrix (engine.py) removes a further 16 C x C GEMMs = 0.027 TF."""
