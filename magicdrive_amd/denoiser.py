@@ -18,6 +18,7 @@ import torch
 from . import _lib as L
 from . import ops as O
 from . import packing as PK
+from .networks import spec
 from .engine import Act, Builder, PackedNet, TembTable, build_context_kv, level_sizes
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -98,16 +99,23 @@ class ConditioningBuffers:
         nblk = 0
         while cn.has(f"{pre}blocks.{nblk}.weight"):
             nblk += 1
-        for i in range(nblk):                               # map_embedder.py:36-56
-            if i < nblk - 2:
-                layers.append((f"{pre}blocks.{i}.", (1, 1), (1, 1), True) if i % 2 == 0 else (f"{pre}blocks.{i}.", (2, 2), (2, 1), True))
-            elif i == nblk - 2:
-                layers.append((f"{pre}blocks.{i}.", (1, 1), (2, 1), True))
-            else:
-                layers.append((f"{pre}blocks.{i}.", (2, 1), (2, 1), True))
+        plus = spec.map_embedder_plus_size(cfg)
+        for i in range(nblk):
+            if plus is None:                                # BEVControlNetConditioningEmbedding, map_embedder.py:36-56
+                if i < nblk - 2:
+                    layers.append((f"{pre}blocks.{i}.", (1, 1), (1, 1), True) if i % 2 == 0 else (f"{pre}blocks.{i}.", (2, 2), (2, 1), True))
+                elif i == nblk - 2:
+                    layers.append((f"{pre}blocks.{i}.", (1, 1), (2, 1), True))
+                else:
+                    layers.append((f"{pre}blocks.{i}.", (2, 1), (2, 1), True))
+            else:                                           # ...Plus, map_embedder.py:94-117: pad 1 everywhere; strides 1,1 | 1,2 | 1,(2,1)
+                stride = (1, 1) if i % 2 == 0 else ((2, 1) if i == nblk - 1 else ((1, 1) if i == 1 else (2, 2)))
+                layers.append((f"{pre}blocks.{i}.", stride, (1, 1), True))
         layers.append((pre + "conv_out.", (1, 1), (1, 1), False))
         keep = [x]
         for key, stride, pad, act in layers:
+            if plus is not None and key == pre + "conv_out.":
+                x = self._adaptive_avg_pool_silu(bld, x, plus, keep)      # blocks[-1] = AdaptiveAvgPool2d, then SiLU (map_embedder.py:117, :71-73)
             wt = cn.conv(key + "weight")
             Hi, Wi = x.shape[1], x.shape[2]
             Ho = (Hi + 2 * pad[0] - 3) // stride[0] + 1
@@ -118,13 +126,39 @@ class ConditioningBuffers:
             keep.append(y)
             x = y
         if (x.shape[1], x.shape[2]) != (h, w):
-            raise ValueError(f"map encoder output {tuple(x.shape[1:3])} != latent size {(h, w)} (needs the ...Plus embedder, SURVEY.md §8f)")
+            raise ValueError(f"map encoder output {tuple(x.shape[1:3])} != latent size {(h, w)}: select BEVControlNetConditioningEmbeddingPlus with "
+                             f"conditioning_embedding_size={[h, w]} (configs/exp/272x736.yaml:15-22; spec.with_plus_map_embedder)")
         C0 = x.shape[3]
         self.map_rep = torch.empty(B, h, w, C0, dtype=BF16, device=dev)
         for s in range(n_scene):
             for c in range(n_cam):
                 bld.emit(O.Ew(L.EW_COPY, x[s].view(h * w, C0), self.map_rep[s * n_cam + c].view(h * w, C0), name="map.repeat"))
         self._keep_map = keep
+
+    @staticmethod
+    def _adaptive_avg_pool_silu(bld, x, out_hw, keep):
+        """SiLU(AdaptiveAvgPool2d(out_hw)(x)) for channels-last x [n, Hi, Wi, C] on the existing kernels (runs once per scene, in the
+        prologue): the pooling is a fixed linear map over pixels, so it is ONE batched GEMM  out[n] = P @ x[n]  with the
+        [Ho*Wo, Hi*Wi] matrix of window weights (torch's windows: start = floor(o*I/O), end = ceil((o+1)*I/O)) and the SiLU epilogue;
+        the GEMM wants its second operand K-contiguous, i.e. x as [C, Hi*Wi] = NCHW, hence the layout op.  Weights 1/count are bf16:
+        exact for counts 1, 2, 4 (every window of the 432x768 case), 2^-9 relative otherwise."""
+        n, Hi, Wi, C = x.shape
+        Ho, Wo = out_hw
+        dev = x.device
+
+        def windows(I, Oo):
+            m = torch.zeros(Oo, I, dtype=torch.float64)
+            for o in range(Oo):
+                a, b = (o * I) // Oo, -((-(o + 1) * I) // Oo)
+                m[o, a:b] = 1.0 / (b - a)
+            return m
+        P = torch.kron(windows(Hi, Ho), windows(Wi, Wo)).to(BF16).to(dev)              # [(oy,ox), (iy,ix)]
+        xn = torch.empty(n, C, Hi, Wi, dtype=BF16, device=dev)
+        bld.emit(O.Layout(x, xn, False, name="map.pool.nchw"))
+        y = torch.empty(n, Ho, Wo, C, dtype=BF16, device=dev)
+        bld.emit(O.Gemm(P, xn.view(n, C, Hi * Wi), y.view(n, Ho * Wo, C), epilogue=L.EPI_SILU, ws=bld.ws, name="map.pool"))
+        keep += [P, xn, y]
+        return y
 
     # ---- input marshalling (torch: dtype / layout of user tensors only) ----
     def load(self, camera_param: torch.Tensor, text: torch.Tensor, bev_map: torch.Tensor, boxes: Optional[Dict[str, torch.Tensor]]):

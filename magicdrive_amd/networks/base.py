@@ -49,6 +49,14 @@ def arch_config_from_json(js: Dict, base: Optional[Dict] = None) -> Dict:
     for k in ("camera_in_dim", "camera_out_dim", "map_size", "conditioning_embedding_out_channels", "uncond_cam_in_dim"):
         if k in js and js[k] is not None:
             cn[k] = tuple(js[k]) if isinstance(js[k], list) else js[k]
+    if js.get("map_embedder_cls"):          # configs/exp/272x736.yaml:15-22 (BEVControlNetConditioningEmbeddingPlus)
+        mp = js.get("map_embedder_param") or {}
+        cn["map_embedder_cls"] = js["map_embedder_cls"]
+        cn["map_embedder_param"] = {k: tuple(v) for k, v in mp.items()}
+        if "conditioning_size" in mp:
+            cn["map_size"] = tuple(mp["conditioning_size"])
+        if "block_out_channels" in mp:
+            cn["conditioning_embedding_out_channels"] = tuple(mp["block_out_channels"])
     if "cam_embedder_param" in js and js["cam_embedder_param"]:
         cn["cam_embedder_num_freqs"] = js["cam_embedder_param"].get("num_freqs", cn["cam_embedder_num_freqs"])
     if "bbox_embedder_param" in js and js["bbox_embedder_param"]:

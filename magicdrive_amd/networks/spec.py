@@ -42,6 +42,31 @@ TINY_CONFIG["controlnet"].update(camera_out_dim=64, conditioning_embedding_out_c
 TINY_CONFIG["controlnet"]["bbox"].update(class_token_dim=64, proj_dims=(64, 48, 48, 64))
 
 
+PLUS_MAP_EMBEDDER = "magicdrive.networks.map_embedder.BEVControlNetConditioningEmbeddingPlus"   # configs/exp/272x736.yaml:18
+
+
+def map_embedder_plus_size(cfg):
+    """None for the default BEVControlNetConditioningEmbedding; (h, w) of the AdaptiveAvgPool2d target when the config selects
+    BEVControlNetConditioningEmbeddingPlus (map_embedder_cls / map_embedder_param, unet_addon_rawbox.py:172-184)."""
+    cn = cfg["controlnet"]
+    cls = cn.get("map_embedder_cls")
+    if not cls:
+        return None
+    if not str(cls).endswith("BEVControlNetConditioningEmbeddingPlus"):
+        raise NotImplementedError(f"map_embedder_cls={cls!r}: only the two embedders of magicdrive/networks/map_embedder.py are built")
+    return tuple(cn["map_embedder_param"]["conditioning_embedding_size"])
+
+
+def with_plus_map_embedder(cfg, size):
+    """A copy of cfg that selects the ...Plus map encoder for latent size `size` (what configs/exp/272x736.yaml:15-22 does)."""
+    c = copy.deepcopy(cfg)
+    cn = c["controlnet"]
+    cn["map_embedder_cls"] = PLUS_MAP_EMBEDDER
+    cn["map_embedder_param"] = dict(conditioning_embedding_size=tuple(size), conditioning_size=tuple(cn["map_size"]),
+                                    block_out_channels=tuple(cn["conditioning_embedding_out_channels"]))
+    return c
+
+
 def heads_at(cfg, level: int) -> int:
     h = cfg["attention_head_dim"]       # NUMBER of heads (diffusers 0.17 naming quirk, unet_2d_blocks.py:842-844)
     return h[level] if isinstance(h, (tuple, list)) else h

@@ -28,6 +28,8 @@ class BEVControlNetModel(MdxModel):
                   cam_embedder_param=dict(input_dims=3, num_freqs=cn["cam_embedder_num_freqs"], include_input=True, log_sampling=True),
                   bbox_embedder_param=dict(n_classes=cn["bbox"]["n_classes"], class_token_dim=cn["bbox"]["class_token_dim"],
                                            embedder_num_freq=cn["bbox"]["embedder_num_freq"], proj_dims=list(cn["bbox"]["proj_dims"])))
+        if cn.get("map_embedder_cls"):
+            js.update(map_embedder_cls=cn["map_embedder_cls"], map_embedder_param={k: list(v) for k, v in cn["map_embedder_param"].items()})
 
     @property
     def uncond_cam_num(self) -> int:

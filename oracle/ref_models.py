@@ -18,8 +18,14 @@ def build_reference(cfg, unet_sd, cn_sd, img_size=(224, 400)):
         base, neighboring_view_pair=cfg["neighboring_view_pair"], neighboring_attn_type="add",
         zero_module_type="zero_linear", img_size=list(img_size))
     cn = cfg["controlnet"]; bb = cn["bbox"]
+    extra = {}
+    if cn.get("map_embedder_cls"):          # configs/exp/272x736.yaml:15-22
+        mp = cn["map_embedder_param"]
+        extra = dict(map_embedder_cls=cn["map_embedder_cls"],
+                     map_embedder_param=dict(conditioning_embedding_size=list(mp["conditioning_embedding_size"]),
+                                             conditioning_size=list(mp["conditioning_size"]), block_out_channels=list(mp["block_out_channels"])))
     cnet = ns.controlnet.BEVControlNetModel.from_unet(
-        base, camera_in_dim=cn["camera_in_dim"], camera_out_dim=cn["camera_out_dim"], map_size=list(cn["map_size"]),
+        base, **extra, camera_in_dim=cn["camera_in_dim"], camera_out_dim=cn["camera_out_dim"], map_size=list(cn["map_size"]),
         conditioning_embedding_out_channels=cn["conditioning_embedding_out_channels"],
         uncond_cam_in_dim=cn["uncond_cam_in_dim"], use_uncond_map=None, drop_cond_ratio=0.25, drop_cam_num=6,
         drop_cam_with_box=False,

@@ -182,6 +182,30 @@ def test_module_api_forward(dev):
     assert max(rel_l2(eps[i], G["eps"][i]) for i in range(12)) < 4e-2
 
 
+def test_module_api_forward_hires_plus_map_encoder(dev):
+    """BASELINE.json configs[3] shape on the GPU: 432x768 (54x96 latents, T0 = 5184 tokens) with the ...Plus map encoder, through the
+    reference module signatures, vs outputs of the REAL reference modules (tests/golden/tiny_forward_hires.pt)."""
+    import os
+    from magicdrive_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiview
+    from magicdrive_amd.networks.unet_addon_rawbox import BEVControlNetModel
+    G = torch.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_forward_hires.pt"))
+    hw = tuple(G["hw"])
+    cfg = spec.with_plus_map_embedder(spec.TINY_CONFIG, hw)
+    unet = UNet2DConditionModelMultiview.from_config(cfg, 0).to(dev); cn = BEVControlNetModel.from_config(cfg, 1).to(dev)
+    sc = scene(cfg, 1, 3, hw)
+    lat = torch.randn(1, 6, 4, *hw, generator=torch.Generator().manual_seed(G["lat_seed"]))
+    t = G["timesteps"]
+    down, mid, ctx = cn(lat.to(dev), t.to(dev), sc["camera_param"].to(dev), {k: v.to(dev) for k, v in sc["bboxes_3d_data"].items()},
+                        sc["prompt_embeds"].to(dev), sc["bev_map"].to(dev), return_dict=False)
+    assert rel_l2(mid, G["mid"]) < 3e-2 and rel_l2(down[0][:, :, ::9, ::12], G["down_first"]) < 3e-2
+    eps = unet(lat.reshape(-1, 4, *hw).to(dev), t.repeat_interleave(6).to(dev), encoder_hidden_states=ctx,
+               down_block_additional_residuals=down, mid_block_additional_residual=mid).sample
+    torch.cuda.synchronize()
+    e = max(rel_l2(eps[i], G["eps"][i].float()) for i in range(6))
+    print(f"[hires 54x96 + Plus map encoder vs reference golden] eps per-view max rel {e:.4f}")
+    assert e < 4e-2
+
+
 def test_real_size_ddim_loop_sd15(dev):
     """SD-1.5-size sampler loop (the bench workload: text-only, camera_param=None => CFG off) through the drop-in
     pipeline vs the CPU oracle on the same bf16-rounded weights.  6 DDIM steps by default (CPU oracle ~5 s/step);

@@ -80,6 +80,19 @@ def test_checkpoint_layout_roundtrip(tmp_path):
     assert u2.config.in_channels == 4 and u2.dtype == torch.bfloat16
 
 
+def test_plus_map_embedder_config_roundtrip(tmp_path):
+    """configs/exp/272x736.yaml:15-22 (map_embedder_cls / map_embedder_param) survives save_pretrained -> from_pretrained."""
+    cfg = spec.with_plus_map_embedder(spec.TINY_CONFIG, (34, 92))
+    c = BEVControlNetModel.from_config(cfg, seed=1)
+    c.save_pretrained(str(tmp_path / "controlnet"))
+    c2 = BEVControlNetModel.from_pretrained(str(tmp_path / "controlnet"))
+    assert spec.map_embedder_plus_size(c2.cfg) == (34, 92) and c2.cfg["controlnet"]["map_size"] == (8, 200, 200)
+    assert spec.map_embedder_plus_size(spec.TINY_CONFIG) is None
+    bad = spec.with_plus_map_embedder(spec.TINY_CONFIG, (34, 92)); bad["controlnet"]["map_embedder_cls"] = "some.other.Embedder"
+    with pytest.raises(NotImplementedError):
+        spec.map_embedder_plus_size(bad)
+
+
 def test_state_dict_validation():
     cfg = spec.TINY_CONFIG
     usd, _ = state_dicts(cfg)

@@ -189,6 +189,24 @@ def test_golden_pipeline_unipc(tiny):
     assert rel_l2(out, G["latents_cfg"]) < 2e-4, rel_l2(out, G["latents_cfg"])
 
 
+def test_golden_forward_hires_plus_map_encoder(tiny):
+    """BASELINE.json configs[3] shape (432x768 -> 54x96 latents, BEVControlNetConditioningEmbeddingPlus): the oracle vs the real
+    reference modules (tests/golden/tiny_forward_hires.pt, tools/make_golden.py hires)."""
+    cfg0, usd, csd = tiny
+    G = torch.load(os.path.join(GOLD, "tiny_forward_hires.pt"))
+    hw = tuple(G["hw"])
+    cfg = spec.with_plus_map_embedder(cfg0, hw)
+    sc = scene(cfg, 1, 3, hw)
+    lat = torch.randn(1, 6, 4, *hw, generator=torch.Generator().manual_seed(G["lat_seed"]))
+    t = G["timesteps"]
+    with torch.no_grad():
+        d, m, ctx = D.controlnet_forward(csd, cfg, lat, t, sc["camera_param"], sc["bboxes_3d_data"], sc["prompt_embeds"], sc["bev_map"])
+        e = D.unet_forward(usd, cfg, lat.reshape(-1, 4, *hw), t.repeat_interleave(6), ctx, d, m)
+    assert rel_l2(m, G["mid"]) < 1e-4 and torch.allclose(torch.tensor([x.abs().mean() for x in d]), G["down_absmean"], rtol=1e-4)
+    assert rel_l2(d[0][:, :, ::9, ::12], G["down_first"]) < 1e-4
+    assert rel_l2(e, G["eps"].float()) < 2e-3          # golden eps stored as fp16
+
+
 # ---------------------------------------------------------------- live reference (authoring container only)
 needs_ref = pytest.mark.skipif(not refshim.available(), reason="/root/reference not present")
 

@@ -95,6 +95,36 @@ def test_unipc_sampler_plan_matches_golden_pipeline(tiny):
     assert sp.step_ctr.item() == 0 and not sp.m1.any() and not sp.x_last.any()
 
 
+def test_module_plans_hires_plus_map_encoder(tiny):
+    """configs[3] shape: 54x96 latents + the ...Plus map encoder (adaptive average pool as one GEMM over pixels) through the op
+    graphs vs the real reference's outputs."""
+    cfg0, usd, csd, un, cn = tiny
+    G = torch.load(os.path.join(GOLD, "tiny_forward_hires.pt"))
+    hw = tuple(G["hw"])
+    cfg = spec.with_plus_map_embedder(cfg0, hw)
+    sc = scene(cfg, 1, 3, hw)
+    lat = torch.randn(1, 6, 4, *hw, generator=torch.Generator().manual_seed(G["lat_seed"]))
+    t = G["timesteps"]
+    cp = DN.ControlNetPlan(cfg, cn, CPU, 1, 3, hw)
+    cp.sample_nchw.copy_(lat.reshape(-1, 4, *hw)); cp.temb.t.copy_(t.float().repeat_interleave(6))
+    cp.cond.load(sc["camera_param"], sc["prompt_embeds"], sc["bev_map"], sc["bboxes_3d_data"])
+    plan_interp.run(cp.ops)
+    assert rel_l2(cp.mid_out, G["mid"]) < 3e-2
+    assert rel_l2(cp.down_out[0][:, :, ::9, ::12], G["down_first"]) < 3e-2      # carries the map feature (added after conv_in)
+    with torch.no_grad():
+        d, m, ctx = D.controlnet_forward(csd, cfg, lat, t, sc["camera_param"], sc["bboxes_3d_data"], sc["prompt_embeds"], sc["bev_map"])
+    up = DN.UNetPlan(cfg, un, CPU, 6, ctx.shape[1], hw)
+    up.sample_nchw.copy_(lat.reshape(-1, 4, *hw)); up.temb.t.copy_(t.float().repeat_interleave(6)); up.ctx.copy_(ctx)
+    for dst, src in zip(up.res_in, d):
+        dst.copy_(src)
+    up.mid_in.copy_(m)
+    plan_interp.run(up.ops)
+    per_view = max(rel_l2(up.out_nchw[i], G["eps"][i].float()) for i in range(6))
+    assert per_view < 3e-2, per_view
+    with pytest.raises(ValueError):          # the default encoder cannot produce a 54x96 feature: loud, with the config hint
+        DN.ControlNetPlan(cfg0, cn, CPU, 1, 3, hw)
+
+
 def test_fused_qkv_op_equals_separate_projections():
     """The level-0 fused q/k/v op (engine.self_like_attention) in the CPU interpreter == the q/k GEMM + batched V^T GEMM it replaces."""
     import magicdrive_amd.ops as O

@@ -14,7 +14,11 @@ Fixtures
   tiny_pipeline_unipc.pt  the same call with the scheduler tools/test.py really installs (UniPCMultistepScheduler,
                     magicdrive/misc/test_utils.py:129), 6 steps (warm-up, order-2 and lower-order-final steps all occur).
 
-`python tools/make_golden.py unipc` regenerates only the last fixture.
+  tiny_forward_hires.pt  BASELINE.json configs[3] shape: 432x768 images = 54x96 latents with the
+                    BEVControlNetConditioningEmbeddingPlus map encoder (configs/exp/272x736.yaml:15-22 with size [54, 96]);
+                    reference BEVControlNetModel.forward + UNet2DConditionModelMultiview.forward, 1 scene x 6 views, 3 boxes/view.
+
+`python tools/make_golden.py unipc` / `... hires` regenerate only that fixture.
 """
 import os
 import sys
@@ -46,6 +50,23 @@ def unipc_fixture(out_dir, cfg, usd, csd, meta, hw=(28, 50)):
     print("tiny_pipeline_unipc: |x|", out.abs().mean().item())
 
 
+def hires_fixture(out_dir, cfg0, usd, csd, meta, hw=(54, 96)):
+    cfg = spec.with_plus_map_embedder(cfg0, hw)
+    ns, unet, cnet = ref_models.build_reference(cfg, usd, csd, img_size=(hw[0] * 8, hw[1] * 8))
+    sc = scene(cfg, 1, 3, hw)
+    g = torch.Generator().manual_seed(11)
+    lat = torch.randn(1, 6, 4, *hw, generator=g)
+    t = torch.tensor([741])
+    with torch.no_grad():
+        d, m, ctx = cnet(lat, t, sc["camera_param"], sc["bboxes_3d_data"], sc["prompt_embeds"], sc["bev_map"], return_dict=False)
+        e = unet(lat.reshape(-1, 4, *hw), t.repeat_interleave(6), encoder_hidden_states=ctx,
+                 down_block_additional_residuals=d, mid_block_additional_residual=m).sample
+    torch.save({"meta": meta, "lat_seed": 11, "timesteps": t, "hw": hw, "mid": m.clone(), "eps": e.half(),
+                "down_absmean": torch.tensor([x.abs().mean() for x in d]), "down_first": d[0][:, :, ::9, ::12].clone()},
+               os.path.join(out_dir, "tiny_forward_hires.pt"))
+    print("tiny_forward_hires: eps std", e.std().item(), "down0 |x|", d[0].abs().mean().item())
+
+
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
@@ -54,6 +75,8 @@ def main():
     meta = {"unet_checksum": checksum(usd), "cn_checksum": checksum(csd), "torch": str(torch.__version__)}
     if sys.argv[1:] == ["unipc"]:
         return unipc_fixture(out_dir, cfg, usd, csd, meta)
+    if sys.argv[1:] == ["hires"]:
+        return hires_fixture(out_dir, cfg, usd, csd, meta)
 
     # ---- module-level forwards
     ns, unet, cnet = ref_models.build_reference(cfg, usd, csd)
@@ -87,6 +110,7 @@ def main():
                os.path.join(out_dir, "tiny_pipeline.pt"))
     print("tiny_pipeline: |x|", out.abs().mean().item(), out_nocam.abs().mean().item())
     unipc_fixture(out_dir, cfg, usd, csd, meta, hw)
+    hires_fixture(out_dir, cfg, usd, csd, meta)
     for f in os.listdir(out_dir):
         print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")
 
