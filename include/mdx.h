@@ -42,7 +42,7 @@ extern "C" {
 #define MDX_ELAUNCH (-2)     /* hip launch / runtime error */
 #define MDX_EUNSUPPORTED (-3)
 
-#define MDX_ABI_VERSION 2
+#define MDX_ABI_VERSION 3
 
 /* ---- epilogue flags shared by GEMM / conv ------------------------------- */
 #define MDX_EPI_NONE 0
@@ -242,6 +242,16 @@ typedef struct MdxDdimDesc {
     int64_t n, cfg;
     double guidance;
     int64_t xin_c, xin_ld;
+    /* Given views (StableDiffusionBEVControlNetGivenViewPipeline, magicdrive/pipeline/pipeline_bev_controlnet_given_view.py:263-291,
+     * :380-390): gv_mask[i / gv_view_elems] != 0 marks the views whose clean latents gv_cond are known; gv_noise is the initial
+     * noise of every view (same layout as x).
+     *   gv_mode 1 (conditional_latents_change_every_input): after the update of step s < gv_last_step a given view is replaced by
+     *     add_noise(cond, noise, next timestep) = coef[s][2] * cond + coef[s][3] * noise (what the reference does at the top of
+     *     the next iteration); the last step's output is kept.
+     *   gv_mode 2: the combined noise prediction of a given view is replaced by gv_noise before the update.
+     *   gv_mode 0 / gv_mask NULL: off. */
+    const float* gv_cond; const float* gv_noise; const uint8_t* gv_mask;
+    int64_t gv_mode, gv_view_elems, gv_last_step;
 } MdxDdimDesc;
 int mdx_cfg_ddim_step(const MdxDdimDesc* d, void* stream);
 

@@ -13,7 +13,7 @@ from typing import Dict, List, Tuple
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmdx.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # opcodes (mdx.h)
 OP_GEMM, OP_CONV, OP_CONV_DIRECT, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM = 1, 2, 3, 4, 5, 6
@@ -48,7 +48,8 @@ MdxEwDesc = _struct("MdxEwDesc", _f(P, "X Y ymap xmap") + _f(I, "kind M C ldx ld
 MdxFourierDesc = _struct("MdxFourierDesc", _f(P, "X Y mask null_feat") + _f(I, "n P F ldy"))
 MdxGatherDesc = _struct("MdxGatherDesc", _f(P, "T Y idx mask null_row reserved_p") + _f(I, "n C ldt ldy n_rows reserved0"))
 MdxTimeEmbDesc = _struct("MdxTimeEmbDesc", _f(P, "t Y") + _f(I, "n dim flip_sin_to_cos ldy") + _f(D, "freq_shift max_period"))
-MdxDdimDesc = _struct("MdxDdimDesc", _f(P, "x eps coef step_ptr x_in reserved_p") + _f(I, "n cfg") + _f(D, "guidance") + _f(I, "xin_c xin_ld"))
+MdxDdimDesc = _struct("MdxDdimDesc", _f(P, "x eps coef step_ptr x_in reserved_p") + _f(I, "n cfg") + _f(D, "guidance") + _f(I, "xin_c xin_ld")
+                      + _f(P, "gv_cond gv_noise gv_mask") + _f(I, "gv_mode gv_view_elems gv_last_step"))
 MdxUniPCDesc = _struct("MdxUniPCDesc", _f(P, "x eps coef step_ptr x_in x_last m1 m2") + _f(I, "n cfg") + _f(D, "guidance") + _f(I, "xin_c xin_ld"))
 
 DESC_OF_OP = {

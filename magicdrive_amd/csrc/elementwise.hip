@@ -282,7 +282,8 @@ __global__ __launch_bounds__(256) void timeemb_kernel(TimeEmbParams p) {
     if (p.y_f32) ((float*)p.Y)[i * p.ldy + j] = out; else ((bf16_t*)p.Y)[i * p.ldy + j] = f2bf(out);
 }
 
-struct DdimParams { float* x; const float* eps; const float* coef; int* step; void* x_in; long n; int cfg; float g; int xin_c, xin_ld; };
+struct DdimParams { float* x; const float* eps; const float* coef; int* step; void* x_in; long n; int cfg; float g; int xin_c, xin_ld;
+                    const float* gv_cond; const float* gv_noise; const unsigned char* gv_mask; int gv_mode; long gv_view; int gv_last; };
 
 __global__ __launch_bounds__(256) void ddim_kernel(DdimParams p) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -296,9 +297,13 @@ __global__ __launch_bounds__(256) void ddim_kernel(DdimParams p) {
         } else {
             e = p.eps[i];
         }
+        // given views (pipeline_bev_controlnet_given_view.py:263-291, 380-390; include/mdx.h: MdxDdimDesc.gv_*)
+        const bool given = p.gv_mode != 0 && p.gv_mask[i / p.gv_view] != 0;
+        if (given && p.gv_mode == 2) e = p.gv_noise[i];
         float x = p.x[i];
         float x0 = (x - c[1] * e) / c[0];
         float xn = c[2] * x0 + c[3] * e;
+        if (given && p.gv_mode == 1 && step < p.gv_last) xn = c[2] * p.gv_cond[i] + c[3] * p.gv_noise[i];
         p.x[i] = xn;
         if (p.x_in) {
             if (p.xin_ld > 0) {          // bf16 channels-last copy with padded pixel stride
@@ -447,8 +452,11 @@ extern "C" int mdx_timestep_embedding(const MdxTimeEmbDesc* d, void* stream) {
 
 extern "C" int mdx_cfg_ddim_step(const MdxDdimDesc* d, void* stream) {
     if (!d || !d->x || !d->eps || !d->coef || !d->step_ptr) return set_error(MDX_EINVAL, "mdx_cfg_ddim_step: null operand");
-    DdimParams p{d->x, d->eps, d->coef, d->step_ptr, d->x_in, d->n, (int)d->cfg, (float)d->guidance, (int)d->xin_c, (int)d->xin_ld};
+    DdimParams p{d->x, d->eps, d->coef, d->step_ptr, d->x_in, d->n, (int)d->cfg, (float)d->guidance, (int)d->xin_c, (int)d->xin_ld,
+                 d->gv_cond, d->gv_noise, d->gv_mask, d->gv_mask ? (int)d->gv_mode : 0, d->gv_view_elems, (int)d->gv_last_step};
     if (p.xin_ld > 0 && (p.xin_c <= 0 || p.xin_ld < p.xin_c || p.n % p.xin_c)) return set_error(MDX_EINVAL, "ddim: bad x_in channel layout");
+    if (p.gv_mode != 0 && (p.gv_mode < 0 || p.gv_mode > 2 || !p.gv_noise || (p.gv_mode == 1 && !p.gv_cond) || p.gv_view <= 0 || p.n % p.gv_view))
+        return set_error(MDX_EINVAL, "ddim: given-view mode %d needs gv_noise (+ gv_cond for mode 1) and gv_view_elems dividing n", p.gv_mode);
     if (p.n <= 0) return MDX_OK;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(ddim_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);

@@ -200,10 +200,12 @@ class SamplerPlan:
 
     def __init__(self, cfg, unet: PackedNet, cn: PackedNet, device, b: int, do_cfg: bool, L_box: int, latent_hw=(28, 50),
                  num_steps: int = 50, guidance_scale: float = 2.0, conditioning_scale: float = 1.0, n_text: int = 77,
-                 scheduler_kind: str = "ddim"):
+                 scheduler_kind: str = "ddim", given_view_mode: int = 0):
         self.cfg, self.device = cfg, device
         assert scheduler_kind in ("ddim", "unipc")
+        assert given_view_mode in (0, 1, 2) and (given_view_mode == 0 or scheduler_kind == "ddim"), "given views: fused for DDIM only"
         self.scheduler_kind = scheduler_kind
+        self.given_view_mode = given_view_mode
         n_cam = len(cfg["neighboring_view_pair"])
         self.b, self.n_cam, self.c = b, n_cam, (2 if do_cfg else 1)
         self.do_cfg = do_cfg
@@ -223,6 +225,10 @@ class SamplerPlan:
         if scheduler_kind == "unipc":       # multistep history of the fused UniPC update (scheduling_unipc_multistep.py:518-600)
             self.x_last = torch.zeros_like(self.x); self.m1 = torch.zeros_like(self.x); self.m2 = torch.zeros_like(self.x)
         self.step_ctr = torch.zeros(1, dtype=torch.int32, device=device)
+        if given_view_mode:       # pipeline_bev_controlnet_given_view.py: known clean latents of some views + every view's initial noise
+            self.gv_mask = torch.zeros(b * n_cam, dtype=torch.uint8, device=device)
+            self.gv_cond = torch.zeros_like(self.x)
+            self.gv_noise = torch.zeros_like(self.x)
         # ---------------- prologue ----------------
         self.cond = ConditioningBuffers(bld, cn, cfg, self.c * b, n_cam, L_box, latent_hw, n_text)
         self.temb_cn = TembTable(cn, num_steps, device, per_sample=False)
@@ -256,8 +262,12 @@ class SamplerPlan:
         bld.emit(O.Conv(y.bhwc, unet.conv("conv_out.weight"), self.eps, bias=unet.vec("conv_out.bias"), direct=True, name="unet.conv_out"))
         bld.free(y)
         if scheduler_kind == "ddim":
+            gv = {}
+            if given_view_mode:
+                gv = dict(gv_mask=self.gv_mask, gv_cond=self.gv_cond.view(-1), gv_noise=self.gv_noise.view(-1), gv_mode=given_view_mode,
+                          gv_last_step=num_steps - 1)
             bld.emit(O.DdimStep(self.x.view(-1), self.eps.view(-1), self.coef, self.step_ctr, x_in=self.x_in.view(-1, CIN_PAD), cfg=do_cfg,
-                                guidance=guidance_scale, xin_c=Cl, name="cfg+ddim"))
+                                guidance=guidance_scale, xin_c=Cl, name="cfg+ddim", **gv))
         else:
             bld.emit(O.UniPCStep(self.x.view(-1), self.eps.view(-1), self.coef, self.step_ctr, self.x_last.view(-1), self.m1.view(-1),
                                  self.m2.view(-1), x_in=self.x_in.view(-1, CIN_PAD), cfg=do_cfg, guidance=guidance_scale, xin_c=Cl, name="cfg+unipc"))
@@ -271,11 +281,23 @@ class SamplerPlan:
         self.step = O.build_program(self.step_ops)
 
     # ---- per-call inputs ----
-    def load_inputs(self, latents: torch.Tensor, camera_param, text, bev_map, boxes, timesteps: torch.Tensor, coef: torch.Tensor):
-        """latents (b, n_cam, C, h, w) any float dtype; camera/text/map/boxes already hold the [uncond | cond] halves."""
+    def load_inputs(self, latents: torch.Tensor, camera_param, text, bev_map, boxes, timesteps: torch.Tensor, coef: torch.Tensor,
+                    given_mask: Optional[torch.Tensor] = None, given_latents: Optional[torch.Tensor] = None):
+        """latents (b, n_cam, C, h, w) any float dtype; camera/text/map/boxes already hold the [uncond | cond] halves.
+        given_mask (b, n_cam) bool + given_latents (b, n_cam, C, h, w): the known views of a given-view plan."""
         b, nc = self.b, self.n_cam
         assert latents.shape[:2] == (b, nc)
         xl = latents.to(self.device, F32).reshape(b * nc, *latents.shape[2:]).permute(0, 2, 3, 1).contiguous()
+        if self.given_view_mode:
+            assert given_mask is not None and given_latents is not None and tuple(given_mask.shape) == (b, nc)
+            gm = given_mask.to(self.device).reshape(-1).bool()
+            self.gv_mask.copy_(gm.to(torch.uint8))
+            self.gv_noise.copy_(xl)                                                  # original_noise (:263)
+            self.gv_cond.copy_(given_latents.to(self.device, F32).reshape(b * nc, *latents.shape[2:]).permute(0, 2, 3, 1))
+            c0 = coef[0].to(self.device, F32)                                        # add_noise at the first timestep (:265-275, :284-291)
+            xl = torch.where(gm.view(-1, 1, 1, 1), c0[0] * self.gv_cond + c0[1] * self.gv_noise, xl)
+        else:
+            assert given_mask is None, "this plan was built without given views"
         self.x.copy_(xl)
         self.x_in.view(self.c, b * nc, self.h, self.w, CIN_PAD)[..., :xl.shape[-1]].copy_(self.x.unsqueeze(0).expand(self.c, *self.x.shape))
         self.cond.load(camera_param, text, bev_map, boxes)

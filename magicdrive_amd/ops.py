@@ -417,6 +417,12 @@ class DdimStep:
     guidance: float = 1.0
     xin_c: int = 0                        # channels per pixel of x (for the bf16 padded x_in)
     name: str = ""
+    # given views (MdxDdimDesc.gv_*): mask uint8 [views], cond / noise fp32 [n] in x's layout, mode 1 | 2, last step index
+    gv_mask: Optional[torch.Tensor] = None
+    gv_cond: Optional[torch.Tensor] = None
+    gv_noise: Optional[torch.Tensor] = None
+    gv_mode: int = 0
+    gv_last_step: int = 0
     opcode = L.OP_DDIM
 
     def lower(self):
@@ -433,6 +439,14 @@ class DdimStep:
                 _chk(self.x_in.shape[0] * self.xin_c == self.eps.numel() and self.x_in.shape[1] >= self.xin_c, "ddim: bf16 x_in shape")
                 d.xin_c, d.xin_ld = self.xin_c, self.x_in.shape[1]
         d.n, d.cfg, d.guidance = n, int(self.cfg), float(self.guidance)
+        if self.gv_mode:
+            _chk(self.gv_mode in (1, 2) and self.gv_mask is not None and self.gv_mask.dtype == torch.uint8 and self.gv_mask.is_contiguous()
+                 and n % self.gv_mask.numel() == 0, "ddim: given-view mask")
+            _chk(self.gv_noise is not None and self.gv_noise.dtype == F32 and self.gv_noise.is_contiguous() and self.gv_noise.numel() == n, "ddim: gv_noise")
+            _chk(self.gv_mode == 2 or (self.gv_cond is not None and self.gv_cond.dtype == F32 and self.gv_cond.is_contiguous()
+                                       and self.gv_cond.numel() == n), "ddim: gv_cond")
+            d.gv_mask, d.gv_noise, d.gv_cond = _p(self.gv_mask), _p(self.gv_noise), _p(self.gv_cond)
+            d.gv_mode, d.gv_view_elems, d.gv_last_step = self.gv_mode, n // self.gv_mask.numel(), self.gv_last_step
         return self.opcode, d
 
 

@@ -177,7 +177,9 @@ class StableDiffusionBEVControlNetPipeline:
                  callback: Optional[Callable[[int, int, torch.Tensor], None]] = None, callback_steps: int = 1,
                  cross_attention_kwargs: Optional[Dict[str, Any]] = None, controlnet_conditioning_scale: float = 1,
                  guess_mode: bool = False, use_zero_map_as_unconditional: bool = False, bev_controlnet_kwargs={},
-                 bbox_max_length=None):
+                 bbox_max_length=None, _given_view=None):
+        """`_given_view` = (conditional_latents, change_every_input) is how StableDiffusionBEVControlNetGivenViewPipeline reuses
+        this body; not part of the reference signature."""
         if guess_mode:
             raise NotImplementedError("guess_mode is outside the built hot path")
         if eta != 0.0:
@@ -232,15 +234,30 @@ class StableDiffusionBEVControlNetPipeline:
         L_box = 0 if boxes is None else int(boxes["bboxes"].shape[2])
         h, w = latents.shape[-2:]
         n_steps = len(timesteps)
-        key = (b, do_cfg, L_box, h, w, n_steps, float(guidance_scale), float(controlnet_conditioning_scale), text.shape[1], sched_kind)
+        gv_mode, gv_mask, gv_lat = 0, None, None
+        if _given_view is not None:
+            cond_lat, every_input = _given_view
+            if sched_kind != "ddim":
+                raise NotImplementedError("given views are fused into the DDIM step only")
+            assert len(cond_lat) == b and all(len(r) == n_cam for r in cond_lat), "conditional_latents must be a B x N_cam list"
+            gv_mode = 1 if every_input else 2
+            gv_mask = torch.tensor([[v is not None for v in r] for r in cond_lat], dtype=torch.bool)
+            gv_lat = torch.zeros(b, n_cam, *latents.shape[2:], dtype=torch.float32, device=device)
+            for i, r in enumerate(cond_lat):
+                for j, v in enumerate(r):
+                    if v is not None:
+                        gv_lat[i, j] = v.to(device, torch.float32)
+        key = (b, do_cfg, L_box, h, w, n_steps, float(guidance_scale), float(controlnet_conditioning_scale), text.shape[1], sched_kind, gv_mode)
         plan = self._plans.get(key)
         if plan is None:
             plan = SamplerPlan(self.unet.cfg, self.unet.packed(), self.controlnet.packed(), device, b, do_cfg, L_box, (h, w),
                                num_steps=n_steps, guidance_scale=guidance_scale,
-                               conditioning_scale=float(controlnet_conditioning_scale), n_text=text.shape[1], scheduler_kind=sched_kind)
+                               conditioning_scale=float(controlnet_conditioning_scale), n_text=text.shape[1], scheduler_kind=sched_kind,
+                               given_view_mode=gv_mode)
             plan.compile()
             self._plans[key] = plan
-        plan.load_inputs(latents, camera_param, text, image, boxes, timesteps, self.scheduler.coefficient_table())
+        plan.load_inputs(latents, camera_param, text, image, boxes, timesteps, self.scheduler.coefficient_table(),
+                         given_mask=gv_mask, given_latents=gv_lat)
         st = torch.cuda.current_stream().cuda_stream
         plan.prologue.run(st)
         with self.progress_bar(total=num_inference_steps) as bar:

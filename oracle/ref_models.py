@@ -39,7 +39,7 @@ def build_reference(cfg, unet_sd, cn_sd, img_size=(224, 400)):
     return ns, unet.eval(), cnet.eval()
 
 
-def build_reference_pipeline(cfg, unet_sd, cn_sd, scheduler="ddim"):
+def build_reference_pipeline(cfg, unet_sd, cn_sd, scheduler="ddim", given_view=False):
     """The reference StableDiffusionBEVControlNetPipeline with a 1-layer random CLIP (only .dtype is read when
     prompt_embeds are given, pipeline_controlnet.py:371) and a generator-free DDIM subclass."""
     ns, unet, cnet = build_reference(cfg, unet_sd, cn_sd)
@@ -60,7 +60,10 @@ def build_reference_pipeline(cfg, unet_sd, cn_sd, scheduler="ddim"):
     vae = ns.diffusers.AutoencoderKL(in_channels=3, out_channels=3, block_out_channels=(32, 32, 32, 32),
                                      down_block_types=("DownEncoderBlock2D",) * 4, up_block_types=("UpDecoderBlock2D",) * 4,
                                      latent_channels=4, norm_num_groups=8)
-    pipe = ns.pipeline.StableDiffusionBEVControlNetPipeline(vae=vae, text_encoder=te, unet=unet, controlnet=cnet,
-                                                            scheduler=sch, tokenizer=None)
+    pipe_cls = ns.pipeline.StableDiffusionBEVControlNetPipeline
+    if given_view:
+        import importlib
+        pipe_cls = importlib.import_module("magicdrive.pipeline.pipeline_bev_controlnet_given_view").StableDiffusionBEVControlNetGivenViewPipeline
+    pipe = pipe_cls(vae=vae, text_encoder=te, unet=unet, controlnet=cnet, scheduler=sch, tokenizer=None)
     pipe.set_progress_bar_config(disable=True)
     return ns, pipe

@@ -34,3 +34,12 @@ def cfg_inputs(oracle_D, csd, sc, n_cam=6):
     if sc["bboxes_3d_data"] is not None:
         boxes = {k: torch.cat([torch.zeros_like(v), v]) for k, v in sc["bboxes_3d_data"].items()}
     return cam, text, bev, boxes
+
+
+def given_view_inputs(hw=(28, 50)):
+    """The known views of tests/golden/tiny_pipeline_given_view.pt (same generator as tools/make_golden.py: given_view_inputs)."""
+    g = torch.Generator().manual_seed(77)
+    cl = [[None] * 6 for _ in range(2)]
+    for (i, j) in ((0, 0), (0, 3), (1, 5)):
+        cl[i][j] = torch.randn(4, *hw, generator=g) * 0.8
+    return cl

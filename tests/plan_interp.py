@@ -160,8 +160,15 @@ def run_ddim(op: O.DdimStep):
     n = op.x.numel()
     c = op.coef[int(op.step.item())]
     e = op.eps[:n] + op.guidance * (op.eps[n:] - op.eps[:n]) if op.cfg else op.eps
+    given = None
+    if op.gv_mode:
+        given = op.gv_mask.bool().repeat_interleave(n // op.gv_mask.numel())
+        if op.gv_mode == 2:
+            e = torch.where(given, op.gv_noise, e)
     x0 = (op.x - c[1] * e) / c[0]
     xn = c[2] * x0 + c[3] * e
+    if op.gv_mode == 1 and int(op.step.item()) < op.gv_last_step:
+        xn = torch.where(given, c[2] * op.gv_cond + c[3] * op.gv_noise, xn)
     op.x.copy_(xn)
     if op.x_in is not None:
         if op.x_in.dtype == torch.float32:

@@ -11,7 +11,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from helpers import bf16_round, cfg_inputs, rel_l2, scene, state_dicts
+from helpers import given_view_inputs, bf16_round, cfg_inputs, rel_l2, scene, state_dicts
 from magicdrive_amd import denoiser as DN, schedulers
 from magicdrive_amd.engine import PackedNet
 from magicdrive_amd.networks import spec
@@ -180,6 +180,28 @@ def test_module_api_forward(dev):
                down_block_additional_residuals=down, mid_block_additional_residual=mid).sample
     torch.cuda.synchronize()
     assert max(rel_l2(eps[i], G["eps"][i]) for i in range(12)) < 4e-2
+
+
+@pytest.mark.parametrize("every", [True, False])
+def test_given_view_pipeline_matches_reference_golden(dev, every):
+    """StableDiffusionBEVControlNetGivenViewPipeline.__call__ (reference signature) on the GPU vs the real reference's latents."""
+    import os
+    from magicdrive_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiview
+    from magicdrive_amd.networks.unet_addon_rawbox import BEVControlNetModel
+    from magicdrive_amd.pipeline.pipeline_bev_controlnet_given_view import StableDiffusionBEVControlNetGivenViewPipeline
+    G = torch.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_pipeline_given_view.pt"))
+    cfg = spec.TINY_CONFIG
+    pipe = StableDiffusionBEVControlNetGivenViewPipeline(unet=UNet2DConditionModelMultiview.from_config(cfg, 0),
+                                                         controlnet=BEVControlNetModel.from_config(cfg, 1)).to(dev)
+    sc = scene(cfg, 2, 5)
+    out = pipe(prompt=None, image=sc["bev_map"], camera_param=sc["camera_param"], height=224, width=400,
+               conditional_latents=given_view_inputs(), conditional_latents_change_every_input=every, num_inference_steps=G["steps"],
+               guidance_scale=G["guidance"], latents=sc["latents"], prompt_embeds=sc["prompt_embeds"], negative_prompt_embeds=sc["negative_prompt_embeds"],
+               output_type="latent", bev_controlnet_kwargs={"bboxes_3d_data": sc["bboxes_3d_data"]}).images
+    torch.cuda.synchronize()
+    e = rel_l2(out, G["latents_every" if every else "latents_once"])
+    print(f"[given-view pipeline (every_input={every}) vs reference golden] {e:.4f}")
+    assert e < 5e-2
 
 
 def test_module_api_forward_hires_plus_map_encoder(dev):

@@ -433,6 +433,40 @@ def test_cfg_ddim_and_graph_replay(dev):
     assert torch.allclose(x.cpu(), ref_step(r1, coef[1].cpu()), atol=1e-5) and step.item() == 2
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_cfg_ddim_given_views(dev, mode):
+    """MdxDdimDesc.gv_*: views 1 and 4 of 6 are known.  Mode 1: after every step but the last they are replaced by
+    coef[2] * cond + coef[3] * noise; mode 2: their noise prediction is the initial noise."""
+    V, ve = 6, 4 * 28 * 50
+    n = V * ve
+    x = rnd(n, seed=1, dtype=torch.float32); x0 = x.clone()
+    eps = rnd(2 * n, seed=2, dtype=torch.float32)
+    cond = rnd(n, seed=3, dtype=torch.float32); noise = rnd(n, seed=4, dtype=torch.float32)
+    mask = torch.tensor([0, 1, 0, 0, 1, 0], dtype=torch.uint8, device=dev)
+    coef = torch.tensor([[0.9, 0.4359, 0.95, 0.3122], [0.95, 0.3122, 0.99, 0.1411]], dtype=torch.float32, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    xin = torch.zeros(2 * n, dtype=torch.float32, device=dev)
+    prog = O.build_program([O.DdimStep(x, eps, coef, step, x_in=xin, cfg=True, guidance=2.0, gv_mask=mask, gv_cond=cond, gv_noise=noise,
+                                       gv_mode=mode, gv_last_step=1)])
+    st = torch.cuda.current_stream().cuda_stream
+    g = mask.cpu().bool().repeat_interleave(ve)
+    e = eps[:n].cpu() + 2.0 * (eps[n:].cpu() - eps[:n].cpu())
+    if mode == 2:
+        e = torch.where(g, noise.cpu(), e)
+    ref = x0.cpu()
+    for s_ in range(2):
+        (prog.run if s_ == 0 else prog.launch)(st)
+        torch.cuda.synchronize()
+        c = coef[s_].cpu()
+        ref = c[2] * (ref - c[1] * e) / c[0] + c[3] * e
+        if mode == 1 and s_ < 1:
+            ref = torch.where(g, c[2] * cond.cpu() + c[3] * noise.cpu(), ref)
+        assert torch.allclose(x.cpu(), ref, atol=1e-5), (mode, s_, (x.cpu() - ref).abs().max())
+        assert torch.equal(xin[:n].cpu(), x.cpu()) and torch.equal(xin[n:].cpu(), x.cpu())
+    with pytest.raises(L.MdxError):
+        O.run_ops([O.DdimStep(x, eps, coef, step, gv_mask=mask, gv_noise=None, gv_cond=cond, gv_mode=1, cfg=True)])
+
+
 def test_cfg_unipc_matches_oracle_scheduler(dev):
     """mdx_cfg_unipc_step driven for a whole 8-step trajectory (warm-up, order 2, lower-order final) against
     oracle.denoiser.UniPC with the same per-step eps; also checks the bf16 padded model-input copy."""

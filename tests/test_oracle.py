@@ -12,7 +12,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-from helpers import rel_l2, scene, state_dicts
+from helpers import given_view_inputs, rel_l2, scene, state_dicts
 from magicdrive_amd.networks import spec
 from oracle import denoiser as D
 from oracle import refshim
@@ -187,6 +187,20 @@ def test_golden_pipeline_unipc(tiny):
         out = D.sample_loop(usd, csd, cfg, sc["latents"], sc["prompt_embeds"], sc["negative_prompt_embeds"], sc["bev_map"],
                             sc["camera_param"], sc["bboxes_3d_data"], num_steps=G["steps"], guidance_scale=G["guidance"], scheduler=D.UniPC())
     assert rel_l2(out, G["latents_cfg"]) < 2e-4, rel_l2(out, G["latents_cfg"])
+
+
+@pytest.mark.parametrize("every", [True, False])
+def test_golden_pipeline_given_view(tiny, every):
+    """The restated given-view loop vs the REAL StableDiffusionBEVControlNetGivenViewPipeline (both re-noising modes)."""
+    cfg, usd, csd = tiny
+    G = torch.load(os.path.join(GOLD, "tiny_pipeline_given_view.pt"))
+    sc = scene(cfg, 2, 5)
+    with torch.no_grad():
+        out = D.sample_loop(usd, csd, cfg, sc["latents"], sc["prompt_embeds"], sc["negative_prompt_embeds"], sc["bev_map"],
+                            sc["camera_param"], sc["bboxes_3d_data"], num_steps=G["steps"], guidance_scale=G["guidance"],
+                            conditional_latents=given_view_inputs(), conditional_latents_change_every_input=every)
+    gold = G["latents_every" if every else "latents_once"]
+    assert rel_l2(out, gold) < 2e-4, rel_l2(out, gold)
 
 
 def test_golden_forward_hires_plus_map_encoder(tiny):

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import plan_interp
-from helpers import bf16_round, cfg_inputs, rel_l2, scene, state_dicts
+from helpers import given_view_inputs, bf16_round, cfg_inputs, rel_l2, scene, state_dicts
 from magicdrive_amd import denoiser as DN, flops, schedulers
 from magicdrive_amd.engine import PackedNet
 from magicdrive_amd.networks import spec
@@ -93,6 +93,35 @@ def test_unipc_sampler_plan_matches_golden_pipeline(tiny):
     # a second load_inputs must reset the multistep history (a reused plan starts a fresh trajectory)
     sp.load_inputs(torch.stack([sc["latents"]] * 6, 1), cam, text, bev, boxes, ts, sch.coefficient_table())
     assert sp.step_ctr.item() == 0 and not sp.m1.any() and not sp.x_last.any()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_given_view_sampler_plan_matches_golden(tiny, mode):
+    """Given views inside the fused CFG + DDIM op (MdxDdimDesc.gv_*): mode 1 = re-noise the known views for every model call,
+    mode 2 = noise once and pin their noise prediction — vs the reference's given-view pipeline."""
+    cfg, usd, csd, un, cn = tiny
+    G = torch.load(os.path.join(GOLD, "tiny_pipeline_given_view.pt"))
+    sc = scene(cfg, 2, 5)
+    steps = G["steps"]
+    sch = schedulers.DDIMScheduler(); ts = sch.set_timesteps(steps)
+    cam, text, bev, boxes = cfg_inputs(D, csd, sc)
+    sp = DN.SamplerPlan(cfg, un, cn, CPU, 2, True, 5, (28, 50), num_steps=steps, guidance_scale=G["guidance"], given_view_mode=mode)
+    cl = given_view_inputs()
+    mask = torch.tensor([[v is not None for v in r] for r in cl])
+    lat = torch.zeros(2, 6, 4, 28, 50)
+    for i, r in enumerate(cl):
+        for j, v in enumerate(r):
+            if v is not None:
+                lat[i, j] = v
+    sp.load_inputs(torch.stack([sc["latents"]] * 6, 1), cam, text, bev, boxes, ts, sch.coefficient_table(), given_mask=mask, given_latents=lat)
+    plan_interp.run(sp.prologue_ops)
+    for _ in range(steps):
+        plan_interp.run(sp.step_ops, lower_check=False)
+    gold = G["latents_every" if mode == 1 else "latents_once"]
+    assert rel_l2(sp.latents(), gold) < 4e-2, rel_l2(sp.latents(), gold)
+    # the known views end close to their clean latents (that is the point of conditioning on them)
+    with pytest.raises(AssertionError):
+        DN.SamplerPlan(cfg, un, cn, CPU, 2, True, 5, (28, 50), num_steps=steps, scheduler_kind="unipc", given_view_mode=mode)
 
 
 def test_module_plans_hires_plus_map_encoder(tiny):

@@ -18,7 +18,10 @@ Fixtures
                     BEVControlNetConditioningEmbeddingPlus map encoder (configs/exp/272x736.yaml:15-22 with size [54, 96]);
                     reference BEVControlNetModel.forward + UNet2DConditionModelMultiview.forward, 1 scene x 6 views, 3 boxes/view.
 
-`python tools/make_golden.py unipc` / `... hires` regenerate only that fixture.
+  tiny_pipeline_given_view.pt  StableDiffusionBEVControlNetGivenViewPipeline.__call__ (reference), 5 DDIM steps, guidance 2.0, views 0 and 3
+                    of scene 0 and view 5 of scene 1 given; both `conditional_latents_change_every_input` modes.
+
+`python tools/make_golden.py unipc` / `... hires` / `... given` regenerate only that fixture.
 """
 import os
 import sys
@@ -50,6 +53,31 @@ def unipc_fixture(out_dir, cfg, usd, csd, meta, hw=(28, 50)):
     print("tiny_pipeline_unipc: |x|", out.abs().mean().item())
 
 
+def given_view_inputs(hw=(28, 50)):
+    """Seeded clean latents of the known views: scene 0 views 0 and 3, scene 1 view 5."""
+    g = torch.Generator().manual_seed(77)
+    cl = [[None] * 6 for _ in range(2)]
+    for (i, j) in ((0, 0), (0, 3), (1, 5)):
+        cl[i][j] = torch.randn(4, *hw, generator=g) * 0.8
+    return cl
+
+
+def given_view_fixture(out_dir, cfg, usd, csd, meta, hw=(28, 50)):
+    ns, pipe = ref_models.build_reference_pipeline(cfg, usd, csd, given_view=True)
+    sc = scene(cfg, 2, 5, hw)
+    outs = {}
+    with torch.no_grad():
+        for every in (True, False):
+            outs[every] = pipe(prompt=None, image=sc["bev_map"], camera_param=sc["camera_param"], height=224, width=400,
+                               conditional_latents=given_view_inputs(hw), conditional_latents_change_every_input=every,
+                               num_inference_steps=5, guidance_scale=2.0, latents=sc["latents"].clone(), prompt_embeds=sc["prompt_embeds"],
+                               negative_prompt_embeds=sc["negative_prompt_embeds"], output_type="latent",
+                               bev_controlnet_kwargs={"bboxes_3d_data": sc["bboxes_3d_data"]}).images
+    torch.save({"meta": meta, "steps": 5, "guidance": 2.0, "latents_every": outs[True].clone(), "latents_once": outs[False].clone()},
+               os.path.join(out_dir, "tiny_pipeline_given_view.pt"))
+    print("tiny_pipeline_given_view: |x|", outs[True].abs().mean().item(), outs[False].abs().mean().item())
+
+
 def hires_fixture(out_dir, cfg0, usd, csd, meta, hw=(54, 96)):
     cfg = spec.with_plus_map_embedder(cfg0, hw)
     ns, unet, cnet = ref_models.build_reference(cfg, usd, csd, img_size=(hw[0] * 8, hw[1] * 8))
@@ -77,6 +105,8 @@ def main():
         return unipc_fixture(out_dir, cfg, usd, csd, meta)
     if sys.argv[1:] == ["hires"]:
         return hires_fixture(out_dir, cfg, usd, csd, meta)
+    if sys.argv[1:] == ["given"]:
+        return given_view_fixture(out_dir, cfg, usd, csd, meta)
 
     # ---- module-level forwards
     ns, unet, cnet = ref_models.build_reference(cfg, usd, csd)
@@ -111,6 +141,7 @@ def main():
     print("tiny_pipeline: |x|", out.abs().mean().item(), out_nocam.abs().mean().item())
     unipc_fixture(out_dir, cfg, usd, csd, meta, hw)
     hires_fixture(out_dir, cfg, usd, csd, meta)
+    given_view_fixture(out_dir, cfg, usd, csd, meta)
     for f in os.listdir(out_dir):
         print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")
 
