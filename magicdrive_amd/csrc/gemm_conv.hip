@@ -341,8 +341,9 @@ static int launch_one(const GCParams& p, hipStream_t st) {
 }
 
 // Tile / split-K choice.  The chip has 256 CUs.
-//   MDX_GEMM_IMPL=0 : register-staged main loop (gemm_conv_kernel), 128/64 tiles
-//   MDX_GEMM_IMPL=1 : LDS-DMA ring main loop (gemm_dma_kernel), tile picked per shape (default)
+//   MDX_GEMM_IMPL=0 : register-staged main loop (gemm_conv_kernel), 128/64 tiles (default; the specialised kernels —
+//                     gemm_ws.hip, gemm_pp.hip, conv3x3.hip — are tried first, each behind its own switch)
+//   MDX_GEMM_IMPL=1 : LDS-DMA ring main loop (gemm_dma_kernel), tile picked per shape (kept for comparison: slower, profiles/README.md)
 //   MDX_GEMM_IMPL=10+t : LDS-DMA with tile id t forced (benchmarking)
 int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MDX_OK;

@@ -17,10 +17,11 @@
 //     what lets two 256+320-row buffers fit into 160 KiB.
 //   * Epilogue: bias (+ the per-(step, batch) temb row) is staged once per tile into LDS as fp32 "addend" rows, applied to
 //     the accumulators in registers with activation / GEGLU, the bf16 tile is transposed through LDS in two 128-row halves
-//     and written as full row segments with the residual added (same arithmetic order as gemm_conv.hip => same bits).
+//     and written as full row segments with the residual added (same arithmetic per element as gemm_conv.hip).
 //
-// Used for the big shapes only (K >= 640, many tiles); everything else stays on gemm_conv.hip.  Same GCParams, same
-// results (bit-identical accumulation order per output element: k ascending in 16-wide MFMA steps).
+// Used for the big shapes only (cost model in gemm_conv.hip: N % 256 == 0, K >= 1024, enough tiles); everything else stays on
+// gemm_conv.hip / conv3x3.hip / gemm_ws.hip.  Same GCParams, same reduction order per output element (k ascending in 16-wide
+// MFMA steps, fp32 accumulation).
 #include "common.h"
 #include "launch.h"
 #include "gemm_params.h"
