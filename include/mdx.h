@@ -42,7 +42,7 @@ extern "C" {
 #define MDX_ELAUNCH (-2)     /* hip launch / runtime error */
 #define MDX_EUNSUPPORTED (-3)
 
-#define MDX_ABI_VERSION 3
+#define MDX_ABI_VERSION 4
 
 /* ---- epilogue flags shared by GEMM / conv ------------------------------- */
 #define MDX_EPI_NONE 0
@@ -173,6 +173,18 @@ typedef struct MdxLayerNormDesc {
 } MdxLayerNormDesc;
 int mdx_layernorm_bf16(const MdxLayerNormDesc* d, void* stream);
 
+/* mdx_softmax_rows — Y[r][0..T) = softmax(scale * X[r][0..T)) row by row, fp32 in (the fp32 scores of a Q K^T GEMM), bf16 out;
+ * columns T..ldy-1 of Y are written as zeros (so Y can be the K-padded A operand of the P V GEMM).  Used by the VAE decoder's
+ * single-head, 512-channel mid-block attention (attention_processor.py:495-558 with upcast_softmax; unet_2d_blocks.py:433-445),
+ * whose head dim is outside the fused attention kernel's range. */
+typedef struct MdxSoftmaxDesc {
+    const float* X; void* Y;
+    int64_t rows, T, ldx, ldy;
+    double scale;
+    int64_t reserved0;
+} MdxSoftmaxDesc;
+int mdx_softmax_rows(const MdxSoftmaxDesc* d, void* stream);
+
 /* ---- small element-wise kernels ---------------------------------------- */
 #define MDX_EW_ADD 1          /* Y[m, :C] += X[m, :C]            (unet_2d_condition_multiview.py:464-488) */
 #define MDX_EW_COPY 2         /* Y[m, :C]  = X[m, :C]  (concat halves: unet_2d_blocks.py:1990, 2090) */
@@ -290,6 +302,7 @@ int mdx_cfg_unipc_step(const MdxUniPCDesc* d, void* stream);
 #define MDX_OP_TIMEEMB 10
 #define MDX_OP_DDIM 11
 #define MDX_OP_UNIPC 12
+#define MDX_OP_SOFTMAX 13
 
 #define MDX_OP_BYTES 512
 typedef struct MdxOp {

@@ -13,11 +13,11 @@ from typing import Dict, List, Tuple
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmdx.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # opcodes (mdx.h)
 OP_GEMM, OP_CONV, OP_CONV_DIRECT, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM = 1, 2, 3, 4, 5, 6
-OP_EW, OP_FOURIER, OP_GATHER, OP_TIMEEMB, OP_DDIM, OP_UNIPC = 7, 8, 9, 10, 11, 12
+OP_EW, OP_FOURIER, OP_GATHER, OP_TIMEEMB, OP_DDIM, OP_UNIPC, OP_SOFTMAX = 7, 8, 9, 10, 11, 12, 13
 OP_BYTES = 512
 
 EPI_NONE, EPI_GEGLU, EPI_SILU = 0, 1, 2
@@ -52,16 +52,17 @@ MdxDdimDesc = _struct("MdxDdimDesc", _f(P, "x eps coef step_ptr x_in reserved_p"
                       + _f(P, "gv_cond gv_noise gv_mask") + _f(I, "gv_mode gv_view_elems gv_last_step"))
 MdxUniPCDesc = _struct("MdxUniPCDesc", _f(P, "x eps coef step_ptr x_in x_last m1 m2") + _f(I, "n cfg") + _f(D, "guidance") + _f(I, "xin_c xin_ld"))
 
+MdxSoftmaxDesc = _struct("MdxSoftmaxDesc", _f(P, "X Y") + _f(I, "rows T ldx ldy") + _f(D, "scale") + _f(I, "reserved0"))
 DESC_OF_OP = {
     OP_GEMM: MdxGemmDesc, OP_CONV: MdxConvDesc, OP_CONV_DIRECT: MdxConvDirectDesc, OP_ATTN: MdxAttnDesc,
     OP_GROUPNORM: MdxGroupNormDesc, OP_LAYERNORM: MdxLayerNormDesc, OP_EW: MdxEwDesc, OP_FOURIER: MdxFourierDesc,
-    OP_GATHER: MdxGatherDesc, OP_TIMEEMB: MdxTimeEmbDesc, OP_DDIM: MdxDdimDesc, OP_UNIPC: MdxUniPCDesc,
+    OP_GATHER: MdxGatherDesc, OP_TIMEEMB: MdxTimeEmbDesc, OP_DDIM: MdxDdimDesc, OP_UNIPC: MdxUniPCDesc, OP_SOFTMAX: MdxSoftmaxDesc,
 }
 ENTRY_OF_OP = {
     OP_GEMM: "mdx_gemm_bf16", OP_CONV: "mdx_conv2d_bf16", OP_CONV_DIRECT: "mdx_conv2d_direct", OP_ATTN: "mdx_attention_bf16",
     OP_GROUPNORM: "mdx_groupnorm_bf16", OP_LAYERNORM: "mdx_layernorm_bf16", OP_EW: "mdx_elementwise",
     OP_FOURIER: "mdx_fourier_embed", OP_GATHER: "mdx_gather_rows", OP_TIMEEMB: "mdx_timestep_embedding", OP_DDIM: "mdx_cfg_ddim_step",
-    OP_UNIPC: "mdx_cfg_unipc_step",
+    OP_UNIPC: "mdx_cfg_unipc_step", OP_SOFTMAX: "mdx_softmax_rows",
 }
 # every symbol include/mdx.h declares
 EXPORTS = sorted(set(ENTRY_OF_OP.values()) | {

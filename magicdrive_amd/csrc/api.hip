@@ -36,6 +36,7 @@ static int run_op(const MdxOp* op, hipStream_t st) {
         case MDX_OP_TIMEEMB: return mdx_timestep_embedding((const MdxTimeEmbDesc*)d, st);
         case MDX_OP_DDIM: return mdx_cfg_ddim_step((const MdxDdimDesc*)d, st);
         case MDX_OP_UNIPC: return mdx_cfg_unipc_step((const MdxUniPCDesc*)d, st);
+        case MDX_OP_SOFTMAX: return mdx_softmax_rows((const MdxSoftmaxDesc*)d, st);
         default: return set_error(MDX_EINVAL, "unknown opcode %ld", (long)op->opcode);
     }
 }

@@ -349,6 +349,38 @@ extern "C" int mdx_groupnorm_bf16(const MdxGroupNormDesc* d, void* stream) {
     return check_launch("groupnorm_kernel");
 }
 
+namespace mdx {
+struct SMParams { const float* X; bf16_t* Y; long rows; int T; long ldx, ldy; float scale; };
+
+// One wave per row (4 rows per 256-thread block): lanes stride the row (coalesced fp32 reads), three passes over a row that
+// stays in L1/L2 (a 1400-column row is 5.6 KB): max, sum of exp, normalised write.  exp2 with the scale folded in.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(SMParams p) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.rows) return;
+    const float* x = p.X + r * p.ldx;
+    bf16_t* y = p.Y + r * p.ldy;
+    const float k = p.scale * 1.4426950408889634f;      // log2(e)
+    float m = -INFINITY;
+    for (int c = lane; c < p.T; c += 64) m = fmaxf(m, x[c] * k);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int c = lane; c < p.T; c += 64) sum += exp2f(x[c] * k - m);
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int c = lane; c < p.ldy; c += 64) y[c] = c < p.T ? f2bf(exp2f(x[c] * k - m) * inv) : (bf16_t)0;
+}
+}  // namespace mdx
+
+extern "C" int mdx_softmax_rows(const MdxSoftmaxDesc* d, void* stream) {
+    if (!d || !d->X || !d->Y) return set_error(MDX_EINVAL, "mdx_softmax_rows: null operand");
+    if (d->T <= 0 || d->ldx < d->T || d->ldy < d->T) return set_error(MDX_EINVAL, "softmax: need 0 < T <= ldx, ldy");
+    if (d->rows <= 0) return MDX_OK;
+    mdx::SMParams p{d->X, (bf16_t*)d->Y, d->rows, (int)d->T, d->ldx, d->ldy, (float)d->scale};
+    hipLaunchKernelGGL(mdx::softmax_rows_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    return mdx::check_launch("softmax_rows_kernel");
+}
+
 extern "C" int mdx_layernorm_bf16(const MdxLayerNormDesc* d, void* stream) {
     if (!d || !d->X || !d->Y || !d->gamma || !d->beta) return set_error(MDX_EINVAL, "mdx_layernorm_bf16: null operand");
     if (d->C % 8 || d->ldx % 8 || d->ldy % 8) return set_error(MDX_EINVAL, "layernorm: C, ldx, ldy must be multiples of 8");

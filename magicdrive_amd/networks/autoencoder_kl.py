@@ -1,0 +1,153 @@
+"""AutoencoderKL (decoder side) — drop-in for the `vae` the reference pipeline decodes with
+(pipeline_bev_controlnet.py:100-112 -> diffusers AutoencoderKL.decode, dif:models/autoencoder_kl.py:173-198).
+
+Only what the sampler path touches is built: `decode(z).sample`, `.config.scaling_factor`, `.to()`, `.dtype`, `enable_slicing()`
+(accepted: the op program already decodes one scene's views at a time), `from_pretrained` on the reference checkpoint layout
+`<sd15>/vae/{config.json, diffusion_pytorch_model.(safetensors|bin)}` (encoder / quant_conv tensors are ignored).  The arithmetic is
+an op program on libmdx (magicdrive_amd/vae.py); there is no CPU path.
+"""
+from __future__ import annotations
+
+import json
+import os
+from collections import OrderedDict
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import torch
+
+from . import spec
+from ..engine import PackedNet
+from ..vae import VaeDecodePlan
+
+CONFIG_NAME = "config.json"
+WEIGHTS_ST, WEIGHTS_BIN = "diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.bin"
+
+
+class DecoderOutput(SimpleNamespace):
+    pass
+
+
+class AutoencoderKL:
+    def __init__(self, vcfg: Dict, state_dict: Dict[str, torch.Tensor], torch_dtype=torch.bfloat16):
+        self.vcfg = dict(vcfg)
+        shapes = spec.vae_decoder_param_shapes(self.vcfg)
+        missing = [k for k in shapes if k not in state_dict]
+        if missing:
+            raise KeyError(f"AutoencoderKL: state dict lacks {len(missing)} decoder tensors, e.g. {missing[:4]}")
+        for k, shp in shapes.items():
+            if tuple(state_dict[k].shape) != tuple(shp):
+                raise ValueError(f"AutoencoderKL: {k} has shape {tuple(state_dict[k].shape)}, config implies {tuple(shp)}")
+        self._sd = OrderedDict((k, state_dict[k].detach()) for k in shapes)
+        self._dtype = torch_dtype
+        self._device = torch.device("cpu")
+        self._packed: Optional[PackedNet] = None
+        self._plans: Dict[tuple, VaeDecodePlan] = {}
+        self.config = SimpleNamespace(**self.vcfg)
+        self.max_images_per_pass = 6          # one scene's views per program run (bounds activation memory: 138 MB per 128-ch 224x400 map)
+
+    @classmethod
+    def from_config(cls, vcfg: Dict, seed: int = 0, torch_dtype=torch.bfloat16):
+        return cls(vcfg, spec.random_state_dict(spec.vae_decoder_param_shapes(vcfg), seed), torch_dtype)
+
+    @classmethod
+    def from_pretrained(cls, path: str, torch_dtype=torch.bfloat16, subfolder: Optional[str] = None, **unused):
+        d = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(d, CONFIG_NAME)) as f:
+            js = json.load(f)
+        vcfg = dict(spec.VAE_SD15_CONFIG)
+        for k in ("latent_channels", "out_channels", "layers_per_block", "norm_num_groups", "scaling_factor"):
+            if k in js and js[k] is not None:
+                vcfg[k] = js[k]
+        if "block_out_channels" in js:
+            vcfg["block_out_channels"] = tuple(js["block_out_channels"])
+        if js.get("act_fn", "silu") != "silu":
+            raise NotImplementedError(f"AutoencoderKL act_fn={js['act_fn']!r}: SD-1.5's VAE uses silu")
+        if os.path.exists(os.path.join(d, WEIGHTS_ST)):
+            from safetensors.torch import load_file
+            sd = load_file(os.path.join(d, WEIGHTS_ST))
+        elif os.path.exists(os.path.join(d, WEIGHTS_BIN)):
+            sd = torch.load(os.path.join(d, WEIGHTS_BIN), map_location="cpu")
+        else:
+            raise FileNotFoundError(f"no {WEIGHTS_ST} / {WEIGHTS_BIN} under {d}")
+        # checkpoints older than diffusers 0.17 name the attention projections query/key/value/proj_attn (attention_processor.py:_from_deprecated_attn_block)
+        ren = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+        fixed = {}
+        for k, v in sd.items():
+            for old, new in ren.items():
+                tag = f".attentions.0.{old}."
+                if tag in k:
+                    k = k.replace(tag, f".attentions.0.{new}.")
+                    if v.dim() == 4:
+                        v = v.reshape(v.shape[0], v.shape[1])
+            fixed[k] = v
+        return cls(vcfg, fixed, torch_dtype)
+
+    def save_pretrained(self, path: str, safe_serialization: bool = True):
+        os.makedirs(path, exist_ok=True)
+        js = {k: (list(v) if isinstance(v, tuple) else v) for k, v in self.vcfg.items()}
+        js["_class_name"] = "AutoencoderKL"
+        with open(os.path.join(path, CONFIG_NAME), "w") as f:
+            json.dump(js, f, indent=2)
+        sd = {k: v.contiguous() for k, v in self._sd.items()}
+        if safe_serialization:
+            from safetensors.torch import save_file
+            save_file(sd, os.path.join(path, WEIGHTS_ST))
+        else:
+            torch.save(sd, os.path.join(path, WEIGHTS_BIN))
+
+    # ---- torch-module-like surface ----
+    def state_dict(self):
+        return self._sd
+
+    def parameters(self):
+        return iter(self._sd.values())
+
+    def eval(self):
+        return self
+
+    def to(self, device=None, dtype=None):
+        if device is not None:
+            dev = torch.device(device)
+            if dev != self._device:
+                self._device, self._packed = dev, None
+                self._plans.clear()
+        return self
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def device(self):
+        return self._device
+
+    def enable_slicing(self):
+        """Accepted (val_set_gen.py:78): decode() already runs one scene's views per pass."""
+
+    def disable_slicing(self):
+        pass
+
+    def packed(self) -> PackedNet:
+        if self._packed is None:
+            self._packed = PackedNet(self._sd, self._device)
+        return self._packed
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, return_dict: bool = True):
+        """z (n, 4, h, w) (already divided by scaling_factor, as the pipeline does) -> DecoderOutput(sample=(n, 3, 8h, 8w))."""
+        if self._device.type != "cuda":
+            raise RuntimeError("AutoencoderKL.to('cuda') first: the decoder has no CPU path")
+        n, _, h, w = z.shape
+        outs = []
+        for i0 in range(0, n, self.max_images_per_pass):
+            zi = z[i0:i0 + self.max_images_per_pass]
+            key = (zi.shape[0], h, w)
+            plan = self._plans.get(key)
+            if plan is None:
+                plan = VaeDecodePlan(self.vcfg, self.packed(), self._device, zi.shape[0], (h, w))
+                plan.compile()
+                self._plans[key] = plan
+            outs.append(plan.run(zi).to(z.dtype if z.dtype.is_floating_point else torch.float32))
+        sample = torch.cat(outs)
+        return DecoderOutput(sample=sample) if return_dict else (sample,)

@@ -42,6 +42,49 @@ TINY_CONFIG["controlnet"].update(camera_out_dim=64, conditioning_embedding_out_c
 TINY_CONFIG["controlnet"]["bbox"].update(class_token_dim=64, proj_dims=(64, 48, 48, 64))
 
 
+# AutoencoderKL of SD-1.5 (vae/config.json of runwayml/stable-diffusion-v1-5; dif:models/autoencoder_kl.py:64-112): decoder side only
+VAE_SD15_CONFIG = dict(latent_channels=4, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+                       norm_num_groups=32, scaling_factor=0.18215)
+VAE_TINY_CONFIG = dict(latent_channels=4, out_channels=3, block_out_channels=(32, 32, 64, 64), layers_per_block=2,
+                       norm_num_groups=8, scaling_factor=0.18215)
+
+
+def vae_decoder_param_shapes(vcfg) -> "OrderedDict[str, Tuple[int, ...]]":
+    """post_quant_conv + Decoder of AutoencoderKL (dif:models/autoencoder_kl.py:111, dif:models/vae.py:152-226): conv_in, mid block
+    (resnet, single-head attention, resnet), one UpDecoderBlock2D per level (layers_per_block + 1 resnets, nearest x2 + conv except
+    the last), GroupNorm + SiLU + conv_out.  Keys and shapes of the reference state dict (encoder / quant_conv are not on the path)."""
+    sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    boc = vcfg["block_out_channels"]; L = vcfg["layers_per_block"]; zc = vcfg["latent_channels"]
+    sh["post_quant_conv.weight"] = (zc, zc, 1, 1); sh["post_quant_conv.bias"] = (zc,)
+    top = boc[-1]
+    sh["decoder.conv_in.weight"] = (top, zc, 3, 3); sh["decoder.conv_in.bias"] = (top,)
+
+    def resnet(pre, cin, cout):
+        sh[pre + "norm1.weight"] = (cin,); sh[pre + "norm1.bias"] = (cin,)
+        sh[pre + "conv1.weight"] = (cout, cin, 3, 3); sh[pre + "conv1.bias"] = (cout,)
+        sh[pre + "norm2.weight"] = (cout,); sh[pre + "norm2.bias"] = (cout,)
+        sh[pre + "conv2.weight"] = (cout, cout, 3, 3); sh[pre + "conv2.bias"] = (cout,)
+        if cin != cout:
+            sh[pre + "conv_shortcut.weight"] = (cout, cin, 1, 1); sh[pre + "conv_shortcut.bias"] = (cout,)
+    rev = list(reversed(boc))
+    prev = rev[0]
+    for i, c in enumerate(rev):
+        for j in range(L + 1):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}.", prev if j == 0 else c, c)
+        if i != len(rev) - 1:
+            sh[f"decoder.up_blocks.{i}.upsamplers.0.conv.weight"] = (c, c, 3, 3); sh[f"decoder.up_blocks.{i}.upsamplers.0.conv.bias"] = (c,)
+        prev = c
+    a = "decoder.mid_block.attentions.0."
+    sh[a + "group_norm.weight"] = (top,); sh[a + "group_norm.bias"] = (top,)
+    for nm in ("to_q", "to_k", "to_v", "to_out.0"):
+        sh[a + nm + ".weight"] = (top, top); sh[a + nm + ".bias"] = (top,)
+    resnet("decoder.mid_block.resnets.0.", top, top)
+    resnet("decoder.mid_block.resnets.1.", top, top)
+    sh["decoder.conv_norm_out.weight"] = (boc[0],); sh["decoder.conv_norm_out.bias"] = (boc[0],)
+    sh["decoder.conv_out.weight"] = (vcfg["out_channels"], boc[0], 3, 3); sh["decoder.conv_out.bias"] = (vcfg["out_channels"],)
+    return sh
+
+
 PLUS_MAP_EMBEDDER = "magicdrive.networks.map_embedder.BEVControlNetConditioningEmbeddingPlus"   # configs/exp/272x736.yaml:18
 
 
@@ -214,7 +257,7 @@ def random_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int, dtype=torch
             t = torch.randn(shape, generator=g) * 0.02
         elif name.endswith("_class_tokens") or name.startswith("uncond_cam"):
             t = torch.randn(shape, generator=g)
-        elif ".norm" in name or name.startswith("conv_norm_out") or name.endswith("norm.weight") or name.endswith("norm.bias"):
+        elif ".norm" in name or "conv_norm_out." in name or name.endswith("norm.weight") or name.endswith("norm.bias"):
             t = (1.0 + 0.1 * torch.randn(shape, generator=g)) if name.endswith("weight") else 0.05 * torch.randn(shape, generator=g)
         elif name.endswith("bias"):
             t = 0.05 * torch.randn(shape, generator=g)

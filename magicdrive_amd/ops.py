@@ -273,6 +273,27 @@ class LayerNorm:
 
 
 @dataclass
+class Softmax:
+    """Y[r, :T] = softmax(scale * X[r, :T]) (fp32 scores -> bf16 probabilities); Y's columns T.. are zero-filled."""
+    X: torch.Tensor      # fp32 [rows, >=T] (row stride = X.stride(0))
+    Y: torch.Tensor      # bf16 [rows, ldy >= T] contiguous rows
+    T: int
+    scale: float = 1.0
+    name: str = ""
+    opcode = L.OP_SOFTMAX
+
+    def lower(self):
+        _chk(self.X.dtype == F32 and self.Y.dtype == BF16 and self.X.dim() == 2 and self.Y.dim() == 2, "softmax: dtypes / rank")
+        _chk(self.X.stride(1) == 1 and self.Y.stride(1) == 1 and self.X.shape[0] == self.Y.shape[0], "softmax: layout")
+        _chk(0 < self.T <= self.X.shape[1] and self.T <= self.Y.shape[1], "softmax: T")
+        d = L.MdxSoftmaxDesc()
+        d.X, d.Y, d.rows, d.T, d.ldx, d.ldy, d.scale = _p(self.X), _p(self.Y), self.X.shape[0], self.T, self.X.stride(0), self.Y.stride(0), float(self.scale)
+        # the kernel zero-fills Y[:, T:ldy]: Y must own its whole row pitch
+        _chk(self.Y.shape[1] == self.Y.stride(0), "softmax: Y rows must be dense (the pad columns are written)")
+        return self.opcode, d
+
+
+@dataclass
 class Ew:
     """kind in {ADD (Y += X), COPY, SILU, SCALE} on [M,C] views."""
     kind: int

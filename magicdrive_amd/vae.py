@@ -1,0 +1,133 @@
+"""VAE decode as an op program on the same HIP kernels as the sampler.
+
+AutoencoderKL.decode = post_quant_conv (1x1) -> Decoder (dif:models/vae.py:152-275): conv_in, mid block (resnet, single-head
+512-channel attention, resnet), four UpDecoderBlock2D (3 resnets + nearest x2 + conv), GroupNorm + SiLU + conv_out.
+Everything is GroupNorm(+SiLU) / 3x3 conv / 1x1 GEMM / nearest upsample — kernels the UNet path already has — except the mid-block
+attention: one head of dim C = 512 is outside the fused attention kernel's head-dim range, so it is spelled out on the GEMM kernel:
+S = Q K^T (fp32 out), P = softmax(S / sqrt(C)) (mdx_softmax_rows), O = P V with V^T from the "W_v as A" GEMM; to_v's bias is folded
+through the softmax (rows of P sum to 1) into to_out's bias.  One plan decodes `n_img` latents of a fixed size (the pipeline runs
+it once per scene: 6 views), channels-last bf16 activations like the rest of the library.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+from . import _lib as L
+from . import ops as O
+from . import packing as PK
+from .engine import PackedNet
+
+BF16, F32 = torch.bfloat16, torch.float32
+ZPAD = 8      # latent channels padded 4 -> 8 so conv_in runs on the MFMA path
+
+
+class VaeDecodePlan:
+    def __init__(self, vcfg, net: PackedNet, device, n_img: int, latent_hw):
+        self.vcfg, self.device, self.n = vcfg, device, n_img
+        h, w = latent_hw
+        G, eps = vcfg["norm_num_groups"], 1e-6
+        zc = vcfg["latent_channels"]
+        self.ops: List[object] = []
+        self.keep: List[torch.Tensor] = []
+        self.ws = torch.empty(64 * 1024 * 1024 // 4, dtype=F32, device=device)
+        emit = self.ops.append
+
+        def buf(*shape, dtype=BF16, zero=False):
+            t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=device)
+            self.keep.append(t)
+            return t
+
+        def gn(x, pre, silu):                  # x [n, H, W, C]
+            y = buf(*x.shape)
+            n_, H, W, C = x.shape
+            emit(O.GroupNorm(x.view(n_, H * W, C), y.view(n_, H * W, C), net.vec(pre + "weight"), net.vec(pre + "bias"), G, eps, silu, ws=self.ws, name="vae." + pre))
+            return y
+
+        def conv3(x, key, R=None, name=""):
+            wt = net.conv(key + "weight")
+            y = buf(x.shape[0], x.shape[1], x.shape[2], wt.shape[0])
+            emit(O.Conv(x, wt, y, bias=net.vec(key + "bias"), R=R, ws=self.ws, name="vae." + key))
+            return y
+
+        def resnet(x, pre):
+            """ResnetBlock2D without temb (dif:models/resnet.py:590-640)."""
+            a = gn(x, pre + "norm1.", True)
+            hcv = conv3(a, pre + "conv1.")
+            b = gn(hcv, pre + "norm2.", True)
+            sc = x
+            if net.has(pre + "conv_shortcut.weight"):
+                cout = net.sd[pre + "conv_shortcut.weight"].shape[0]
+                sc = buf(x.shape[0], x.shape[1], x.shape[2], cout)
+                emit(O.Gemm(x.view(-1, x.shape[3]), net.lin(pre + "conv_shortcut.weight"), sc.view(-1, cout), bias=net.vec(pre + "conv_shortcut.bias"),
+                            ws=self.ws, name="vae." + pre + "shortcut"))
+            return conv3(b, pre + "conv2.", R=sc)
+
+        # ---- input: z (already / scaling_factor) fp32 NCHW -> post_quant_conv -> bf16 NHWC padded to ZPAD channels
+        self.z_in = torch.zeros(n_img, zc, h, w, dtype=F32, device=device)
+        z_nhwc = buf(n_img, h, w, zc, dtype=F32)
+        emit(O.Layout(self.z_in, z_nhwc, True, name="vae.z.nhwc"))
+        zq = buf(n_img, h, w, ZPAD, zero=True)
+        emit(O.Conv(z_nhwc, net.conv("post_quant_conv.weight"), zq[..., :zc], bias=net.vec("post_quant_conv.bias"), stride=(1, 1), pad=(0, 0),
+                    direct=True, name="vae.post_quant_conv"))
+        top = net.sd["decoder.conv_in.weight"].shape[0]
+        x = buf(n_img, h, w, top)
+        emit(O.Conv(zq, net.conv_cin_padded("decoder.conv_in.weight", ZPAD), x, bias=net.vec("decoder.conv_in.bias"), ws=self.ws, name="vae.conv_in"))
+        # ---- mid block
+        x = resnet(x, "decoder.mid_block.resnets.0.")
+        x = self._attention(net, x, "decoder.mid_block.attentions.0.", G, eps, buf, emit)
+        x = resnet(x, "decoder.mid_block.resnets.1.")
+        # ---- up blocks
+        nlev = len(vcfg["block_out_channels"])
+        for i in range(nlev):
+            for j in range(vcfg["layers_per_block"] + 1):
+                x = resnet(x, f"decoder.up_blocks.{i}.resnets.{j}.")
+            if i != nlev - 1:
+                H2, W2 = 2 * x.shape[1], 2 * x.shape[2]
+                up = buf(n_img, H2, W2, x.shape[3])
+                emit(O.Upsample(x, up, PK.nearest_index(x.shape[1], H2).to(device), PK.nearest_index(x.shape[2], W2).to(device), name=f"vae.up{i}.nearest"))
+                x = conv3(up, f"decoder.up_blocks.{i}.upsamplers.0.conv.")
+        x = gn(x, "decoder.conv_norm_out.", True)
+        oc = vcfg["out_channels"]
+        self.out_nhwc = buf(n_img, x.shape[1], x.shape[2], oc, dtype=F32)
+        emit(O.Conv(x, net.conv("decoder.conv_out.weight"), self.out_nhwc, bias=net.vec("decoder.conv_out.bias"), direct=True, name="vae.conv_out"))
+        self.program = None
+
+    def _attention(self, net, x, a, G, eps, buf, emit):
+        """Attention(heads=1, dim_head=C, group_norm, bias, residual_connection) with the vanilla processor
+        (attention_processor.py:495-558; unet_2d_blocks.py:433-445)."""
+        n, H, W, C = x.shape
+        T = H * W
+        Tp = PK.round_up(T, 8)
+        t = buf(n, H, W, C)
+        emit(O.GroupNorm(x.view(n, T, C), t.view(n, T, C), net.vec(a + "group_norm.weight"), net.vec(a + "group_norm.bias"), G, eps, False, ws=self.ws, name="vae.attn.gn"))
+        qk = buf(n * T, 2 * C)
+        emit(O.Gemm(t.view(n * T, C), net.cat_lin([a + "to_q.weight", a + "to_k.weight"]), qk, bias=net.cat_vec([a + "to_q.bias", a + "to_k.bias"]),
+                    ws=self.ws, name="vae.attn.qk"))
+        vt = buf(n, C, Tp, zero=True)                                            # V^T (bias folded into the output projection)
+        emit(O.Gemm(net.lin(a + "to_v.weight"), t.view(n, T, C), vt[:, :, :T], name="vae.attn.vT"))
+        qk3 = qk.view(n, T, 2 * C)
+        S = buf(n, T, Tp, dtype=F32)
+        emit(O.Gemm(qk3[:, :, :C], qk3[:, :, C:], S[:, :, :T], name="vae.attn.scores"))       # [n][T][T] fp32
+        P = buf(n * T, Tp)
+        emit(O.Softmax(S.view(n * T, Tp), P, T, scale=float(C) ** -0.5, name="vae.attn.softmax"))
+        o = buf(n, T, C)
+        emit(O.Gemm(P.view(n, T, Tp), vt, o, name="vae.attn.pv"))
+        # to_out(o + b_v) + b_o = W_o o + (W_o b_v + b_o); residual add of the block input
+        wo = net.lin(a + "to_out.0.weight")
+        bo = net._get("vae_attn_bias", [a + "to_out.0.weight", a + "to_out.0.bias", a + "to_v.bias"], lambda w, b, bv: (w @ bv + b).contiguous().to(F32))
+        y = buf(n, H, W, C)
+        emit(O.Gemm(o.view(n * T, C), wo, y.view(n * T, C), bias=bo, R=x.view(n * T, C), ws=self.ws, name="vae.attn.out"))
+        return y
+
+    def compile(self):
+        self.program = O.build_program(self.ops)
+
+    def run(self, z: torch.Tensor) -> torch.Tensor:
+        """z (n_img, 4, h, w), already divided by the scaling factor -> images (n_img, 3, 8h, 8w) fp32, un-clamped."""
+        if self.program is None:
+            self.compile()
+        self.z_in.copy_(z.to(self.device, F32))
+        self.program.run(torch.cuda.current_stream().cuda_stream)
+        return self.out_nhwc.permute(0, 3, 1, 2).contiguous()

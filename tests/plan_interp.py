@@ -207,9 +207,15 @@ def run_unipc(op: O.UniPCStep):
     op.step += 1
 
 
+def run_softmax(op: O.Softmax):
+    y = torch.softmax(op.X[:, :op.T].float() * op.scale, dim=-1)
+    op.Y.zero_()
+    op.Y[:, :op.T].copy_(y.to(op.Y.dtype))
+
+
 DISPATCH = {O.Gemm: run_gemm, O.Conv: run_conv, O.Attn: run_attn, O.GroupNorm: run_groupnorm, O.LayerNorm: run_layernorm,
             O.Ew: run_ew, O.Upsample: run_upsample, O.Layout: run_layout, O.Fourier: run_fourier, O.Gather: run_gather,
-            O.TimeEmb: run_timeemb, O.DdimStep: run_ddim, O.UniPCStep: run_unipc}
+            O.TimeEmb: run_timeemb, O.DdimStep: run_ddim, O.UniPCStep: run_unipc, O.Softmax: run_softmax}
 
 
 def run(ops, lower_check: bool = True):

@@ -25,7 +25,7 @@ def test_library_loads_and_exports_header_symbols():
 
 def test_ctypes_structs_match_c_sizes(tmp_path):
     names = ["MdxGemmDesc", "MdxConvDesc", "MdxConvDirectDesc", "MdxAttnDesc", "MdxGroupNormDesc", "MdxLayerNormDesc",
-             "MdxEwDesc", "MdxFourierDesc", "MdxGatherDesc", "MdxTimeEmbDesc", "MdxDdimDesc", "MdxUniPCDesc", "MdxOp"]
+             "MdxEwDesc", "MdxFourierDesc", "MdxGatherDesc", "MdxTimeEmbDesc", "MdxDdimDesc", "MdxUniPCDesc", "MdxSoftmaxDesc", "MdxOp"]
     c = tmp_path / "sz.c"
     c.write_text('#include <stdio.h>\n#include "mdx.h"\nint main(){' + "".join(f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}")
     exe = tmp_path / "sz"

@@ -204,6 +204,20 @@ def test_given_view_pipeline_matches_reference_golden(dev, every):
     assert e < 5e-2
 
 
+def test_vae_decode_matches_diffusers_golden(dev):
+    """AutoencoderKL.decode as an op program (mid-block attention = GEMM / softmax / GEMM) vs diffusers' output."""
+    import os
+    from magicdrive_amd.networks.autoencoder_kl import AutoencoderKL
+    G = torch.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_vae_decode.pt"))
+    vae = AutoencoderKL.from_config(spec.VAE_TINY_CONFIG, G["weights_seed"]).to(dev)
+    z = torch.randn(2, 4, 7, 13, generator=torch.Generator().manual_seed(G["z_seed"]))
+    img = vae.decode(z.to(dev)).sample
+    torch.cuda.synchronize()
+    e = rel_l2(img, G["image"].float())
+    print(f"[VAE decode vs diffusers golden] rel L2 {e:.4f}")
+    assert img.shape == (2, 3, 56, 104) and e < 3e-2
+
+
 def test_module_api_forward_hires_plus_map_encoder(dev):
     """BASELINE.json configs[3] shape on the GPU: 432x768 (54x96 latents, T0 = 5184 tokens) with the ...Plus map encoder, through the
     reference module signatures, vs outputs of the REAL reference modules (tests/golden/tiny_forward_hires.pt)."""

@@ -433,6 +433,18 @@ def test_cfg_ddim_and_graph_replay(dev):
     assert torch.allclose(x.cpu(), ref_step(r1, coef[1].cpu()), atol=1e-5) and step.item() == 2
 
 
+@pytest.mark.parametrize("rows,T,ld", [(91 * 2, 91, 96), (300, 1400, 1400), (5, 7, 8)])
+def test_softmax_rows(dev, rows, T, ld):
+    """mdx_softmax_rows: fp32 scores (row pitch ld) -> bf16 probabilities, pad columns written as zeros."""
+    X = torch.randn(rows, ld, generator=torch.Generator().manual_seed(1)).mul(3.0).to(dev)
+    Y = torch.full((rows, ld), float("nan"), dtype=BF, device=dev)
+    O.run_ops([O.Softmax(X, Y, T, scale=0.37)])
+    torch.cuda.synchronize()
+    ref = torch.softmax(X[:, :T].cpu() * 0.37, dim=-1)
+    assert torch.allclose(Y[:, :T].float().cpu(), ref, atol=2e-3, rtol=1e-2)
+    assert (Y[:, T:].float() == 0).all() and abs(Y[:, :T].float().sum(-1).mean().item() - 1.0) < 5e-3
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_cfg_ddim_given_views(dev, mode):
     """MdxDdimDesc.gv_*: views 1 and 4 of 6 are known.  Mode 1: after every step but the last they are replaced by

@@ -203,6 +203,18 @@ def test_golden_pipeline_given_view(tiny, every):
     assert rel_l2(out, gold) < 2e-4, rel_l2(out, gold)
 
 
+def test_golden_vae_decode():
+    """the restated AutoencoderKL.decode vs diffusers' (tests/golden/tiny_vae_decode.pt)."""
+    G = torch.load(os.path.join(GOLD, "tiny_vae_decode.pt"))
+    vcfg = spec.VAE_TINY_CONFIG
+    sd = spec.random_state_dict(spec.vae_decoder_param_shapes(vcfg), G["weights_seed"])
+    assert abs(_checksum(sd) - G["checksum"]) < 1e-6 * G["checksum"]
+    z = torch.randn(2, 4, 7, 13, generator=torch.Generator().manual_seed(G["z_seed"]))
+    with torch.no_grad():
+        img = D.vae_decode(sd, vcfg, z)
+    assert img.shape == (2, 3, 56, 104) and rel_l2(img, G["image"].float()) < 1e-3      # golden stored as fp16
+
+
 def test_golden_forward_hires_plus_map_encoder(tiny):
     """BASELINE.json configs[3] shape (432x768 -> 54x96 latents, BEVControlNetConditioningEmbeddingPlus): the oracle vs the real
     reference modules (tests/golden/tiny_forward_hires.pt, tools/make_golden.py hires)."""

@@ -154,6 +154,19 @@ def test_module_plans_hires_plus_map_encoder(tiny):
         DN.ControlNetPlan(cfg0, cn, CPU, 1, 3, hw)
 
 
+def test_vae_decode_plan_matches_golden():
+    """The VAE decode op program (mid-block attention spelled out as GEMM / softmax / GEMM) in the CPU interpreter vs diffusers' output."""
+    from magicdrive_amd.vae import VaeDecodePlan
+    G = torch.load(os.path.join(GOLD, "tiny_vae_decode.pt"))
+    vcfg = spec.VAE_TINY_CONFIG
+    sd = spec.random_state_dict(spec.vae_decoder_param_shapes(vcfg), G["weights_seed"])
+    plan = VaeDecodePlan(vcfg, PackedNet(sd, CPU), CPU, 2, (7, 13))
+    plan.z_in.copy_(torch.randn(2, 4, 7, 13, generator=torch.Generator().manual_seed(G["z_seed"])))
+    plan_interp.run(plan.ops)
+    img = plan.out_nhwc.permute(0, 3, 1, 2)
+    assert rel_l2(img, G["image"].float()) < 3e-2, rel_l2(img, G["image"].float())
+
+
 def test_fused_qkv_op_equals_separate_projections():
     """The level-0 fused q/k/v op (engine.self_like_attention) in the CPU interpreter == the q/k GEMM + batched V^T GEMM it replaces."""
     import magicdrive_amd.ops as O

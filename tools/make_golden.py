@@ -21,7 +21,10 @@ Fixtures
   tiny_pipeline_given_view.pt  StableDiffusionBEVControlNetGivenViewPipeline.__call__ (reference), 5 DDIM steps, guidance 2.0, views 0 and 3
                     of scene 0 and view 5 of scene 1 given; both `conditional_latents_change_every_input` modes.
 
-`python tools/make_golden.py unipc` / `... hires` / `... given` regenerate only that fixture.
+  tiny_vae_decode.pt  diffusers AutoencoderKL.decode (the reference's `vae`, pipeline_bev_controlnet.py:100-112) of a tiny decoder config
+                    (spec.VAE_TINY_CONFIG, seeded weights) on 2 latents of 7x13.
+
+`python tools/make_golden.py unipc` / `... hires` / `... given` / `... vae` regenerate only that fixture.
 """
 import os
 import sys
@@ -78,6 +81,24 @@ def given_view_fixture(out_dir, cfg, usd, csd, meta, hw=(28, 50)):
     print("tiny_pipeline_given_view: |x|", outs[True].abs().mean().item(), outs[False].abs().mean().item())
 
 
+def vae_fixture(out_dir):
+    from oracle import refshim
+    ns = refshim.load()
+    vcfg = spec.VAE_TINY_CONFIG
+    sd = spec.random_state_dict(spec.vae_decoder_param_shapes(vcfg), 5)
+    vae = ns.diffusers.AutoencoderKL(in_channels=3, out_channels=vcfg["out_channels"], block_out_channels=vcfg["block_out_channels"],
+                                     down_block_types=("DownEncoderBlock2D",) * 4, up_block_types=("UpDecoderBlock2D",) * 4,
+                                     latent_channels=vcfg["latent_channels"], norm_num_groups=vcfg["norm_num_groups"],
+                                     layers_per_block=vcfg["layers_per_block"]).eval()
+    missing, unexpected = vae.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith(("encoder.", "quant_conv.")) for k in missing), (missing[:3], unexpected[:3])
+    z = torch.randn(2, 4, 7, 13, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        img = vae.decode(z).sample
+    torch.save({"z_seed": 3, "weights_seed": 5, "checksum": checksum(sd), "image": img.half()}, os.path.join(out_dir, "tiny_vae_decode.pt"))
+    print("tiny_vae_decode:", tuple(img.shape), "|x|", img.abs().mean().item())
+
+
 def hires_fixture(out_dir, cfg0, usd, csd, meta, hw=(54, 96)):
     cfg = spec.with_plus_map_embedder(cfg0, hw)
     ns, unet, cnet = ref_models.build_reference(cfg, usd, csd, img_size=(hw[0] * 8, hw[1] * 8))
@@ -107,6 +128,8 @@ def main():
         return hires_fixture(out_dir, cfg, usd, csd, meta)
     if sys.argv[1:] == ["given"]:
         return given_view_fixture(out_dir, cfg, usd, csd, meta)
+    if sys.argv[1:] == ["vae"]:
+        return vae_fixture(out_dir)
 
     # ---- module-level forwards
     ns, unet, cnet = ref_models.build_reference(cfg, usd, csd)
@@ -142,6 +165,7 @@ def main():
     unipc_fixture(out_dir, cfg, usd, csd, meta, hw)
     hires_fixture(out_dir, cfg, usd, csd, meta)
     given_view_fixture(out_dir, cfg, usd, csd, meta)
+    vae_fixture(out_dir)
     for f in os.listdir(out_dir):
         print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")
 
