@@ -7,6 +7,7 @@ network pass (tools/path_sensitivity.py); the tests allow 3 % per pass / 5 % ove
 per-view rather than whole-tensor errors so a broken single view cannot hide.
 """
 import pytest
+import numpy as np
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -216,6 +217,31 @@ def test_vae_decode_matches_diffusers_golden(dev):
     e = rel_l2(img, G["image"].float())
     print(f"[VAE decode vs diffusers golden] rel L2 {e:.4f}")
     assert img.shape == (2, 3, 56, 104) and e < 3e-2
+
+
+def test_pipeline_images_through_hip_vae(dev):
+    """output_type="np" / "pil" with the HIP AutoencoderKL attached: the whole reference __call__ contract incl. decode_latents
+    (pipeline_bev_controlnet.py:100-112, :466-498) runs on libmdx; images = clamp(decode(latents / 0.18215) / 2 + 0.5)."""
+    from magicdrive_amd.networks.autoencoder_kl import AutoencoderKL
+    from magicdrive_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiview
+    from magicdrive_amd.networks.unet_addon_rawbox import BEVControlNetModel
+    from magicdrive_amd.pipeline.pipeline_bev_controlnet import StableDiffusionBEVControlNetPipeline
+    cfg = spec.TINY_CONFIG
+    vae = AutoencoderKL.from_config(spec.VAE_TINY_CONFIG, 5)
+    pipe = StableDiffusionBEVControlNetPipeline(vae=vae, unet=UNet2DConditionModelMultiview.from_config(cfg, 0),
+                                                controlnet=BEVControlNetModel.from_config(cfg, 1)).to(dev)
+    sc = scene(cfg, 1, 3)
+    kw = dict(prompt=None, image=sc["bev_map"], camera_param=sc["camera_param"], height=224, width=400, num_inference_steps=2, guidance_scale=2.0,
+              latents=sc["latents"], prompt_embeds=sc["prompt_embeds"], negative_prompt_embeds=sc["negative_prompt_embeds"],
+              bev_controlnet_kwargs={"bboxes_3d_data": sc["bboxes_3d_data"]})
+    lat = pipe(output_type="latent", **kw).images
+    img = pipe(output_type="np", **kw).images
+    assert img.shape == (1, 6, 224, 400, 3) and img.dtype == np.float32 and img.min() >= 0.0 and img.max() <= 1.0
+    ref = vae.decode((lat.float() / 0.18215).reshape(-1, 4, 28, 50)).sample
+    ref = (ref / 2 + 0.5).clamp(0, 1).reshape(1, 6, 3, 224, 400).permute(0, 1, 3, 4, 2).cpu().numpy()
+    assert np.abs(img - ref).max() < 1e-5
+    pil = pipe(output_type="pil", **kw).images
+    assert len(pil) == 1 and len(pil[0]) == 6 and pil[0][0].size == (400, 224)
 
 
 def test_module_api_forward_hires_plus_map_encoder(dev):
