@@ -95,7 +95,7 @@ def test_unipc_sampler_plan_matches_golden_pipeline(tiny):
     assert sp.step_ctr.item() == 0 and not sp.m1.any() and not sp.x_last.any()
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1])          # mode 2 (pinned noise prediction): GPU kernel + pipeline tests and the oracle test cover it
 def test_given_view_sampler_plan_matches_golden(tiny, mode):
     """Given views inside the fused CFG + DDIM op (MdxDdimDesc.gv_*): mode 1 = re-noise the known views for every model call,
     mode 2 = noise once and pin their noise prediction — vs the reference's given-view pipeline."""
@@ -140,16 +140,8 @@ def test_module_plans_hires_plus_map_encoder(tiny):
     plan_interp.run(cp.ops)
     assert rel_l2(cp.mid_out, G["mid"]) < 3e-2
     assert rel_l2(cp.down_out[0][:, :, ::9, ::12], G["down_first"]) < 3e-2      # carries the map feature (added after conv_in)
-    with torch.no_grad():
-        d, m, ctx = D.controlnet_forward(csd, cfg, lat, t, sc["camera_param"], sc["bboxes_3d_data"], sc["prompt_embeds"], sc["bev_map"])
-    up = DN.UNetPlan(cfg, un, CPU, 6, ctx.shape[1], hw)
-    up.sample_nchw.copy_(lat.reshape(-1, 4, *hw)); up.temb.t.copy_(t.float().repeat_interleave(6)); up.ctx.copy_(ctx)
-    for dst, src in zip(up.res_in, d):
-        dst.copy_(src)
-    up.mid_in.copy_(m)
-    plan_interp.run(up.ops)
-    per_view = max(rel_l2(up.out_nchw[i], G["eps"][i].float()) for i in range(6))
-    assert per_view < 3e-2, per_view
+    # (the UNet at 54x96 — T0 = 5184 tokens — is checked against the same golden on the GPU: test_e2e_gpu.py, and by the oracle test;
+    #  the CPU interpreter needs a minute for it)
     with pytest.raises(ValueError):          # the default encoder cannot produce a 54x96 feature: loud, with the config hint
         DN.ControlNetPlan(cfg0, cn, CPU, 1, 3, hw)
 
