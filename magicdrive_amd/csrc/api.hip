@@ -6,6 +6,9 @@
 // ~1.2k-launch reference step — per-replay variation (the DDIM step index) lives in
 // device memory (sel_ptr / step_ptr), never in kernel arguments.
 #include <cstring>
+#include <mutex>
+#include <set>
+#include <utility>
 #include "launch.h"
 
 namespace mdx {
@@ -16,6 +19,20 @@ char* error_buffer() {
 char* kernel_tag_buffer() {
     static thread_local char buf[128] = {0};
     return buf;
+}
+int ensure_dyn_smem(const void* kernel, size_t bytes, const char* what) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return set_error(MDX_ELAUNCH, "hipGetDevice: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> lk(mu);
+    const auto key = std::make_pair(kernel, dev);
+    if (done.count(key)) return MDX_OK;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return set_error(MDX_ELAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+    done.insert(key);
+    return MDX_OK;
 }
 }  // namespace mdx
 

@@ -189,12 +189,7 @@ int launch_conv3x3(const GCParams& p, hipStream_t st) {
     constexpr int BM = 128, BN = 128;
     constexpr size_t ring = (size_t)2 * (130 + 128) * 72 * 2, ctile = (size_t)BM * (BN + 8) * 2;
     constexpr size_t smem = ring > ctile ? ring : ctile;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return set_error(MDX_ELAUNCH, "hipFuncSetAttribute(conv3x3): %s", hipGetErrorString(e));
-        attr_done = true;
-    }
+    if (int rc = ensure_dyn_smem((const void*)conv3x3_kernel, smem, "conv3x3")) return rc;
     GCParams q = p;
     q.mt = (p.M + BM - 1) / BM; q.nt = (p.N + BN - 1) / BN;
     static const int swz = [] { const char* e = getenv("MDX_GEMM_SWZ"); return e ? atoi(e) : 1; }();

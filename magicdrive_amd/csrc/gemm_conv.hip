@@ -36,6 +36,8 @@ bool conv3x3_supported(const GCParams& p);
 int launch_gemm_ws(const GCParams& p, hipStream_t st);                          // gemm_ws.hip: weight-stationary K = 320 GEMM
 bool ws_supported(const GCParams& p);
 void pp_tile_dims(int cfg, int* bm, int* bn);
+int launch_gemm_xl(const GCParams& p, bool conv, int bn, hipStream_t st);       // gemm_xl.hip: 256 x {256,160} LDS-DMA quadrant-phase tiles
+bool xl_supported(const GCParams& p, bool conv, int bn);
 
 // WM x WN waves (NTH = 64 WM WN threads); each wave owns a (BM/WM) x (BN/WN) sub-tile of 32x32 MFMA tiles.
 template <int BM, int BN, int BK, int WM, int WN, bool CONV, bool PIPE>
@@ -311,13 +313,8 @@ template <int BM, int BN, int BK, int WM, int WN, bool CONV, bool PIPE>
 static int launch_one_(const GCParams& p, hipStream_t st) {
     constexpr size_t ring = (size_t)2 * (BM + BN) * (BK + 8) * sizeof(bf16_t), ctile = (size_t)BM * (BN + 8) * 2;
     constexpr size_t smem = ring > ctile ? ring : ctile;
-    static bool attr_done = false;
     auto kern = gemm_conv_kernel<BM, BN, BK, WM, WN, CONV, PIPE>;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return set_error(MDX_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
-    }
+    if (int rc = ensure_dyn_smem((const void*)kern, smem, "gemm_conv")) return rc;
     GCParams q = p;
     q.mt = (p.M + BM - 1) / BM; q.nt = (p.N + BN - 1) / BN;
     static const int swz = [] { const char* e = getenv("MDX_GEMM_SWZ"); return e ? atoi(e) : 1; }();
@@ -359,7 +356,27 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
     // K = 320 projections with many rows: weights in registers, activations streamed (gemm_ws.hip).  MDX_GEMM_WS: 0 off, 1 when
     // M >= 8192 (default), 2 whenever supported.
     static const int ws_mode = [] { const char* e = getenv("MDX_GEMM_WS"); return e ? atoi(e) : 1; }();
-    if (impl == 0 && !conv && ws_mode > 0 && p.splitk <= 1 && ws_supported(p) && (ws_mode >= 2 || p.M >= 8192))
+    // Large shapes: the LDS-DMA quadrant-phase kernel (gemm_xl.hip).  MDX_GEMM_XL: 0 off, 1 cost model (default), 2 whenever supported.
+    // Tile width: 256 columns, or 160 when that wastes fewer padded columns (N = 320 / 640 / 960 / 1920); a launch must give most of
+    // the 256 CUs a tile (one workgroup per CU).  MDX_XL_K320 = 1 lets it take the K = 320 projections from gemm_ws.hip as well.
+    static const int xl_mode = [] { const char* e = getenv("MDX_GEMM_XL"); return e ? atoi(e) : 1; }();
+    static const int xl_k320 = [] { const char* e = getenv("MDX_XL_K320"); return e ? atoi(e) : 0; }();
+    static const int xl_min_tiles = [] { const char* e = getenv("MDX_XL_MIN_TILES"); return e ? atoi(e) : 160; }();
+    auto try_xl = [&](int& bn_out) -> bool {
+        if (impl != 0 || xl_mode <= 0 || p.splitk > 1) return false;
+        double best = 1e300;
+        bn_out = 0;
+        for (int bn : {256, 160}) {
+            if (!xl_supported(p, conv, bn)) continue;
+            const long t = (long)((p.M + 255) / 256) * ((p.N + bn - 1) / bn);
+            if (xl_mode < 2 && t < xl_min_tiles) continue;
+            const double c = (double)((t + 255) / 256) * 256.0 * bn * (bn == 160 ? 1.12 : 1.0);   // rounds x tile area / relative efficiency
+            if (c < best) { best = c; bn_out = bn; }
+        }
+        return bn_out != 0;
+    };
+    const bool ws_first = !conv && ws_mode > 0 && p.splitk <= 1 && ws_supported(p) && (ws_mode >= 2 || p.M >= 8192);
+    if (impl == 0 && ws_first && !(xl_k320 && xl_mode > 0))
         return launch_gemm_ws(p, st);
     int BM, BN, tile = -1;
     if (impl == 0) {
@@ -413,6 +430,11 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
     // the 256 x 256 tile is 1.16-1.25x the 128 x 128 kernel per FLOP when N % 256 == 0 and K >= 1024 (N = 1280 convs 763 -> 888,
     // end to end at 64 scenes/GPU: +3.2 % with gain 1.18, +3.8 % with 1.5 — the default);
     // 612 -> 764 TFLOP/s); the 256 x 320 tile (N = 320 / 640) spills and loses, so it is opt-in (MDX_PP_CFG1=1).
+    if (splitk == 1) {
+        int bn_xl;
+        if (try_xl(bn_xl)) return launch_gemm_xl(p, conv, bn_xl, st);
+    }
+    if (impl == 0 && ws_first) return launch_gemm_ws(p, st);       // MDX_XL_K320 was set but the XL kernel declined the shape
     static const int pp_mode = [] { const char* e = getenv("MDX_GEMM_PP"); return e ? atoi(e) : 1; }();
     static const double pp_gain = [] { const char* e = getenv("MDX_PP_GAIN"); return e ? atof(e) : 1.5; }();
     static const int pp_cfg1 = [] { const char* e = getenv("MDX_PP_CFG1"); return e ? atoi(e) : 0; }();

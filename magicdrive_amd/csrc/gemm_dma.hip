@@ -237,13 +237,8 @@ template <int BM, int BN, int WM, int WN, int BK, int ST, bool CONV>
 static int launch_dma_one(const GCParams& p, hipStream_t st) {
     constexpr size_t ring = (size_t)ST * (BM + BN) * BK * 2, ctile = (size_t)BM * (BN + 8) * 2;   // the C tile reuses the ring
     constexpr size_t smem = ring > ctile ? ring : ctile;
-    static bool attr_done = false;
     auto kern = gemm_dma_kernel<BM, BN, WM, WN, BK, ST, CONV>;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return set_error(MDX_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
-    }
+    if (int rc = ensure_dyn_smem((const void*)kern, smem, "dma")) return rc;
     GCParams q = p;
     q.mt = (p.M + BM - 1) / BM; q.nt = (p.N + BN - 1) / BN; q.swz = 0;
     dim3 grid((unsigned)(q.mt * q.nt), 1, p.batch > 1 ? p.batch : p.splitk);

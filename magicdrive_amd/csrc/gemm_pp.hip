@@ -397,13 +397,8 @@ static int launch_pp(const GCParams& p, hipStream_t st) {
     constexpr size_t smem = (size_t)2 * (BM + BN) * 64 * sizeof(bf16_t) + (size_t)PP_SLOTS * BN * sizeof(float);
     static_assert(smem <= 163840, "LDS budget");
     static_assert((size_t)128 * (BN + 8) * 2 <= (size_t)2 * (BM + BN) * 64 * 2, "C staging must fit the operand ring");
-    static bool attr_done = false;
     auto kern = gemm_pp_kernel<WM, WN, TM, TN, CONV, EARLY>;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return set_error(MDX_ELAUNCH, "hipFuncSetAttribute(pp): %s", hipGetErrorString(e));
-        attr_done = true;
-    }
+    if (int rc = ensure_dyn_smem((const void*)kern, smem, "pp")) return rc;
     GCParams q = p;
     q.mt = (p.M + BM - 1) / BM; q.nt = (p.N + BN - 1) / BN;
     static const int swz = [] { const char* e = getenv("MDX_GEMM_SWZ"); return e ? atoi(e) : 1; }();

@@ -304,13 +304,8 @@ template <bool GEGLU, bool VT>
 static int launch_ws_one(const GCParams& p, hipStream_t st) {
     constexpr int ST = 3;
     const size_t smem = (size_t)ST * 128 * 64 * 2 + (size_t)128 * (64 + 8) * 2;   // ring + staging (also holds 64 x 136 and the transposed 128 x 72)
-    static bool attr_done = false;
     auto kern = gemm_ws_kernel<GEGLU, ST, VT>;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return set_error(MDX_ELAUNCH, "hipFuncSetAttribute(ws): %s", hipGetErrorString(e));
-        attr_done = true;
-    }
+    if (int rc = ensure_dyn_smem((const void*)kern, smem, "ws")) return rc;
     GCParams q = p;
     q.mt = (p.M + 127) / 128; q.nt = (p.N + 127) / 128;
     // walkers per N-tile: fill the 512 workgroup slots (2 per CU), multiple of 8 (one XCD per walker), at most one per M-tile

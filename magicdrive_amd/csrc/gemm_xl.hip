@@ -1,0 +1,496 @@
+// gemm_xl.hip — the large-shape bf16 MFMA GEMM / implicit-GEMM convolution main loop for gfx950: 256 x {256,160} x 64 tiles,
+// operands global -> LDS by LDS-DMA, quadrant phases, counted vmcnt, two wave groups staggered by one barrier.
+//
+// Why a third main loop (after gemm_conv.hip's 128x128 register-staged tile and gemm_pp.hip's register-staged ping-pong):
+// round 1 measured both as bound by the global -> register -> LDS staging path (profiles/README.md: ~32 B/clk per CU, a load phase
+// of 1.2-1.7 k cycles beside 1.0 k cycles of MFMA issue).  Here nothing is staged through registers:
+//   * every operand byte goes global -> LDS with `buffer_load_dwordx4 ... lds` (1 KiB per wave instruction, full 128-byte lines per
+//     row), the XOR swizzle that makes the ds_read_b128 fragment reads conflict-free is applied on the SOURCE address
+//     (xl_layout.h); conv zero padding / row tails are lanes whose voffset is out of the descriptor's range (the DMA writes zeros);
+//   * a K slab (64 deep) is four load units — A0, B0, B1, A1: the rows the four quadrant phases of a wave tile read first.  A unit's
+//     LDS slot is refilled one phase after its last fragment read, for the slab TWO ahead, so three units are always in flight
+//     and the only wait in the loop is ONE counted `s_waitcnt vmcnt(3 units)` per slab (never a drain);
+//   * a phase = {fragment reads of one quadrant + the unit refill} | s_barrier | {MFMAs of the quadrant} | s_barrier.  Waves 0-3
+//     and 4-7 (w and w + 4 share a SIMD) run the same sequence shifted by one barrier: one group's MFMA segment is the other
+//     group's LDS / DMA segment ("matrix beside memory", MI355X_MICROARCH.md "Two waves per SIMD"); s_setprio 1 around the MFMAs;
+//   * fragments are read ONCE per slab (A half 32 + both B parts in registers beside the accumulators).
+// Reduction order per output element: k ascending in 32-wide MFMA steps (conv: (channel block, ky, kx) slabs), fp32 accumulation —
+// a permutation of gemm_conv.hip's order for conv, identical for GEMM.
+//
+// Epilogue: bias (+ the per-(step, image) temb row) staged once per tile as fp32 addend rows in LDS; applied in registers with
+// SiLU / GEGLU; the bf16 tile is transposed through LDS (whole 256-row tile at once: the operand ring is dead) and written as
+// 16-byte row segments with the residual added — same arithmetic per element as gemm_conv.hip / gemm_pp.hip.
+//
+// Replaces (through mdx_gemm_bf16 / mdx_conv2d_bf16, include/mdx.h): ATen addmm / conv2d of ResnetBlock2D (resnet.py:590-640),
+// Down/Upsample2D convs (resnet.py:165-170, 198-222), the transformer projections and feed-forward (attention.py:200-280,
+// attention_processor.py:141-157) at shapes with >= ~200 tiles.
+#include "common.h"
+#include "launch.h"
+#include "gemm_params.h"
+#include "xl_layout.h"
+#include <cstdlib>
+
+namespace mdx {
+
+using namespace mdx_xl;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+constexpr unsigned XL_OOB = 0x80000000u;       // voffset >= num_records (also with any soffset < 2^31 added): the load returns 0
+constexpr unsigned XL_RECORDS = 0x80000000u;
+constexpr int XL_SLOTS = 12;                   // distinct temb rows (images) one 256-row tile may span (4x7 images: 11)
+
+template <int N>
+__device__ __forceinline__ void xl_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void xl_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+typedef __attribute__((ext_vector_type(4))) unsigned xl_rsrc_t;   // buffer descriptor words, held in SGPRs
+
+// Raw buffer descriptor (stride 0, 2 GiB window) over `base`.  Every word is made provably wave-uniform so the inline-asm "s"
+// operands below get SGPRs.
+__device__ __forceinline__ xl_rsrc_t xl_make_rsrc(const void* base) {
+    const unsigned long long a = (unsigned long long)base;
+    xl_rsrc_t r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    r.z = XL_RECORDS;
+    r.w = 0x00020000u;
+    return r;
+}
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from (descriptor base + soff + voff[lane]) to LDS bytes [lds_addr, lds_addr + 1024).
+// Inline asm on purpose: hipcc models the builtin as an LDS store of unknown extent and drains `vmcnt(0)` in front of the next
+// ds_read — every phase — which serialises the whole pipeline (seen in the .s of the builtin version).  An asm statement is absent
+// from the compiler's wait bookkeeping: completion is counted by hand (xl_wait_vmcnt + s_barrier before any read of the slot, see
+// the schedule in the kernel).  M0 (the DMA's LDS base) is compiler-reserved: saved and restored inside the statement; the s_nop
+// covers the SALU-write-M0 -> LDS-DMA hazard.
+__device__ __forceinline__ void xl_glds(const xl_rsrc_t rs, unsigned lds_addr, unsigned voff, int soff) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
+        : "memory");
+}
+
+template <int BN, bool CONV>
+__global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
+    using G = Geo<BN>;
+    constexpr int BM = 256, NTH = 512;
+    constexpr int TI = G::TI, TJ = G::TJ, TJ0 = G::TJ0, TJ1 = TJ - TJ0, TIH = TI / 2;
+    constexpr int A_BYTES = BM * 128, B_BYTES = G::BNP * 128, BUF = A_BYTES + B_BYTES;
+    constexpr int PA = G::PA, PB0 = G::PB0, PB1 = G::PB1;
+    constexpr int UNIT_MAX = PA > PB0 ? PA : PB0;
+    // outstanding DMA instructions of the three units issued after a slab's last unit (A1): A0, B0, B1 of the next slab
+    constexpr int INFLIGHT = PA + PB0 + PB1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                                  // waves w and w + 4 share a SIMD
+    const int wm = wave % G::WM, wn = wave / G::WM;
+    int tile_m, tile_n;
+    if (!tile_coords(p, tile_m, tile_n)) return;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nt = p.K / 64;                                    // K % 64 == 0 (xl_supported)
+
+    // ---- DMA source bookkeeping -------------------------------------------------------------------------------------------
+    // A: GEMM: descriptor base = row m0, voffset = row * lda + chunk, soffset = k.  CONV: base = the tile's first receptive-field
+    // pixel, voffset = (input pixel of the row's tap (0,0)) - that, soffset = tap shift + channel block; invalid taps -> XL_OOB.
+    long a_base_el;                                              // element offset of the descriptor base inside p.A
+    int hw = 1, Wo = 1;
+    if (CONV) {
+        hw = p.Ho * p.Wo; Wo = p.Wo;
+        const int b = m0 / hw, rem = m0 - b * hw;
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        a_base_el = (((long)b * p.Hi + (oy * p.sh - p.ph)) * p.Wi + (ox * p.sw - p.pw)) * p.lda;   // may point before p.A: never dereferenced there
+    } else {
+        a_base_el = (long)m0 * p.lda;
+    }
+    const xl_rsrc_t rsA = xl_make_rsrc(p.A + a_base_el);
+    const xl_rsrc_t rsB = xl_make_rsrc(p.W + (long)n0 * p.ldw);
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_void_t*)smem;      // LDS byte address of the dynamic region
+
+    unsigned a_voff[2][PA];                                      // [unit A0 / A1][piece]
+    unsigned a_taps[2][PA];                                      // CONV: bit t set = tap t reads inside the image (else zero)
+    int a_lds[2][PA];                                            // LDS byte offset of the piece inside a buffer (wave-uniform)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < PA; ++e) {
+            const int row0 = a_piece_row0<BN>(h, wave, e);
+            a_lds[h][e] = row0 * 128;
+            const int R = piece_lane_row(row0, lane);
+            const int cl = piece_lane_chunk(row0, lane);
+            const int m = m0 + R;
+            a_taps[h][e] = 0;
+            if (CONV) {
+                const int mm = min(m, p.M - 1);
+                const int b = mm / hw, rem = mm - b * hw;
+                const int oy = rem / Wo, ox = rem - oy * Wo;
+                const int iy0 = oy * p.sh - p.ph, ix0 = ox * p.sw - p.pw;
+                const long pix = ((long)b * p.Hi + iy0) * p.Wi + ix0;
+                a_voff[h][e] = (unsigned)((pix * p.lda - a_base_el) * 2 + cl * 16);
+                unsigned bits = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+                    if (m < p.M && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) bits |= 1u << t;
+                }
+                a_taps[h][e] = bits;
+            } else {
+                a_voff[h][e] = m < p.M ? (unsigned)(((long)R * p.lda) * 2 + cl * 16) : XL_OOB;
+            }
+        }
+    unsigned b_voff[2][UNIT_MAX];
+    int b_lds[2][UNIT_MAX];
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+        for (int e = 0; e < (part ? PB1 : PB0); ++e) {
+            const int row0 = b_piece_row0<BN>(part, wave, e);
+            if (row0 < 0) {                                      // dummy piece (BN = 160): zeros into scratch rows
+                b_lds[part][e] = A_BYTES + b_dummy_row0<BN>(wave) * 128;
+                b_voff[part][e] = XL_OOB;
+            } else {
+                b_lds[part][e] = A_BYTES + row0 * 128;
+                const int R = piece_lane_row(row0, lane);
+                const int cl = piece_lane_chunk(row0, lane);
+                b_voff[part][e] = (n0 + R < p.N) ? (unsigned)(((long)R * p.ldw) * 2 + cl * 16) : XL_OOB;
+            }
+        }
+
+    // slab T -> scalar byte offsets of its k position in A and W
+    const int row_bytes = (int)(p.lda * 2);
+    auto a_soff = [&](int T, int& tap) -> int {
+        if (CONV) {
+            const int cb = T / 9;
+            tap = T - cb * 9;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            return (ky * p.Wi + kx) * row_bytes + cb * 128;
+        }
+        tap = 0;
+        return T * 128;
+    };
+    auto b_soff = [&](int T) -> int {
+        if (CONV) {
+            const int cb = T / 9, tap = T - cb * 9;
+            return (tap * p.Cin + cb * 64) * 2;
+        }
+        return T * 128;
+    };
+    // issue one unit of slab T into buffer T & 1 (skipped past the last slab: the waits below account for it)
+#define XL_ISSUE_A(h, T)                                                                                                         \
+    if ((T) < nt && !(p.dbg & 2)) {                                                                                               \
+        int tap_;                                                                                                                 \
+        const int so_ = a_soff((T), tap_);                                                                                        \
+        const unsigned dst_ = lds0 + ((T) & 1) * BUF;                                                                             \
+        _Pragma("unroll") for (int e = 0; e < PA; ++e) {                                                                          \
+            const unsigned vo_ = CONV ? (((a_taps[h][e] >> tap_) & 1u) ? a_voff[h][e] : XL_OOB) : a_voff[h][e];                   \
+            xl_glds(rsA, dst_ + a_lds[h][e], vo_, so_);                                                                           \
+        }                                                                                                                         \
+    }
+#define XL_ISSUE_B(part, T)                                                                                                       \
+    if ((T) < nt && !(p.dbg & 2)) {                                                                                               \
+        const int so_ = b_soff((T));                                                                                              \
+        const unsigned dst_ = lds0 + ((T) & 1) * BUF;                                                                             \
+        _Pragma("unroll") for (int e = 0; e < ((part) ? PB1 : PB0); ++e)                                                          \
+            xl_glds(rsB, dst_ + b_lds[part][e], b_voff[part][e], so_);                                                            \
+    }
+
+    // ---- fragment read offsets (bytes inside a buffer) ----
+    const int fo0 = frag_off(0, lane, 0), fo1 = frag_off(0, lane, 1);     // row part = (lane & 15) * 128: tile row blocks add multiples of 2048
+    const int a_rd = a_tile_row0<BN>(wm, 0) * 128;
+    const int b_rd = A_BYTES + b_tile_row0<BN>(wn, 0) * 128;
+
+    f32x4_t acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    Frag8 af[TIH][2], bf0[TJ0][2], bf1[TJ1][2];
+#define XL_READ_A(h, buf_)                                                                                                        \
+    {                                                                                                                             \
+        const unsigned char* s_ = smem + (buf_) * BUF + a_rd + (h) * TIH * 2048;                                                  \
+        _Pragma("unroll") for (int i = 0; i < TIH; ++i) {                                                                         \
+            af[i][0].u = *(const uint4*)(s_ + i * 2048 + fo0);                                                                    \
+            af[i][1].u = *(const uint4*)(s_ + i * 2048 + fo1);                                                                    \
+        }                                                                                                                         \
+    }
+#define XL_READ_B0(buf_)                                                                                                          \
+    {                                                                                                                             \
+        const unsigned char* s_ = smem + (buf_) * BUF + b_rd;                                                                     \
+        _Pragma("unroll") for (int j = 0; j < TJ0; ++j) {                                                                         \
+            bf0[j][0].u = *(const uint4*)(s_ + j * 2048 + fo0);                                                                   \
+            bf0[j][1].u = *(const uint4*)(s_ + j * 2048 + fo1);                                                                   \
+        }                                                                                                                         \
+    }
+#define XL_READ_B1(buf_)                                                                                                          \
+    {                                                                                                                             \
+        const unsigned char* s_ = smem + (buf_) * BUF + b_rd + TJ0 * 2048;                                                        \
+        _Pragma("unroll") for (int j = 0; j < TJ1; ++j) {                                                                         \
+            bf1[j][0].u = *(const uint4*)(s_ + j * 2048 + fo0);                                                                   \
+            bf1[j][1].u = *(const uint4*)(s_ + j * 2048 + fo1);                                                                   \
+        }                                                                                                                         \
+    }
+    // D = Wfrag x Afrag: the accumulator holds 4 consecutive n (rows of D) of one m (column of D) per lane
+#define XL_MMA(h, BF, J0, NJ)                                                                                                     \
+    if (!(p.dbg & 1)) {                                                                                                           \
+        __builtin_amdgcn_s_setprio(1);                                                                                            \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                                          \
+            _Pragma("unroll") for (int i = 0; i < TIH; ++i)                                                                       \
+                _Pragma("unroll") for (int j = 0; j < (NJ); ++j)                                                                  \
+                    acc[(h) * TIH + i][(J0) + j] =                                                                                \
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][kk].v, af[i][kk].v, acc[(h) * TIH + i][(J0) + j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                                            \
+    }
+    // end of a load segment: this wave's fragment reads have RETURNED before the barrier (so a unit may be refilled by anyone one
+    // phase later), then the barrier that hands the matrix pipe over
+#define XL_SEG_END()                                                                                                              \
+    {                                                                                                                             \
+        xl_wait_lgkm0();                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                                        \
+        __builtin_amdgcn_s_barrier();                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                                        \
+    }
+#define XL_MMA_END()                                                                                                              \
+    {                                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                                        \
+        __builtin_amdgcn_s_barrier();                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                                        \
+    }
+
+    // ---- prologue: slab 0 whole + A0, B0, B1 of slab 1 in flight; wait for slab 0 ----
+    XL_ISSUE_A(0, 0)
+    XL_ISSUE_B(0, 0)
+    XL_ISSUE_B(1, 0)
+    XL_ISSUE_A(1, 0)
+    XL_ISSUE_A(0, 1)
+    XL_ISSUE_B(0, 1)
+    XL_ISSUE_B(1, 1)
+    if (nt > 1) xl_wait_vmcnt<INFLIGHT>(); else xl_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) {                                              // the stagger: group 1 runs one barrier behind group 0
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        // q0: quadrant (A0, B0).  Reads A0, B0; refills A1 of slab t + 1 (last read in q2 of slab t - 1).
+        XL_READ_A(0, buf)
+        XL_READ_B0(buf)
+        XL_ISSUE_A(1, t + 1)
+        XL_SEG_END()
+        XL_MMA(0, bf0, 0, TJ0)
+        XL_MMA_END()
+        // q1: (A0, B1).  Reads B1; refills A0 of slab t + 2 (last read in q0).
+        XL_READ_B1(buf)
+        XL_ISSUE_A(0, t + 2)
+        XL_SEG_END()
+        XL_MMA(0, bf1, TJ0, TJ1)
+        XL_MMA_END()
+        // q2: (A1, B1).  Reads A1; refills B0 of slab t + 2 (last read in q0).
+        XL_READ_A(1, buf)
+        XL_ISSUE_B(0, t + 2)
+        XL_SEG_END()
+        XL_MMA(1, bf1, TJ0, TJ1)
+        XL_MMA_END()
+        // q3: (A1, B0), B0 still in registers.  Refills B1 of slab t + 2 (last read in q1); slab t + 1 must have landed: its last unit
+        // (A1, issued in q0) is followed by exactly the three units A0, B0, B1 of slab t + 2 when that slab exists.
+        XL_ISSUE_B(1, t + 2)
+        if (t + 2 < nt) xl_wait_vmcnt<INFLIGHT>(); else xl_wait_vmcnt<0>();
+        XL_SEG_END()
+        XL_MMA(1, bf0, 0, TJ0)
+        XL_MMA_END()
+    }
+    if (grp == 0) {                                              // balance the stagger
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef XL_ISSUE_A
+#undef XL_ISSUE_B
+#undef XL_READ_A
+#undef XL_READ_B0
+#undef XL_READ_B1
+#undef XL_MMA
+#undef XL_SEG_END
+#undef XL_MMA_END
+
+    // ---- epilogue ----
+    const bool geglu = p.epi == 1;
+    const bool has_t = p.temb != nullptr && !geglu;
+    const int BNo = geglu ? BN / 2 : BN;
+    const int CSTR = BNo + 8;                                    // LDS row stride of the bf16 tile (elements); rows stay 16-byte aligned
+    bf16_t* Cs = (bf16_t*)smem;                                  // [256][CSTR], aliases the (dead) operand ring
+    float* addend = (float*)(smem + (size_t)BM * (BN + 8) * 2);  // [XL_SLOTS][BN] fp32, behind the largest C tile
+    const int b0 = has_t ? m0 / p.rows_per_b : 0;
+    {
+        const int nslots = has_t ? XL_SLOTS : 1;
+        const int sel = (has_t && p.sel) ? *p.sel : 0;
+        const int bmax = has_t ? (p.M - 1) / p.rows_per_b : 0;
+        for (int idx = tid; idx < nslots * BN; idx += NTH) {
+            const int slot = idx / BN, n = idx - slot * BN, col = n0 + n;
+            float v = 0.f;
+            if (col < p.N) {
+                if (p.bias) v = p.bias[col];
+                if (has_t && b0 + slot <= bmax) v += p.temb[(long)sel * p.temb_sel_stride + (long)(b0 + slot) * p.temb_b_stride + col];
+            }
+            addend[idx] = v;
+        }
+    }
+    __syncthreads();                                             // ring dead (every wave passed its last MFMA), addend visible
+    {
+        const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int ml = wm * TI * 16 + i * 16 + fr;           // row inside the tile
+            int slot = 0;
+            if (has_t) slot = min(min(m0 + ml, p.M - 1) / p.rows_per_b - b0, XL_SLOTS - 1);
+            const float* ad = addend + slot * BN;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                if (geglu && (j & 2)) continue;                   // gate tiles (columns 32..63 of a 64 group) are consumed with their value tile
+                const int nl = wn * TJ * 16 + j * 16 + 4 * fq;    // raw column inside the tile
+                const float4 a4 = *(const float4*)(ad + nl);
+                const float bb[4] = {a4.x, a4.y, a4.z, a4.w};
+                float o[4];
+                if (geglu) {
+                    const float4 g4 = *(const float4*)(ad + nl + 32);
+                    const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = acc[i][j][e] + bb[e];
+                        const float gt = acc[i][(TJ > 2) ? (j | 2) : j][e] + gg[e];
+                        o[e] = x * gelu_erf_f(gt);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[i][j][e] + bb[e];
+                        if (p.epi == 2) x = silu_f(x);
+                        o[e] = x;
+                    }
+                }
+                const int cl = geglu ? ((nl >> 6) * 32 + (nl & 31)) : nl;
+                uint2 ov; ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]);
+                *(uint2*)(Cs + ml * CSTR + cl) = ov;
+            }
+        }
+    }
+    __syncthreads();
+    const int n0o = geglu ? n0 / 2 : n0, Nout = geglu ? p.N / 2 : p.N;
+    const bf16_t* Rg = p.R ? (const bf16_t*)p.R : nullptr;
+    bf16_t* Cg = (bf16_t*)p.C;
+    if (p.wide) {
+        const int cpr = BNo >> 3;
+        const int total = BM * cpr;
+#pragma unroll 1
+        for (int i0 = 0; i0 < total; i0 += 4 * NTH) {
+            uint4 rv[4];
+            int row[4], c8[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = i0 + u * NTH + tid;
+                row[u] = idx / cpr;
+                c8[u] = (idx - row[u] * cpr) * 8;
+                ok[u] = idx < total && m0 + row[u] < p.M && n0o + c8[u] < Nout;
+                rv[u] = make_uint4(0, 0, 0, 0);
+                if (Rg && ok[u]) rv[u] = *(const uint4*)(Rg + (long)(m0 + row[u]) * p.ldr + n0o + c8[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u]) continue;
+                uint4 v = *(const uint4*)(Cs + row[u] * CSTR + c8[u]);
+                if (Rg) { v.x = add2bf(v.x, rv[u].x); v.y = add2bf(v.y, rv[u].y); v.z = add2bf(v.z, rv[u].z); v.w = add2bf(v.w, rv[u].w); }
+                *(uint4*)(Cg + (long)(m0 + row[u]) * p.ldc + n0o + c8[u]) = v;
+            }
+        }
+    } else {
+        const int cpr = BNo >> 2;
+        const int total = BM * cpr;
+#pragma unroll 1
+        for (int i0 = 0; i0 < total; i0 += 4 * NTH) {
+            uint2 rv[4];
+            int row[4], c4[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = i0 + u * NTH + tid;
+                row[u] = idx / cpr;
+                c4[u] = (idx - row[u] * cpr) * 4;
+                ok[u] = idx < total && m0 + row[u] < p.M && n0o + c4[u] < Nout;
+                rv[u] = make_uint2(0, 0);
+                if (Rg && ok[u]) rv[u] = *(const uint2*)(Rg + (long)(m0 + row[u]) * p.ldr + n0o + c4[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u]) continue;
+                uint2 v = *(const uint2*)(Cs + row[u] * CSTR + c4[u]);
+                if (Rg) { v.x = add2bf(v.x, rv[u].x); v.y = add2bf(v.y, rv[u].y); }
+                *(uint2*)(Cg + (long)(m0 + row[u]) * p.ldc + n0o + c4[u]) = v;
+            }
+        }
+    }
+}
+
+// LDS: operand ring (2 slabs) or the bf16 C tile, whichever is larger, + the addend rows
+template <int BN>
+constexpr size_t xl_smem_bytes() {
+    constexpr size_t ring = (size_t)2 * (256 + Geo<BN>::BNP) * 128, ctile = (size_t)256 * (BN + 8) * 2;
+    return (ring > ctile ? ring : ctile) + (size_t)XL_SLOTS * BN * sizeof(float);
+}
+
+template <int BN, bool CONV>
+static int launch_xl(const GCParams& p, hipStream_t st) {
+    constexpr size_t smem = xl_smem_bytes<BN>();
+    static_assert(smem <= 163840, "LDS budget");
+    auto kern = gemm_xl_kernel<BN, CONV>;
+    if (int rc = ensure_dyn_smem((const void*)kern, smem, "xl")) return rc;
+    GCParams q = p;
+    q.mt = (p.M + 255) / 256; q.nt = (p.N + BN - 1) / BN;
+    static const int swz = [] { const char* e = getenv("MDX_GEMM_SWZ"); return e ? atoi(e) : 1; }();
+    static const int dbg = [] { const char* e = getenv("MDX_XL_DBG"); return e ? atoi(e) : 0; }();
+    q.dbg = dbg;
+    q.swz = swz && q.nt > 1 && q.mt >= 64;
+    const unsigned nblk = q.swz ? (unsigned)((q.mt + 7) / 8 * 8 * q.nt) : (unsigned)(q.mt * q.nt);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), smem, st, q);
+    char tag[96];
+    snprintf(tag, sizeof tag, "gemm_xl_kernel<256x%d,%s>", BN, CONV ? "conv" : "gemm");
+    return check_launch(tag);
+}
+
+// Can the XL main loop run this problem at all?  (The caller's cost model decides whether it should.)  bn = 256 or 160.
+bool xl_supported(const GCParams& p, bool conv, int bn) {
+    if (p.batch > 1 || p.splitk > 1 || p.c_f32 || (p.N % 4) || (p.K % 64) || p.Vt) return false;
+    if (p.epi == 1 && (bn != 256 || (p.N % 64))) return false;
+    if (conv) {
+        if (p.kh != 3 || p.kw != 3 || p.ph != 1 || p.pw != 1 || (p.Cin % 64) || !p.cimajor) return false;   // pad 1: input pixel index monotonic in m
+        // voffsets are relative to the tile's first receptive-field pixel: 256 output pixels span < 2^31 bytes for every real shape,
+        // but keep the arithmetic honest
+        const long span = ((long)(256 / p.Wo + 3) * p.sh * p.Wi + 256L * p.sw + 3 * p.Wi) * p.lda * 2;
+        if (span >= 0x40000000L) return false;
+    } else if ((long)256 * p.lda * 2 >= 0x40000000L) return false;
+    if ((long)bn * p.ldw * 2 >= 0x40000000L) return false;
+    if (p.temb && p.epi != 1) {
+        const int rows = p.rows_per_b > 0 ? p.rows_per_b : 1;
+        if (256 / rows + 2 > XL_SLOTS) return false;
+    }
+    return true;
+}
+
+int launch_gemm_xl(const GCParams& p, bool conv, int bn, hipStream_t st) {
+    if (bn == 256) return conv ? launch_xl<256, true>(p, st) : launch_xl<256, false>(p, st);
+    return conv ? launch_xl<160, true>(p, st) : launch_xl<160, false>(p, st);
+}
+
+}  // namespace mdx

@@ -27,4 +27,8 @@ inline int check_launch(const char* what, bool primary = true) {
     return MDX_OK;
 }
 
+// Raise a kernel's dynamic-LDS limit once per (kernel, device).  Thread-safe (api.hip keeps the set behind a mutex); returns MDX_OK
+// or MDX_ELAUNCH with the error text set.
+int ensure_dyn_smem(const void* kernel, size_t bytes, const char* what);
+
 }  // namespace mdx

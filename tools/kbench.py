@@ -26,7 +26,12 @@ def timeit(op, reps):
         L.call_op(code, desc, st)
     e1.record()
     torch.cuda.synchronize()
+    global LAST_KERNEL
+    LAST_KERNEL = (L.lib().mdx_last_kernel() or b"").decode()
     return e0.elapsed_time(e1) / reps * 1e3    # us
+
+
+LAST_KERNEL = ""
 
 
 def main():
@@ -44,7 +49,7 @@ def main():
     rows = []
 
     def rec(kind, name, us, gf):
-        rows.append((kind, name, us, gf))
+        rows.append((kind, name, us, gf, LAST_KERNEL))
         t = tot.setdefault(kind, [0.0, 0.0]); t[0] += us; t[1] += gf
 
     if "gemm" in a.only:
@@ -93,8 +98,8 @@ def main():
             x = r(B * h * w, C); y = torch.empty_like(x)
             us = timeit(O.LayerNorm(x, y, torch.ones(C, device=dev), torch.zeros(C, device=dev)), a.reps)
             rec("norm", f"LN M={B*h*w} C={C}", us, 0)
-    for kind, name, us, gf in rows:
-        print(f"{kind:5s} {name:34s} {us:9.1f} us  {gf/us*1e3 if gf else 0:8.1f} TF/s")
+    for kind, name, us, gf, kern in rows:
+        print(f"{kind:5s} {name:34s} {us:9.1f} us  {gf/us*1e3 if gf else 0:8.1f} TF/s  {kern}")
     for k, (us, gf) in tot.items():
         print(f"== {k}: {us:.0f} us total, {gf/us*1e3 if gf else 0:.1f} TF/s aggregate")
 
