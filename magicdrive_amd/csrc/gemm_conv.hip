@@ -362,15 +362,22 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
     static const int xl_mode = [] { const char* e = getenv("MDX_GEMM_XL"); return e ? atoi(e) : 1; }();
     static const int xl_k320 = [] { const char* e = getenv("MDX_XL_K320"); return e ? atoi(e) : 0; }();
     static const int xl_min_tiles = [] { const char* e = getenv("MDX_XL_MIN_TILES"); return e ? atoi(e) : 160; }();
+    // Width choice: time model fitted on MI355X at 384 views (profiles/README.md, round 2): a tile costs a(bn) + b(bn) * K/64
+    // microseconds — b falls with the tile width (operand bytes per MAC through the global -> LDS path), a (prologue + the
+    // HBM-bound epilogue burst; the 320-wide tile stages C in two halves) rises — times the rounds of tiles over the 256 CUs.
     auto try_xl = [&](int& bn_out) -> bool {
         if (impl != 0 || xl_mode <= 0 || p.splitk > 1) return false;
+        static const int xl_bn = [] { const char* e = getenv("MDX_XL_BN"); return e ? atoi(e) : 0; }();   // benchmarking: force a width
         double best = 1e300;
         bn_out = 0;
-        for (int bn : {256, 160}) {
+        const double nslab = p.K / 64.0;
+        for (int bn : {320, 256, 160}) {
+            if (xl_bn && bn != xl_bn) continue;
             if (!xl_supported(p, conv, bn)) continue;
             const long t = (long)((p.M + 255) / 256) * ((p.N + bn - 1) / bn);
             if (xl_mode < 2 && t < xl_min_tiles) continue;
-            const double c = (double)((t + 255) / 256) * 256.0 * bn * (bn == 160 ? 1.12 : 1.0);   // rounds x tile area / relative efficiency
+            const double a = bn == 320 ? 23.7 : bn == 256 ? 13.4 : 16.6, b = bn == 320 ? 1.896 : bn == 256 ? 1.565 : 1.116;
+            const double c = (double)((t + 255) / 256) * (a + b * nslab);
             if (c < best) { best = c; bn_out = bn; }
         }
         return bn_out != 0;

@@ -77,7 +77,7 @@ __device__ __forceinline__ void xl_glds(const xl_rsrc_t rs, unsigned lds_addr, u
         : "memory");
 }
 
-template <int BN, bool CONV>
+template <int BN, bool CONV, int SCHED>
 __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
     using G = Geo<BN>;
     constexpr int BM = 256, NTH = 512;
@@ -85,8 +85,6 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
     constexpr int A_BYTES = BM * 128, B_BYTES = G::BNP * 128, BUF = A_BYTES + B_BYTES;
     constexpr int PA = G::PA, PB0 = G::PB0, PB1 = G::PB1;
     constexpr int UNIT_MAX = PA > PB0 ? PA : PB0;
-    // outstanding DMA instructions of the three units issued after a slab's last unit (A1): A0, B0, B1 of the next slab
-    constexpr int INFLIGHT = PA + PB0 + PB1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -183,24 +181,32 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
         }
         return T * 128;
     };
-    // issue one unit of slab T into buffer T & 1 (skipped past the last slab: the waits below account for it)
-#define XL_ISSUE_A(h, T)                                                                                                         \
-    if ((T) < nt && !(p.dbg & 2)) {                                                                                               \
-        int tap_;                                                                                                                 \
-        const int so_ = a_soff((T), tap_);                                                                                        \
-        const unsigned dst_ = lds0 + ((T) & 1) * BUF;                                                                             \
-        _Pragma("unroll") for (int e = 0; e < PA; ++e) {                                                                          \
-            const unsigned vo_ = CONV ? (((a_taps[h][e] >> tap_) & 1u) ? a_voff[h][e] : XL_OOB) : a_voff[h][e];                   \
-            xl_glds(rsA, dst_ + a_lds[h][e], vo_, so_);                                                                           \
+    // Debug ablations (MDX_XL_DBG: 1 skip the MFMAs, 2 skip the DMA) exist only in builds with -DMDX_XL_ABLATE: a runtime test inside
+    // the MFMA clusters splits their scheduling regions.
+#ifdef MDX_XL_ABLATE
+    const bool do_mma = !(p.dbg & 1), do_dma = !(p.dbg & 2);
+#else
+    constexpr bool do_mma = true, do_dma = true;
+#endif
+    // ONE 1-KiB piece (e) of a load unit of slab T into buffer T & 1; nothing past the last slab (the waits account for it)
+#define XL_PIECE_A(h, e, T)                                                                                                       \
+    if constexpr ((e) < PA) {                                                                                                     \
+        if ((T) < nt && do_dma) {                                                                                                 \
+            int tap_;                                                                                                             \
+            const int so_ = a_soff((T), tap_);                                                                                    \
+            const unsigned vo_ = CONV ? (((a_taps[h][(e) < PA ? (e) : 0] >> tap_) & 1u) ? a_voff[h][(e) < PA ? (e) : 0] : XL_OOB) \
+                                      : a_voff[h][(e) < PA ? (e) : 0];                                                            \
+            xl_glds(rsA, lds0 + ((T) & 1) * BUF + a_lds[h][(e) < PA ? (e) : 0], vo_, so_);                                        \
         }                                                                                                                         \
     }
-#define XL_ISSUE_B(part, T)                                                                                                       \
-    if ((T) < nt && !(p.dbg & 2)) {                                                                                               \
-        const int so_ = b_soff((T));                                                                                              \
-        const unsigned dst_ = lds0 + ((T) & 1) * BUF;                                                                             \
-        _Pragma("unroll") for (int e = 0; e < ((part) ? PB1 : PB0); ++e)                                                          \
-            xl_glds(rsB, dst_ + b_lds[part][e], b_voff[part][e], so_);                                                            \
+#define XL_PIECE_B(part, e, T)                                                                                                    \
+    if constexpr ((e) < ((part) ? PB1 : PB0)) {                                                                                   \
+        if ((T) < nt && do_dma)                                                                                                   \
+            xl_glds(rsB, lds0 + ((T) & 1) * BUF + b_lds[part][(e) < UNIT_MAX ? (e) : 0], b_voff[part][(e) < UNIT_MAX ? (e) : 0],  \
+                    b_soff((T)));                                                                                                 \
     }
+#define XL_ISSUE_A(h, T) { XL_PIECE_A(h, 0, T) XL_PIECE_A(h, 1, T) }
+#define XL_ISSUE_B(part, T) { XL_PIECE_B(part, 0, T) XL_PIECE_B(part, 1, T) XL_PIECE_B(part, 2, T) }
 
     // ---- fragment read offsets (bytes inside a buffer) ----
     const int fo0 = frag_off(0, lane, 0), fo1 = frag_off(0, lane, 1);     // row part = (lane & 15) * 128: tile row blocks add multiples of 2048
@@ -215,7 +221,8 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
-    Frag8 af[TIH][2], bf0[TJ0][2], bf1[TJ1][2];
+    constexpr int NBF = (BN == 320) ? TJ0 : TJ;                   // BN = 320: B0 (3 tiles) and B1 (2 tiles) share one register set
+    Frag8 af[TIH][2], bfr[NBF][2];                                // one A half + the B tiles of the wave, both k32 steps
 #define XL_READ_A(h, buf_)                                                                                                        \
     {                                                                                                                             \
         const unsigned char* s_ = smem + (buf_) * BUF + a_rd + (h) * TIH * 2048;                                                  \
@@ -224,31 +231,64 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
             af[i][1].u = *(const uint4*)(s_ + i * 2048 + fo1);                                                                    \
         }                                                                                                                         \
     }
-#define XL_READ_B0(buf_)                                                                                                          \
+#define XL_READ_B(J0, NJ, buf_)                                                                                                   \
     {                                                                                                                             \
         const unsigned char* s_ = smem + (buf_) * BUF + b_rd;                                                                     \
-        _Pragma("unroll") for (int j = 0; j < TJ0; ++j) {                                                                         \
-            bf0[j][0].u = *(const uint4*)(s_ + j * 2048 + fo0);                                                                   \
-            bf0[j][1].u = *(const uint4*)(s_ + j * 2048 + fo1);                                                                   \
+        _Pragma("unroll") for (int j = (J0); j < (J0) + (NJ); ++j) {                                                              \
+            bfr[j][0].u = *(const uint4*)(s_ + j * 2048 + fo0);                                                                   \
+            bfr[j][1].u = *(const uint4*)(s_ + j * 2048 + fo1);                                                                   \
         }                                                                                                                         \
     }
-#define XL_READ_B1(buf_)                                                                                                          \
+#define XL_READ_B_TO(D0, J0, NJ, buf_)                                                                                            \
     {                                                                                                                             \
-        const unsigned char* s_ = smem + (buf_) * BUF + b_rd + TJ0 * 2048;                                                        \
-        _Pragma("unroll") for (int j = 0; j < TJ1; ++j) {                                                                         \
-            bf1[j][0].u = *(const uint4*)(s_ + j * 2048 + fo0);                                                                   \
-            bf1[j][1].u = *(const uint4*)(s_ + j * 2048 + fo1);                                                                   \
+        const unsigned char* s_ = smem + (buf_) * BUF + b_rd;                                                                     \
+        _Pragma("unroll") for (int j = 0; j < (NJ); ++j) {                                                                        \
+            bfr[(D0) + j][0].u = *(const uint4*)(s_ + ((J0) + j) * 2048 + fo0);                                                   \
+            bfr[(D0) + j][1].u = *(const uint4*)(s_ + ((J0) + j) * 2048 + fo1);                                                   \
         }                                                                                                                         \
     }
-    // D = Wfrag x Afrag: the accumulator holds 4 consecutive n (rows of D) of one m (column of D) per lane
-#define XL_MMA(h, BF, J0, NJ)                                                                                                     \
-    if (!(p.dbg & 1)) {                                                                                                           \
+#define XL_MMA_TO(h, D0, J0, NJ)                                                                                                  \
+    if (do_mma) {                                                                                                                 \
         __builtin_amdgcn_s_setprio(1);                                                                                            \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                                          \
             _Pragma("unroll") for (int i = 0; i < TIH; ++i)                                                                       \
                 _Pragma("unroll") for (int j = 0; j < (NJ); ++j)                                                                  \
                     acc[(h) * TIH + i][(J0) + j] =                                                                                \
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][kk].v, af[i][kk].v, acc[(h) * TIH + i][(J0) + j], 0, 0, 0); \
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[(D0) + j][kk].v, af[i][kk].v, acc[(h) * TIH + i][(J0) + j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                                            \
+    }
+    // D = Wfrag x Afrag: the accumulator holds 4 consecutive n (rows of D) of one m (column of D) per lane
+#define XL_MMA(h, J0, NJ)                                                                                                         \
+    if (do_mma) {                                                                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                                                                            \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                                          \
+            _Pragma("unroll") for (int i = 0; i < TIH; ++i)                                                                       \
+                _Pragma("unroll") for (int j = (J0); j < (J0) + (NJ); ++j)                                                        \
+                    acc[(h) * TIH + i][j] =                                                                                       \
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j][kk].v, af[i][kk].v, acc[(h) * TIH + i][j], 0, 0, 0);       \
+        __builtin_amdgcn_s_setprio(0);                                                                                            \
+    }
+    // MFMA segment of the two-phase schedule: one A half x every B tile, with up to four DMA pieces interleaved between the MFMAs
+    // (pinned by sched_barrier: an LDS-DMA issued among MFMAs costs ~60 cycles of this wave's issue slot, hidden under the matrix
+    // pipe's 16 cycles per MFMA; in the load segment the same instruction costs 100-185 and sits on the critical path).
+#define XL_MSEG(h, I0, I1, I2, I3)                                                                                                \
+    {                                                                                                                             \
+        __builtin_amdgcn_s_setprio(1);                                                                                            \
+        constexpr int P_ = 2 * TIH;                                                                                               \
+        _Pragma("unroll") for (int pr = 0; pr < P_; ++pr) {                                                                       \
+            const int kk = pr / TIH, i = pr % TIH;                                                                                \
+            if (pr == 1) { I0 }                                                                                                   \
+            if (pr == 1 + (P_ - 1) / 4) { I1 }                                                                                    \
+            if (pr == 1 + 2 * (P_ - 1) / 4) { I2 }                                                                                \
+            if (pr == 1 + 3 * (P_ - 1) / 4) { I3 }                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                                    \
+            if (do_mma) {                                                                                                         \
+                _Pragma("unroll") for (int j = 0; j < TJ; ++j)                                                                    \
+                    acc[(h) * TIH + i][j] =                                                                                       \
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j][kk].v, af[i][kk].v, acc[(h) * TIH + i][j], 0, 0, 0);       \
+            }                                                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                                    \
+        }                                                                                                                         \
         __builtin_amdgcn_s_setprio(0);                                                                                            \
     }
     // end of a load segment: this wave's fragment reads have RETURNED before the barrier (so a unit may be refilled by anyone one
@@ -267,71 +307,222 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
         __builtin_amdgcn_sched_barrier(0);                                                                                        \
     }
 
-    // ---- prologue: slab 0 whole + A0, B0, B1 of slab 1 in flight; wait for slab 0 ----
-    XL_ISSUE_A(0, 0)
-    XL_ISSUE_B(0, 0)
-    XL_ISSUE_B(1, 0)
-    XL_ISSUE_A(1, 0)
-    XL_ISSUE_A(0, 1)
-    XL_ISSUE_B(0, 1)
-    XL_ISSUE_B(1, 1)
-    if (nt > 1) xl_wait_vmcnt<INFLIGHT>(); else xl_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (grp == 1) {                                              // the stagger: group 1 runs one barrier behind group 0
+    if constexpr (BN == 320) {
+        // ===== 256 x 320: quadrant order (A0,B0) (A1,B0) (A1,B1) (A0,B1) so that B0 and B1 are never live together (160 accumulators
+        // leave room for one A half + 3 B tiles); A0 is read twice per slab (34 instead of 26 fragment reads: LDS port time is not the
+        // bound, the global -> LDS path is — this tile moves 0.0070 operand bytes per MAC against 0.0078 / 0.0102 for 256 / 160 wide).
+        //   reads:   q0 A0,B0   q1 A1   q2 B1   q3 A0            last read of a unit: B0 q0, A1 q1, B1 q2, A0 q3
+        //   refills: q1 B0(t+2) q2 A1(t+2) q3 B1(t+2) q0' A0(t+2)  (each one phase after the last read, lgkmcnt(0) before the barrier)
+        //   wait in q3(t) for A0(t+1) (issued in q0(t)): followed by B0(t+2), A1(t+2), B1(t+2) -> vmcnt(PB0 + PA + PB1)
+        constexpr int INFLIGHT = PB0 + PA + PB1;
+        XL_ISSUE_A(0, 0)
+        XL_ISSUE_B(0, 0)
+        XL_ISSUE_A(1, 0)
+        XL_ISSUE_B(1, 0)
+        XL_ISSUE_B(0, 1)
+        XL_ISSUE_A(1, 1)
+        XL_ISSUE_B(1, 1)
+        if (nt > 1) xl_wait_vmcnt<INFLIGHT>(); else xl_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-    }
-
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        // q0: quadrant (A0, B0).  Reads A0, B0; refills A1 of slab t + 1 (last read in q2 of slab t - 1).
-        XL_READ_A(0, buf)
-        XL_READ_B0(buf)
-        XL_ISSUE_A(1, t + 1)
-        XL_SEG_END()
-        XL_MMA(0, bf0, 0, TJ0)
-        XL_MMA_END()
-        // q1: (A0, B1).  Reads B1; refills A0 of slab t + 2 (last read in q0).
-        XL_READ_B1(buf)
-        XL_ISSUE_A(0, t + 2)
-        XL_SEG_END()
-        XL_MMA(0, bf1, TJ0, TJ1)
-        XL_MMA_END()
-        // q2: (A1, B1).  Reads A1; refills B0 of slab t + 2 (last read in q0).
-        XL_READ_A(1, buf)
-        XL_ISSUE_B(0, t + 2)
-        XL_SEG_END()
-        XL_MMA(1, bf1, TJ0, TJ1)
-        XL_MMA_END()
-        // q3: (A1, B0), B0 still in registers.  Refills B1 of slab t + 2 (last read in q1); slab t + 1 must have landed: its last unit
-        // (A1, issued in q0) is followed by exactly the three units A0, B0, B1 of slab t + 2 when that slab exists.
-        XL_ISSUE_B(1, t + 2)
-        if (t + 2 < nt) xl_wait_vmcnt<INFLIGHT>(); else xl_wait_vmcnt<0>();
-        XL_SEG_END()
-        XL_MMA(1, bf0, 0, TJ0)
-        XL_MMA_END()
+        if (grp == 1) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            XL_READ_A(0, buf)
+            XL_READ_B_TO(0, 0, TJ0, buf)
+            XL_ISSUE_A(0, t + 1)
+            XL_SEG_END()
+            XL_MMA_TO(0, 0, 0, TJ0)
+            XL_MMA_END()
+            XL_READ_A(1, buf)
+            XL_ISSUE_B(0, t + 2)
+            XL_SEG_END()
+            XL_MMA_TO(1, 0, 0, TJ0)
+            XL_MMA_END()
+            XL_READ_B_TO(0, TJ0, TJ1, buf)
+            XL_ISSUE_A(1, t + 2)
+            XL_SEG_END()
+            XL_MMA_TO(1, 0, TJ0, TJ1)
+            XL_MMA_END()
+            XL_READ_A(0, buf)
+            XL_ISSUE_B(1, t + 2)
+            if (t + 2 < nt) xl_wait_vmcnt<INFLIGHT>(); else xl_wait_vmcnt<0>();
+            XL_SEG_END()
+            XL_MMA_TO(0, 0, TJ0, TJ1)
+            XL_MMA_END()
+        }
+    } else if constexpr (SCHED == 2 || SCHED == 3) {
+        // ===== schedule 2: schedule 0's quadrants with every refill >= 2 phases after the slot's last read, so the fragment reads'
+        // lgkmcnt(0) can sit AFTER the barrier (the load segment ends when the reads are ISSUED; their latency overlaps the barrier).
+        // schedule 3: same refill order, lgkmcnt(0) before the barrier, DMA issued after it (no contention with the wave's own reads).
+        //   issue order per wave: A1(t+1)@q0  B0(t+1)@q1  A0(t+2)@q2  B1(t+2)@q3 ; reads: q0 A0,B0  q1 B1  q2 A1
+        //   wait in q3(t) for B0(t+1) (and everything older): followed by A0(t+2), B1(t+2) -> vmcnt(PA + PB1)
+        XL_ISSUE_A(0, 0)
+        XL_ISSUE_B(1, 0)
+        XL_ISSUE_A(1, 0)
+        XL_ISSUE_B(0, 0)
+        XL_ISSUE_A(0, 1)
+        XL_ISSUE_B(1, 1)
+        if (nt > 1) xl_wait_vmcnt<PA + PB1>(); else xl_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 1) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#define XL_SEG2(ISSUE)                                                                                                            \
+        if constexpr (SCHED == 2) {                                                                                               \
+            ISSUE                                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                                    \
+            __builtin_amdgcn_s_barrier();                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                                    \
+        } else {                                                                                                                  \
+            xl_wait_lgkm0();                                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                                    \
+            ISSUE                                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                                    \
+            __builtin_amdgcn_s_barrier();                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                                    \
+        }
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            XL_READ_A(0, buf)
+            XL_READ_B(0, TJ0, buf)
+            XL_SEG2(XL_ISSUE_A(1, t + 1))
+            XL_MMA(0, 0, TJ0)
+            XL_MMA_END()
+            XL_READ_B(TJ0, TJ1, buf)
+            XL_SEG2(XL_ISSUE_B(0, t + 1))
+            XL_MMA(0, TJ0, TJ1)
+            XL_MMA_END()
+            XL_READ_A(1, buf)
+            XL_SEG2(XL_ISSUE_A(0, t + 2))
+            XL_MMA(1, TJ0, TJ1)
+            XL_MMA_END()
+            XL_SEG2(XL_ISSUE_B(1, t + 2) if (t + 2 < nt) xl_wait_vmcnt<PA + PB1>(); else xl_wait_vmcnt<0>();)
+            XL_MMA(1, 0, TJ0)
+            XL_MMA_END()
+        }
+#undef XL_SEG2
+    } else     if constexpr (SCHED == 0) {
+        // ===== schedule 0: four quadrant phases per slab, one unit refilled per load segment ==========================================
+        // units A0, B0, B1, A1 (the rows the quadrants (A0,B0) (A0,B1) (A1,B1) (A1,B0) read first); a unit's slot is refilled one
+        // phase after its last fragment read, for the slab two ahead; ONE counted wait per slab.
+        constexpr int INFLIGHT = PA + PB0 + PB1;                     // A0, B0, B1 of the next slab follow a slab's last unit (A1)
+        XL_ISSUE_A(0, 0)
+        XL_ISSUE_B(0, 0)
+        XL_ISSUE_B(1, 0)
+        XL_ISSUE_A(1, 0)
+        XL_ISSUE_A(0, 1)
+        XL_ISSUE_B(0, 1)
+        XL_ISSUE_B(1, 1)
+        if (nt > 1) xl_wait_vmcnt<INFLIGHT>(); else xl_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 1) {                                              // the stagger: group 1 runs one barrier behind group 0
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            // q0: quadrant (A0, B0).  Reads A0, B0; refills A1 of slab t + 1 (last read in q2 of slab t - 1).
+            XL_READ_A(0, buf)
+            XL_READ_B(0, TJ0, buf)
+            XL_ISSUE_A(1, t + 1)
+            XL_SEG_END()
+            XL_MMA(0, 0, TJ0)
+            XL_MMA_END()
+            // q1: (A0, B1).  Reads B1; refills A0 of slab t + 2 (last read in q0).
+            XL_READ_B(TJ0, TJ1, buf)
+            XL_ISSUE_A(0, t + 2)
+            XL_SEG_END()
+            XL_MMA(0, TJ0, TJ1)
+            XL_MMA_END()
+            // q2: (A1, B1).  Reads A1; refills B0 of slab t + 2 (last read in q0).
+            XL_READ_A(1, buf)
+            XL_ISSUE_B(0, t + 2)
+            XL_SEG_END()
+            XL_MMA(1, TJ0, TJ1)
+            XL_MMA_END()
+            // q3: (A1, B0), B0 still in registers.  Refills B1 of slab t + 2 (last read in q1); slab t + 1 must have landed: its last
+            // unit (A1, issued in q0) is followed by exactly the three units A0, B0, B1 of slab t + 2 when that slab exists.
+            XL_ISSUE_B(1, t + 2)
+            if (t + 2 < nt) xl_wait_vmcnt<INFLIGHT>(); else xl_wait_vmcnt<0>();
+            XL_SEG_END()
+            XL_MMA(1, 0, TJ0)
+            XL_MMA_END()
+        }
+    } else {
+        // ===== schedule 1: two phases per slab (A half x all B tiles), DMA issued from INSIDE the MFMA segments ======================
+        // Round-2 ablation of schedule 0 (profiles/README.md): per slab and wave group the serial path is L + M with L = 24 fragment
+        // reads (~380 cycles) + 8 DMA issues (~100 each in a load segment) + 4 exposed LDS latencies vs M = 1024 cycles of MFMA
+        // issue, i.e. ~2.6 k + 8 barriers against the matrix pipe's 2.05 k per slab.  Here L carries only the fragment reads and two
+        // latencies, the DMA instructions ride between the MFMAs (whose wave has 12 idle issue cycles per MFMA), and there are
+        // 4 barriers per slab.
+        //   P0(t): L: read A0, B(all) of slab t; wait for A1(t)          M: A0 x B, issuing B1(t+1), A1(t+1) into the other buffer
+        //   P1(t): L: read A1 of slab t; wait for A0, B0, B1 of t+1      M: A1 x B, issuing A0(t+2), B0(t+2) into this buffer
+        // Issue order per wave: ... A1(t) | A0(t+1) B0(t+1) | B1(t+1) A1(t+1) | A0(t+2) B0(t+2) ...
+        //   wait in P0(t): A1(t) is followed by A0(t+1), B0(t+1)          -> vmcnt(PA + PB0)   (0 past the end)
+        //   wait in P1(t): B1(t+1) is followed by A1(t+1)                 -> vmcnt(PA)
+        // Slot reuse: B1/A1 of the other buffer were last read in P0(t-1) / P1(t-1); A0/B0 of this buffer in P0(t) — every refill
+        // is issued at least one full barrier interval after both groups' reads of the slot returned (lgkmcnt(0) before the barrier).
+        XL_ISSUE_A(0, 0)
+        XL_ISSUE_B(0, 0)
+        XL_ISSUE_B(1, 0)
+        XL_ISSUE_A(1, 0)
+        XL_ISSUE_A(0, 1)
+        XL_ISSUE_B(0, 1)
+        if (nt > 1) xl_wait_vmcnt<PA + PB0>(); else xl_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 1) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            XL_READ_A(0, buf)
+            XL_READ_B(0, TJ, buf)
+            if (t + 1 < nt) xl_wait_vmcnt<PA + PB0>(); else xl_wait_vmcnt<0>();
+            XL_SEG_END()
+            XL_MSEG(0, XL_PIECE_B(1, 0, t + 1), XL_PIECE_B(1, 1, t + 1), XL_PIECE_A(1, 0, t + 1), XL_PIECE_A(1, 1, t + 1))
+            XL_MMA_END()
+            XL_READ_A(1, buf)
+            if (t + 1 < nt) xl_wait_vmcnt<PA>();
+            XL_SEG_END()
+            XL_MSEG(1, XL_PIECE_A(0, 0, t + 2), XL_PIECE_A(0, 1, t + 2), XL_PIECE_B(0, 0, t + 2), XL_PIECE_B(0, 1, t + 2))
+            XL_MMA_END()
+        }
     }
     if (grp == 0) {                                              // balance the stagger
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
+#undef XL_PIECE_A
+#undef XL_PIECE_B
 #undef XL_ISSUE_A
 #undef XL_ISSUE_B
 #undef XL_READ_A
-#undef XL_READ_B0
-#undef XL_READ_B1
+#undef XL_READ_B
+#undef XL_READ_B_TO
+#undef XL_MMA_TO
 #undef XL_MMA
+#undef XL_MSEG
 #undef XL_SEG_END
 #undef XL_MMA_END
 
     // ---- epilogue ----
+    constexpr int NH = (BN == 320) ? 2 : 1;                       // the 320-wide bf16 tile goes through LDS in two 128-row halves
+    constexpr int HROWS = BM / NH;
     const bool geglu = p.epi == 1;
     const bool has_t = p.temb != nullptr && !geglu;
     const int BNo = geglu ? BN / 2 : BN;
     const int CSTR = BNo + 8;                                    // LDS row stride of the bf16 tile (elements); rows stay 16-byte aligned
-    bf16_t* Cs = (bf16_t*)smem;                                  // [256][CSTR], aliases the (dead) operand ring
-    float* addend = (float*)(smem + (size_t)BM * (BN + 8) * 2);  // [XL_SLOTS][BN] fp32, behind the largest C tile
+    bf16_t* Cs = (bf16_t*)smem;                                  // [HROWS][CSTR], aliases the (dead) operand ring
+    float* addend = (float*)(smem + (size_t)HROWS * (BN + 8) * 2);   // [XL_SLOTS][BN] fp32, behind the largest C staging tile
     const int b0 = has_t ? m0 / p.rows_per_b : 0;
     {
         const int nslots = has_t ? XL_SLOTS : 1;
@@ -347,97 +538,103 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
             addend[idx] = v;
         }
     }
-    __syncthreads();                                             // ring dead (every wave passed its last MFMA), addend visible
-    {
-        const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const int ml = wm * TI * 16 + i * 16 + fr;           // row inside the tile
-            int slot = 0;
-            if (has_t) slot = min(min(m0 + ml, p.M - 1) / p.rows_per_b - b0, XL_SLOTS - 1);
-            const float* ad = addend + slot * BN;
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                if (geglu && (j & 2)) continue;                   // gate tiles (columns 32..63 of a 64 group) are consumed with their value tile
-                const int nl = wn * TJ * 16 + j * 16 + 4 * fq;    // raw column inside the tile
-                const float4 a4 = *(const float4*)(ad + nl);
-                const float bb[4] = {a4.x, a4.y, a4.z, a4.w};
-                float o[4];
-                if (geglu) {
-                    const float4 g4 = *(const float4*)(ad + nl + 32);
-                    const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x = acc[i][j][e] + bb[e];
-                        const float gt = acc[i][(TJ > 2) ? (j | 2) : j][e] + gg[e];
-                        o[e] = x * gelu_erf_f(gt);
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = acc[i][j][e] + bb[e];
-                        if (p.epi == 2) x = silu_f(x);
-                        o[e] = x;
-                    }
-                }
-                const int cl = geglu ? ((nl >> 6) * 32 + (nl & 31)) : nl;
-                uint2 ov; ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]);
-                *(uint2*)(Cs + ml * CSTR + cl) = ov;
-            }
-        }
-    }
-    __syncthreads();
     const int n0o = geglu ? n0 / 2 : n0, Nout = geglu ? p.N / 2 : p.N;
     const bf16_t* Rg = p.R ? (const bf16_t*)p.R : nullptr;
     bf16_t* Cg = (bf16_t*)p.C;
-    if (p.wide) {
-        const int cpr = BNo >> 3;
-        const int total = BM * cpr;
 #pragma unroll 1
-        for (int i0 = 0; i0 < total; i0 += 4 * NTH) {
-            uint4 rv[4];
-            int row[4], c8[4];
-            bool ok[4];
+    for (int hh = 0; hh < NH; ++hh) {
+        __syncthreads();                                         // ring dead / previous half stored; addend visible
+        {
+            const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = i0 + u * NTH + tid;
-                row[u] = idx / cpr;
-                c8[u] = (idx - row[u] * cpr) * 8;
-                ok[u] = idx < total && m0 + row[u] < p.M && n0o + c8[u] < Nout;
-                rv[u] = make_uint4(0, 0, 0, 0);
-                if (Rg && ok[u]) rv[u] = *(const uint4*)(Rg + (long)(m0 + row[u]) * p.ldr + n0o + c8[u]);
-            }
+            for (int i = 0; i < TI; ++i) {
+                const int mt_ = wm * TI * 16 + i * 16;            // first row of this MFMA tile inside the block tile
+                if (NH > 1 && mt_ / HROWS != hh) continue;        // wave-uniform
+                const int ml = mt_ + fr;
+                int slot = 0;
+                if (has_t) slot = min(min(m0 + ml, p.M - 1) / p.rows_per_b - b0, XL_SLOTS - 1);
+                const float* ad = addend + slot * BN;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (!ok[u]) continue;
-                uint4 v = *(const uint4*)(Cs + row[u] * CSTR + c8[u]);
-                if (Rg) { v.x = add2bf(v.x, rv[u].x); v.y = add2bf(v.y, rv[u].y); v.z = add2bf(v.z, rv[u].z); v.w = add2bf(v.w, rv[u].w); }
-                *(uint4*)(Cg + (long)(m0 + row[u]) * p.ldc + n0o + c8[u]) = v;
+                for (int j = 0; j < TJ; ++j) {
+                    if (geglu && (j & 2)) continue;               // gate tiles (columns 32..63 of a 64 group) are consumed with their value tile
+                    const int nl = wn * TJ * 16 + j * 16 + 4 * fq;   // raw column inside the tile
+                    const float4 a4 = *(const float4*)(ad + nl);
+                    const float bb[4] = {a4.x, a4.y, a4.z, a4.w};
+                    float o[4];
+                    if (geglu) {
+                        const float4 g4 = *(const float4*)(ad + nl + 32);
+                        const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x = acc[i][j][e] + bb[e];
+                            const float gt = acc[i][(TJ == 4) ? (j | 2) : j][e] + gg[e];
+                            o[e] = x * gelu_erf_f(gt);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = acc[i][j][e] + bb[e];
+                            if (p.epi == 2) x = silu_f(x);
+                            o[e] = x;
+                        }
+                    }
+                    const int cl = geglu ? ((nl >> 6) * 32 + (nl & 31)) : nl;
+                    uint2 ov; ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]);
+                    *(uint2*)(Cs + (ml - hh * HROWS) * CSTR + cl) = ov;
+                }
             }
         }
-    } else {
-        const int cpr = BNo >> 2;
-        const int total = BM * cpr;
+        __syncthreads();
+        const int mh = m0 + hh * HROWS;
+        if (p.wide) {
+            const int cpr = BNo >> 3;
+            const int total = HROWS * cpr;
 #pragma unroll 1
-        for (int i0 = 0; i0 < total; i0 += 4 * NTH) {
-            uint2 rv[4];
-            int row[4], c4[4];
-            bool ok[4];
+            for (int i0 = 0; i0 < total; i0 += 4 * NTH) {
+                uint4 rv[4];
+                int row[4], c8[4];
+                bool ok[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = i0 + u * NTH + tid;
-                row[u] = idx / cpr;
-                c4[u] = (idx - row[u] * cpr) * 4;
-                ok[u] = idx < total && m0 + row[u] < p.M && n0o + c4[u] < Nout;
-                rv[u] = make_uint2(0, 0);
-                if (Rg && ok[u]) rv[u] = *(const uint2*)(Rg + (long)(m0 + row[u]) * p.ldr + n0o + c4[u]);
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = i0 + u * NTH + tid;
+                    row[u] = idx / cpr;
+                    c8[u] = (idx - row[u] * cpr) * 8;
+                    ok[u] = idx < total && mh + row[u] < p.M && n0o + c8[u] < Nout;
+                    rv[u] = make_uint4(0, 0, 0, 0);
+                    if (Rg && ok[u]) rv[u] = *(const uint4*)(Rg + (long)(mh + row[u]) * p.ldr + n0o + c8[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (!ok[u]) continue;
+                    uint4 v = *(const uint4*)(Cs + row[u] * CSTR + c8[u]);
+                    if (Rg) { v.x = add2bf(v.x, rv[u].x); v.y = add2bf(v.y, rv[u].y); v.z = add2bf(v.z, rv[u].z); v.w = add2bf(v.w, rv[u].w); }
+                    *(uint4*)(Cg + (long)(mh + row[u]) * p.ldc + n0o + c8[u]) = v;
+                }
             }
+        } else {
+            const int cpr = BNo >> 2;
+            const int total = HROWS * cpr;
+#pragma unroll 1
+            for (int i0 = 0; i0 < total; i0 += 4 * NTH) {
+                uint2 rv[4];
+                int row[4], c4[4];
+                bool ok[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (!ok[u]) continue;
-                uint2 v = *(const uint2*)(Cs + row[u] * CSTR + c4[u]);
-                if (Rg) { v.x = add2bf(v.x, rv[u].x); v.y = add2bf(v.y, rv[u].y); }
-                *(uint2*)(Cg + (long)(m0 + row[u]) * p.ldc + n0o + c4[u]) = v;
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = i0 + u * NTH + tid;
+                    row[u] = idx / cpr;
+                    c4[u] = (idx - row[u] * cpr) * 4;
+                    ok[u] = idx < total && mh + row[u] < p.M && n0o + c4[u] < Nout;
+                    rv[u] = make_uint2(0, 0);
+                    if (Rg && ok[u]) rv[u] = *(const uint2*)(Rg + (long)(mh + row[u]) * p.ldr + n0o + c4[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (!ok[u]) continue;
+                    uint2 v = *(const uint2*)(Cs + row[u] * CSTR + c4[u]);
+                    if (Rg) { v.x = add2bf(v.x, rv[u].x); v.y = add2bf(v.y, rv[u].y); }
+                    *(uint2*)(Cg + (long)(mh + row[u]) * p.ldc + n0o + c4[u]) = v;
+                }
             }
         }
     }
@@ -446,15 +643,16 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
 // LDS: operand ring (2 slabs) or the bf16 C tile, whichever is larger, + the addend rows
 template <int BN>
 constexpr size_t xl_smem_bytes() {
-    constexpr size_t ring = (size_t)2 * (256 + Geo<BN>::BNP) * 128, ctile = (size_t)256 * (BN + 8) * 2;
-    return (ring > ctile ? ring : ctile) + (size_t)XL_SLOTS * BN * sizeof(float);
+    constexpr size_t ring = (size_t)2 * (256 + Geo<BN>::BNP) * 128;
+    constexpr size_t epi = (size_t)(BN == 320 ? 128 : 256) * (BN + 8) * 2 + (size_t)XL_SLOTS * BN * sizeof(float);   // C staging + addend rows
+    return ring > epi ? ring : epi;
 }
 
-template <int BN, bool CONV>
+template <int BN, bool CONV, int SCHED>
 static int launch_xl(const GCParams& p, hipStream_t st) {
     constexpr size_t smem = xl_smem_bytes<BN>();
     static_assert(smem <= 163840, "LDS budget");
-    auto kern = gemm_xl_kernel<BN, CONV>;
+    auto kern = gemm_xl_kernel<BN, CONV, SCHED>;
     if (int rc = ensure_dyn_smem((const void*)kern, smem, "xl")) return rc;
     GCParams q = p;
     q.mt = (p.M + 255) / 256; q.nt = (p.N + BN - 1) / BN;
@@ -465,13 +663,14 @@ static int launch_xl(const GCParams& p, hipStream_t st) {
     const unsigned nblk = q.swz ? (unsigned)((q.mt + 7) / 8 * 8 * q.nt) : (unsigned)(q.mt * q.nt);
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), smem, st, q);
     char tag[96];
-    snprintf(tag, sizeof tag, "gemm_xl_kernel<256x%d,%s>", BN, CONV ? "conv" : "gemm");
+    snprintf(tag, sizeof tag, "gemm_xl_kernel<256x%d,%s>", BN, CONV ? "conv" : "gemm");   // (the schedule is a tuning knob, not part of the name)
     return check_launch(tag);
 }
 
 // Can the XL main loop run this problem at all?  (The caller's cost model decides whether it should.)  bn = 256 or 160.
 bool xl_supported(const GCParams& p, bool conv, int bn) {
     if (p.batch > 1 || p.splitk > 1 || p.c_f32 || (p.N % 4) || (p.K % 64) || p.Vt) return false;
+    if (bn != 256 && bn != 160 && bn != 320) return false;
     if (p.epi == 1 && (bn != 256 || (p.N % 64))) return false;
     if (conv) {
         if (p.kh != 3 || p.kw != 3 || p.ph != 1 || p.pw != 1 || (p.Cin % 64) || !p.cimajor) return false;   // pad 1: input pixel index monotonic in m
@@ -488,9 +687,16 @@ bool xl_supported(const GCParams& p, bool conv, int bn) {
     return true;
 }
 
+// MDX_XL_SCHED: 0 (default) = four quadrant phases per slab, refill in the load segments; 1 = two phases per slab with the DMA
+// issued between the MFMAs (measured 10 % slower: the DMA issue lengthens the MFMA segments, which are the serial resource);
+// 2 / 3 = quadrant variants (see the kernel).
 int launch_gemm_xl(const GCParams& p, bool conv, int bn, hipStream_t st) {
-    if (bn == 256) return conv ? launch_xl<256, true>(p, st) : launch_xl<256, false>(p, st);
-    return conv ? launch_xl<160, true>(p, st) : launch_xl<160, false>(p, st);
+    static const int sched = [] { const char* e = getenv("MDX_XL_SCHED"); return e ? atoi(e) : 0; }();
+#define XL_GO(BN_, S_) (conv ? launch_xl<BN_, true, S_>(p, st) : launch_xl<BN_, false, S_>(p, st))
+    if (bn == 320) return XL_GO(320, 0);
+    if (bn == 256) return sched == 1 ? XL_GO(256, 1) : sched == 2 ? XL_GO(256, 2) : sched == 3 ? XL_GO(256, 3) : XL_GO(256, 0);
+    return sched == 1 ? XL_GO(160, 1) : sched == 2 ? XL_GO(160, 2) : sched == 3 ? XL_GO(160, 3) : XL_GO(160, 0);
+#undef XL_GO
 }
 
 }  // namespace mdx

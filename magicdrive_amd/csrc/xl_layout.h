@@ -5,6 +5,7 @@
 // Geometry: tile 256 x BN x 64, 8 waves.  16x16x32 bf16 MFMA tiles: a wave owns TI x TJ of them.
 //   BN = 256: waves 2 (M) x 4 (N), wave tile 128 x 64  (TI = 8, TJ = 4)
 //   BN = 160: waves 4 (M) x 2 (N), wave tile  64 x 80  (TI = 4, TJ = 5)
+//   BN = 320: waves 2 (M) x 4 (N), wave tile 128 x 80  (TI = 8, TJ = 5)
 // LDS buffer (one K slab of 64): A rows [0, 256) then B rows [0, BNP), 128 B per row, UNPADDED (the LDS-DMA writes 1 KiB = 8 rows per
 // wave instruction, lane l -> row l >> 3, 16-byte slot l & 7); the slot index is XOR-swizzled by (row >> 1) & 7 on the SOURCE side
 // (lane l fetches logical chunk (l & 7) ^ swz(row)) and again on the fragment reads (rule: linear destination, same involution on
@@ -30,6 +31,12 @@ template <> struct Geo<256> {
     static constexpr int TJ0 = 2;                              // tiles in the wave's first column part (B0); the rest is B1
     static constexpr int BNP = 256;                            // B rows held in LDS (incl. scratch)
     static constexpr int PA = 2, PB0 = 2, PB1 = 2;             // 1-KiB pieces per wave per unit (A0 = A1 = PA)
+};
+template <> struct Geo<320> {                                      // waves 2 x 4, wave tile 128 x 80: the widest tile the registers allow
+    static constexpr int WM = 2, WN = 4, TI = 8, TJ = 5;          // (160 accumulators; B0 = 3 column tiles, B1 = 2 share one register set)
+    static constexpr int TJ0 = 3;
+    static constexpr int BNP = 320;
+    static constexpr int PA = 2, PB0 = 3, PB1 = 2;
 };
 template <> struct Geo<160> {
     static constexpr int WM = 4, WN = 2, TI = 4, TJ = 5;

@@ -52,13 +52,13 @@ def run_one(op):
 @pytest.mark.parametrize("M,N,K,bias,res,inplace,epi,expect", [
     (41037, 1280, 1280, True, True, False, 0, "gemm_xl_kernel<256x"),              # ragged M, residual
     (41000, 640, 640, True, False, False, 2, "gemm_xl_kernel<256x"),                # SiLU epilogue
-    (82000, 320, 1280, True, True, True, 0, "gemm_xl_kernel<256x160,gemm>"),        # ff.out at level 0: in-place residual (R == C)
-    (82000, 160, 640, True, False, False, 0, "gemm_xl_kernel<256x160,gemm>"),       # one 160-wide N tile
+    (82000, 320, 1280, True, True, True, 0, "gemm_xl_kernel<256x"),        # ff.out at level 0: in-place residual (R == C)
+    (82000, 160, 640, True, False, False, 0, "gemm_xl_kernel<256x"),       # one 160-wide N tile
     (41000, 644, 640, False, False, False, 0, "gemm_xl_kernel<256x"),               # N % 8 != 0: narrow stores, ragged last N tile
     (45000, 1920, 640, True, False, False, 0, "gemm_xl_kernel<256x"),               # fused q|k|v width at level 1
-    (40960, 256, 64, True, False, False, 0, "gemm_xl_kernel<256x256,gemm>"),        # a single K slab (prologue == whole loop)
-    (40960, 512, 128, False, True, False, 0, "gemm_xl_kernel<256x256,gemm>"),       # two slabs
-    (40960, 512, 192, True, True, False, 0, "gemm_xl_kernel<256x256,gemm>"),        # three slabs (odd count: both ring buffers end mid-cycle)
+    (40960, 256, 64, True, False, False, 0, "gemm_xl_kernel<256x"),        # a single K slab (prologue == whole loop)
+    (40960, 512, 128, False, True, False, 0, "gemm_xl_kernel<256x"),       # two slabs
+    (40960, 512, 192, True, True, False, 0, "gemm_xl_kernel<256x"),        # three slabs (odd count: both ring buffers end mid-cycle)
 ])
 def test_xl_gemm(dev, M, N, K, bias, res, inplace, epi, expect):
     A = rnd(M, K, seed=1); W = rnd(N, K, scale=K ** -0.5, seed=2)
@@ -121,12 +121,12 @@ def conv_ref(x, w, b, stride, pad, tb, R, epi=0):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,res,temb,expect", [
-    (48, 28, 50, 320, 320, (1, 1), True, True, "gemm_xl_kernel<256x160,conv>"),      # level 0 resnet conv; tiles straddle image rows
+    (48, 28, 50, 320, 320, (1, 1), True, True, "gemm_xl_kernel<256x"),      # level 0 resnet conv; tiles straddle image rows
     (120, 14, 25, 640, 640, (1, 1), True, False, "gemm_xl_kernel<256x"),             # 350-px images: every tile crosses an image
     (480, 7, 13, 1280, 1280, (1, 1), True, True, "gemm_xl_kernel<256x"),             # 91-px images: 3-4 images (temb rows) per tile
     (1470, 4, 7, 1280, 1280, (1, 1), False, True, "gemm_xl_kernel<256x"),            # 28-px images: 10-11 images per tile (the bench's mid block)
-    (240, 28, 50, 320, 320, (2, 2), False, False, "gemm_xl_kernel<256x160,conv>"),   # Downsample2D: stride 2, 28x50 -> 14x25
-    (420, 9, 11, 64, 256, (1, 1), False, False, "gemm_xl_kernel<256x256,conv>"),     # one channel block; odd sizes
+    (240, 28, 50, 320, 320, (2, 2), False, False, "gemm_xl_kernel<256x"),   # Downsample2D: stride 2, 28x50 -> 14x25
+    (420, 9, 11, 64, 256, (1, 1), False, False, "gemm_xl_kernel<256x"),     # one channel block; odd sizes
     (130, 14, 25, 1920, 640, (1, 1), False, True, "gemm_xl_kernel<256x"),            # up-block concat width, ragged M tile
 ])
 def test_xl_conv(dev, B, H, W, Cin, Cout, stride, res, temb, expect):
@@ -144,67 +144,20 @@ def test_xl_conv(dev, B, H, W, Cin, Cout, stride, res, temb, expect):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-# The round-1 main loops stay behind the XL kernel for mid-size grids (4-16 scenes per GPU): force each and check it.
-@pytest.mark.parametrize("M,N,K,geglu,expect", [
-    (8736, 1024, 1280, False, "gemm_pp_kernel<256x256,gemm>"),        # 35 x 4 = 140 tiles of 256: under the XL threshold, two rounds of 128-tiles
-    (8736, 1024, 1280, True, "gemm_pp_kernel<256x256,gemm>"),         # packed GEGLU
-    (4500, 2048, 1280, False, "gemm_pp_kernel<256x256,gemm>"),        # ragged M (not a multiple of 256)
+# Forced routes.  The library reads its routing switches from the environment once per process, so each forced configuration runs
+# tests/route_worker.py in its own interpreter: every XL tile width on small ragged shapes (MDX_GEMM_XL=2: whenever supported), and
+# the round-1 main loops (gemm_pp, conv3x3, gemm_ws) with the XL kernel switched off, at the shapes the round-1 review listed.
+@pytest.mark.parametrize("mode,env", [
+    ("xl320", {"MDX_GEMM_XL": "2", "MDX_XL_BN": "320"}),
+    ("xl256", {"MDX_GEMM_XL": "2", "MDX_XL_BN": "256"}),
+    ("xl160", {"MDX_GEMM_XL": "2", "MDX_XL_BN": "160"}),
+    ("noxl", {"MDX_GEMM_XL": "0"}),
 ])
-def test_pp_gemm_route(dev, M, N, K, geglu, expect):
-    A = rnd(M, K, seed=1)
-    if geglu:
-        W = rnd(N, K, scale=K ** -0.5, seed=2, dtype=torch.float32); b = rnd(N, seed=3, dtype=torch.float32)
-        Wp, bp = PK.pack_geglu(W.cpu(), b.cpu())
-        C = torch.zeros(M, N // 2, dtype=BF, device=dev)
-        op = O.Gemm(A, Wp.to(dev), C, bias=bp.to(dev), epilogue=L.EPI_GEGLU, ws=ws_buf())
-        h, g = (A.float() @ W.to(BF).float().T + b).chunk(2, dim=-1)
-        ref = h * F.gelu(g)
-    else:
-        W = rnd(N, K, scale=K ** -0.5, seed=2); b = rnd(N, seed=3, dtype=torch.float32); R = rnd(M, N, seed=4)
-        C = torch.zeros(M, N, dtype=BF, device=dev)
-        op = O.Gemm(A, W, C, bias=b, R=R, ws=ws_buf())
-        ref = A.float() @ W.float().T + b + R.float()
-    k = run_one(op)
-    close(C, ref, name=f"pp gemm {M}x{N}x{K} ({k})")
-    assert k == expect, k
-
-
-@pytest.mark.parametrize("B,H,W,Cin,Cout,res,temb", [
-    (48, 7, 13, 1280, 1280, True, True),       # 4368 rows, 5 N tiles: tiles span 3 images -> temb slots
-    (12, 14, 25, 1920, 1280, False, True),     # 4200 rows
-    (160, 4, 7, 1280, 1280, True, True),       # 4x7 images: 10 images per 256-row tile (> 8 slots: pp must decline, whoever takes it must be right)
-])
-def test_mid_grid_convs(dev, B, H, W, Cin, Cout, res, temb):
-    x = rnd(B, H, W, Cin, seed=1)
-    w = rnd(Cout, Cin, 3, 3, scale=(Cin * 9) ** -0.5, seed=2, dtype=torch.float32)
-    b = rnd(Cout, seed=3, dtype=torch.float32)
-    y = torch.full((B, H, W, Cout), float("nan"), dtype=BF, device=dev)
-    R = rnd(B, H, W, Cout, seed=4) if res else None
-    tb = rnd(B, Cout, seed=5, dtype=torch.float32) if temb else None
-    k = run_one(O.Conv(x, PK.pack_conv_weight(w.cpu()).to(dev), y, bias=b, R=R, temb=tb, temb_b_stride=Cout if temb else 0, ws=ws_buf()))
-    assert k.startswith(("gemm_pp_kernel", "gemm_conv_kernel", "conv3x3_kernel", "gemm_xl_kernel")), k
-    print(f"mid-grid conv {B}x{H}x{W} {Cin}->{Cout}: {k}")
-    close(y, conv_ref(x, w, b, (1, 1), (1, 1), tb, R), name=f"mid conv {k}")
-
-
-@pytest.mark.parametrize("B,H,W,C", [(12, 28, 50, 320), (7, 28, 50, 640), (160, 4, 7, 320), (9, 28, 28, 320)])
-def test_conv3x3_route(dev, B, H, W, C):
-    """conv3x3.hip (3 taps share one A slab) between its 4096-row threshold and the XL threshold; incl. 4x7 images and 28-px rows
-    straddling 128-row tiles."""
-    x = rnd(B, H, W, C, seed=1)
-    w = rnd(C, C, 3, 3, scale=(C * 9) ** -0.5, seed=2, dtype=torch.float32); b = rnd(C, seed=3, dtype=torch.float32)
-    y = torch.full((B, H, W, C), float("nan"), dtype=BF, device=dev)
-    R = rnd(B, H, W, C, seed=4); tb = rnd(B, C, seed=5, dtype=torch.float32)
-    k = run_one(O.Conv(x, PK.pack_conv_weight(w.cpu()).to(dev), y, bias=b, R=R, temb=tb, temb_b_stride=C, ws=ws_buf()))
-    close(y, conv_ref(x, w, b, (1, 1), (1, 1), tb, R), name=f"conv3x3 {B}x{H}x{W}x{C} ({k})")
-    assert k == "conv3x3_kernel", k
-
-
-def test_ws_gemm_at_bench_rows(dev):
-    """gemm_ws.hip at the bench's row count (M = 537600 = 384 views x 1400 tokens): persistent walkers over 4200 M tiles."""
-    M, N, K = 537600, 320, 320
-    A = rnd(M, K, seed=1); W = rnd(N, K, scale=K ** -0.5, seed=2); b = rnd(N, seed=3, dtype=torch.float32); R = rnd(M, N, seed=4)
-    C = torch.zeros(M, N, dtype=BF, device=dev)
-    k = run_one(O.Gemm(A, W, C, bias=b, R=R, ws=ws_buf()))
-    assert k in ("gemm_ws_kernel<plain>", "gemm_xl_kernel<256x160,gemm>"), k
-    close(C, A.float() @ W.float().T + b + R.float(), name=f"ws gemm at bench rows ({k})")
+def test_forced_routes(dev, mode, env):
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(here, "route_worker.py"), mode], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ROUTE_WORKER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

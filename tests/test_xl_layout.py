@@ -17,4 +17,4 @@ def test_xl_layout_model(tmp_path):
     subprocess.run([gxx, "-O1", "-std=c++17", "-o", exe, os.path.join(HERE, "xl_layout_check.cpp")], check=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "BN=256: ok" in r.stdout and "BN=160: ok" in r.stdout
+    assert "BN=256: ok" in r.stdout and "BN=160: ok" in r.stdout and "BN=320: ok" in r.stdout

@@ -103,6 +103,6 @@ static int check() {
 }
 
 int main() {
-    int e = check<256>() + check<160>();
+    int e = check<256>() + check<160>() + check<320>();
     return e ? 1 : 0;
 }

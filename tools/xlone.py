@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""Time a few representative shapes of the XL GEMM / conv main loop (gemm_xl.hip) — the A/B tool for its schedule knobs.
+Usage: [MDX_XL_DBG=..] python tools/xlone.py [--views 384] [--reps 10] [--only c160,c256,...]"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from magicdrive_amd import _lib as L, ops as O  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--views", type=int, default=384)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--only", type=str, default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda")
+    B = a.views
+    ws = torch.empty(64 * 1024 * 1024 // 4, dtype=torch.float32, device=dev)
+    r = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(BF)
+    cases = {}
+
+    def conv(name, h, w, cin, cout):
+        def mk():
+            x = r(B, h, w, cin); wt = r(cout, 3, 3, cin); y = torch.empty(B, h, w, cout, dtype=BF, device=dev)
+            return O.Conv(x, wt, y, bias=torch.randn(cout, device=dev), R=r(B, h, w, cout), ws=ws), 2.0 * B * h * w * cout * 9 * cin
+        cases[name] = mk
+
+    def gemm(name, M, N, K, epi=0, res=False):
+        def mk():
+            A = r(M, K); W = r(N, K); No = N // 2 if epi == 1 else N
+            C = torch.empty(M, No, dtype=BF, device=dev)
+            return O.Gemm(A, W, C, bias=torch.randn(N, device=dev), R=r(M, No) if res else None, epilogue=epi, ws=ws), 2.0 * M * N * K
+        cases[name] = mk
+
+    conv("c160_28x50_640_640", 28, 50, 640, 640)
+    conv("c160_28x50_320_320", 28, 50, 320, 320)
+    conv("c256_14x25_1280_1280", 14, 25, 1280, 1280)
+    conv("c256_7x13_1280_1280", 7, 13, 1280, 1280)
+    gemm("g256_geglu_L1", B * 350, 5120, 640, epi=1)
+    gemm("g256_ffout_L1", B * 350, 640, 2560, res=True)
+    gemm("g160_ffout_L0", B * 1400, 320, 1280, res=True)
+    gemm("g256_qk_L1", B * 350, 1280, 640)
+    gemm("g_geglu_L0", B * 1400, 2560, 320, epi=1)
+    gemm("g_out_L0", B * 1400, 320, 320, res=True)
+    only = [s for s in a.only.split(",") if s]
+    st = torch.cuda.current_stream().cuda_stream
+    for name, mk in cases.items():
+        if only and not any(name.startswith(o) for o in only):
+            continue
+        op, fl = mk()
+        code, desc = op.lower()
+        for _ in range(2):
+            L.call_op(code, desc, st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.reps):
+            L.call_op(code, desc, st)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / a.reps * 1e3
+        print(f"{name:26s} {us:9.1f} us {fl / us / 1e6:8.1f} TF/s  {(L.lib().mdx_last_kernel() or b'').decode()}", flush=True)
+        del op
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
