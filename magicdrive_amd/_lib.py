@@ -157,10 +157,15 @@ class Program:
             self.capture()
         check(lib().mdx_graph_launch(self._graph, C.c_void_p(stream)), "mdx_graph_launch")
 
+    def destroy(self) -> None:
+        """Release the captured hipGraph (idempotent)."""
+        if self._graph and _LIB is not None:
+            _LIB.mdx_graph_destroy(self._graph)
+        self._graph = C.c_void_p(None)
+
     def __del__(self):
         try:
-            if self._graph and _LIB is not None:
-                _LIB.mdx_graph_destroy(self._graph)
+            self.destroy()
         except Exception:
             pass
 

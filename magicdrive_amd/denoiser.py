@@ -34,8 +34,59 @@ def _rows_as_pixels(t2d: torch.Tensor) -> torch.Tensor:
     return torch.as_strided(t2d, (M, 1, 1, C), (ld, ld, ld, 1), t2d.storage_offset())
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0
+def device_stream(device=None) -> int:
+    """Raw hipStream_t of torch's current stream ON `device` (not on whatever device happens to be current)."""
+    if not torch.cuda.is_available():
+        return 0
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _stream(device=None) -> int:
+    return device_stream(device)
+
+
+class PlanCache:
+    """Small LRU of plans keyed by batch geometry.  A plan owns a 64 MB workspace, its activation pool, K/V and temb tables and a
+    captured hipGraph; the reference's validation flow changes the padded box count (and with it the plan key) almost every batch,
+    so an unbounded dict would accumulate ~100 plans per batch size.  Evicted plans release their graph and device buffers.
+    Size: MDX_PLAN_CACHE (default 4)."""
+
+    def __init__(self, maxsize: Optional[int] = None):
+        import os
+        from collections import OrderedDict
+        self.maxsize = maxsize if maxsize is not None else max(1, int(os.environ.get("MDX_PLAN_CACHE", "4")))
+        self._d = OrderedDict()
+
+    def get(self, key):
+        p = self._d.get(key)
+        if p is not None:
+            self._d.move_to_end(key)
+        return p
+
+    def put(self, key, plan):
+        self._d[key] = plan
+        self._d.move_to_end(key)
+        while len(self._d) > self.maxsize:
+            _, old = self._d.popitem(last=False)
+            rel = getattr(old, "release", None)
+            if rel is not None:
+                rel()
+
+    def clear(self):
+        for old in self._d.values():
+            rel = getattr(old, "release", None)
+            if rel is not None:
+                rel()
+        self._d.clear()
+
+    def values(self):
+        return self._d.values()
+
+    def __len__(self):
+        return len(self._d)
+
+    def __contains__(self, key):
+        return key in self._d
 
 
 class ConditioningBuffers:
@@ -45,6 +96,7 @@ class ConditioningBuffers:
     def __init__(self, bld: Builder, cn: PackedNet, cfg, n_scene: int, n_cam: int, L_box: int, latent_hw, n_text: int = 77):
         dev = bld.device
         cc = cfg["controlnet"]; bb = cc["bbox"]
+        self.minmax_normalize = bool(bb.get("minmax_normalize", False))
         self.n_scene, self.n_cam, self.L = n_scene, n_cam, L_box
         B = n_scene * n_cam
         D = cfg["cross_attention_dim"]
@@ -177,7 +229,10 @@ class ConditioningBuffers:
                 assert bb.shape[1] == 1
                 bb = bb.expand(ns, nc, *bb.shape[2:]); cl = cl.expand(ns, nc, -1); mk = mk.expand(ns, nc, -1)
             assert bb.shape[2] == self.L, f"boxes padded to {bb.shape[2]} but plan built for L={self.L}"
-            self.box_in.copy_(bb.to(self.box_in.device, F32).reshape(-1, *bb.shape[3:]))
+            bb = bb.to(self.box_in.device, F32)
+            if self.minmax_normalize:          # normalizer('all-xyz'): (xyz - XYZ_MIN) / XYZ_RANGE (bbox_embedder.py:10-25, :175-176)
+                bb = (bb - bb.new_tensor([-200.0, -300.0, -20.0])) / bb.new_tensor([350.0, 650.0, 80.0])
+            self.box_in.copy_(bb.reshape(-1, *bb.shape[3:]))
             self.box_cls.copy_(cl.to(self.box_cls.device, torch.int64).reshape(-1))
             self.box_mask.copy_(mk.to(self.box_mask.device).reshape(-1).to(torch.uint8))
 
@@ -280,6 +335,16 @@ class SamplerPlan:
         self.prologue = O.build_program(self.prologue_ops)
         self.step = O.build_program(self.step_ops)
 
+    def release(self):
+        """Drop the captured graph and every device buffer this plan owns (called on LRU eviction)."""
+        for prog in (self.prologue, self.step):
+            if prog is not None:
+                prog.destroy()
+        self.prologue = self.step = None
+        self.prologue_ops = self.step_ops = []
+        self.bld = None
+        self.cond = self.temb_cn = self.temb_un = self.kv_cn = self.kv_un = None
+
     # ---- per-call inputs ----
     def load_inputs(self, latents: torch.Tensor, camera_param, text, bev_map, boxes, timesteps: torch.Tensor, coef: torch.Tensor,
                     given_mask: Optional[torch.Tensor] = None, given_latents: Optional[torch.Tensor] = None):
@@ -313,7 +378,7 @@ class SamplerPlan:
         """prologue + num_steps denoising steps on the current stream; returns latents (b, n_cam, C, h, w) fp32."""
         if self.prologue is None:
             self.compile()
-        st = _stream()
+        st = _stream(self.device)
         self.prologue.run(st)
         for _ in range(self.num_steps):
             if use_graph:
@@ -370,7 +435,8 @@ class ControlNetPlan:
             t = t.repeat_interleave(self.n_cam)                      # unet_addon_rawbox.py:840-841
         self.temb.t.copy_(t)
         self.cond.load(camera_param, text, bev_map, boxes)
-        self.program.run(_stream())
+        with torch.cuda.device(self.device):
+            self.program.run(_stream(self.device))
         return self.down_out, self.mid_out, self.cond.ctx
 
 
@@ -431,5 +497,6 @@ class UNetPlan:
             for dst, src in zip(self.res_in, down_res):
                 dst.copy_(src.to(self.device, BF16))
             self.mid_in.copy_(mid_res.to(self.device, BF16))
-        self.program.run(_stream())
+        with torch.cuda.device(self.device):
+            self.program.run(_stream(self.device))
         return self.out_nchw

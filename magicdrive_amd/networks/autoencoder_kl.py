@@ -19,6 +19,7 @@ import torch
 from . import spec
 from ..engine import PackedNet
 from ..vae import VaeDecodePlan
+from ..denoiser import PlanCache
 
 CONFIG_NAME = "config.json"
 WEIGHTS_ST, WEIGHTS_BIN = "diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.bin"
@@ -42,7 +43,7 @@ class AutoencoderKL:
         self._dtype = torch_dtype
         self._device = torch.device("cpu")
         self._packed: Optional[PackedNet] = None
-        self._plans: Dict[tuple, VaeDecodePlan] = {}
+        self._plans = PlanCache()
         self.config = SimpleNamespace(**self.vcfg)
         self.max_images_per_pass = 6          # one scene's views per program run (bounds activation memory: 138 MB per 128-ch 224x400 map)
 
@@ -106,12 +107,16 @@ class AutoencoderKL:
     def eval(self):
         return self
 
-    def to(self, device=None, dtype=None):
-        if device is not None:
-            dev = torch.device(device)
-            if dev != self._device:
-                self._device, self._packed = dev, None
-                self._plans.clear()
+    def to(self, *args, **kw):
+        """.to(device) / .to(dtype) / .to(device, dtype) like a torch module (dtype = API dtype of decode()'s output)."""
+        for a in list(args) + list(kw.values()):
+            if isinstance(a, torch.dtype):
+                self._dtype = a
+            elif isinstance(a, (str, torch.device)):
+                dev = torch.device(a)
+                if dev != self._device:
+                    self._device, self._packed = dev, None
+                    self._plans.clear()
         return self
 
     @property
@@ -145,9 +150,10 @@ class AutoencoderKL:
             key = (zi.shape[0], h, w)
             plan = self._plans.get(key)
             if plan is None:
-                plan = VaeDecodePlan(self.vcfg, self.packed(), self._device, zi.shape[0], (h, w))
-                plan.compile()
-                self._plans[key] = plan
+                with torch.cuda.device(self._device):
+                    plan = VaeDecodePlan(self.vcfg, self.packed(), self._device, zi.shape[0], (h, w))
+                    plan.compile()
+                self._plans.put(key, plan)
             outs.append(plan.run(zi).to(z.dtype if z.dtype.is_floating_point else torch.float32))
         sample = torch.cat(outs)
         return DecoderOutput(sample=sample) if return_dict else (sample,)

@@ -17,6 +17,7 @@ from typing import Dict, Optional
 import torch
 
 from ..engine import PackedNet
+from ..denoiser import PlanCache
 from . import spec
 
 WEIGHTS_BIN = "diffusion_pytorch_model.bin"
@@ -66,6 +67,21 @@ def arch_config_from_json(js: Dict, base: Optional[Dict] = None) -> Dict:
                 cn["bbox"][k] = bp[k]
         if "proj_dims" in bp:
             cn["bbox"]["proj_dims"] = tuple(bp["proj_dims"])
+        # ContinuousBBoxWithTextEmbedding's class default is minmax_normalize=True (bbox_embedder.py:42); the shipped config sets
+        # false (configs/model/SDv1.5mv_rawbox.yaml:56).  A config that omits the key means the class default.
+        cn["bbox"]["minmax_normalize"] = bool(bp.get("minmax_normalize", True))
+        if bp.get("mode", "all-xyz") not in ("all-xyz", "cxyz"):
+            raise NotImplementedError(f"bbox_embedder mode={bp['mode']!r} (bbox_embedder.py:14-25 builds cxyz / all-xyz only)")
+    # classifier-free-guidance map substitution (unet_addon_rawbox.py:188-202, 674-677): an `uncond_map` buffer exists in the
+    # checkpoint only when use_uncond_map is set AND drop_cond_ratio > 0
+    um, dr = js.get("use_uncond_map"), js.get("drop_cond_ratio", 0.0) or 0.0
+    if um is not None:
+        if um not in ("negative1", "random", "learnable"):
+            raise TypeError(f"Unknown map type: {um}.")                 # the reference's error (:200)
+        cn["use_uncond_map"] = um if dr > 0 else None
+    for k in ("guess_mode",):
+        if js.get(k):
+            raise NotImplementedError(f"config option {k}={js[k]!r} is outside the built hot path")
     return cfg
 
 
@@ -87,7 +103,7 @@ class MdxModel:
         self._dtype = torch_dtype
         self._device = torch.device("cpu")
         self._packed: Optional[PackedNet] = None
-        self._plans: Dict[tuple, object] = {}
+        self._plans = PlanCache()          # LRU: module-API plans are keyed by (batch, padded box count, size, ...)
         self.config = SimpleNamespace(**{k: v for k, v in self.cfg.items() if k != "controlnet"})
         self.training = False
 
@@ -121,6 +137,7 @@ class MdxModel:
         with open(os.path.join(path, CONFIG_NAME), "w") as f:
             json.dump(js, f, indent=2)
         sd = {k: v.contiguous() for k, v in self._sd.items()}
+        sd.update({k: v.contiguous() for k, v in self._extra_tensors().items()})
         if safe_serialization:
             from safetensors.torch import save_file
             save_file(sd, os.path.join(path, WEIGHTS_ST))
@@ -129,6 +146,10 @@ class MdxModel:
 
     def _extra_config(self, js):
         pass
+
+    def _extra_tensors(self) -> Dict[str, torch.Tensor]:
+        """Tensors outside the architecture's shape table that belong in the checkpoint (e.g. the ControlNet's uncond_map)."""
+        return {}
 
     # ---- torch-module-like surface the reference's callers touch ----
     def state_dict(self):

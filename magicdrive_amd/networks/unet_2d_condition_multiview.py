@@ -35,9 +35,12 @@ class UNet2DConditionModelMultiview(MdxModel):
         S = encoder_hidden_states.shape[1]
         with_res = down_block_additional_residuals is not None
         key = (B, S, h, w, with_res)
-        if key not in self._plans:
-            self._plans[key] = UNetPlan(self.cfg, self.packed(), self._device, B, S, (h, w), with_residuals=with_res)
-        out = self._plans[key].run(sample, timestep, encoder_hidden_states, down_block_additional_residuals, mid_block_additional_residual)
+        plan = self._plans.get(key)
+        if plan is None:
+            with torch.cuda.device(self._device):
+                plan = UNetPlan(self.cfg, self.packed(), self._device, B, S, (h, w), with_residuals=with_res)
+            self._plans.put(key, plan)
+        out = plan.run(sample, timestep, encoder_hidden_states, down_block_additional_residuals, mid_block_additional_residual)
         out = out.to(sample.dtype if sample.is_floating_point() else self._dtype).clone()
         if not return_dict:
             return (out,)

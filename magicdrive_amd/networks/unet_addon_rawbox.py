@@ -20,6 +20,19 @@ from .output_cls import BEVControlNetOutput
 class BEVControlNetModel(MdxModel):
     _shape_fn = staticmethod(spec.controlnet_param_shapes)
 
+    def __init__(self, cfg, state_dict, torch_dtype=torch.bfloat16):
+        super().__init__(cfg, state_dict, torch_dtype)
+        # `uncond_map` (C, H, W): present in a checkpoint trained with use_uncond_map + drop_cond_ratio > 0
+        # (unet_addon_rawbox.py:188-202); it replaces the BEV map of the unconditional half under CFG (:674-677).
+        self._uncond_map = None
+        if self.cfg["controlnet"].get("use_uncond_map"):
+            if "uncond_map" not in state_dict:
+                raise KeyError("BEVControlNetModel: config sets use_uncond_map but the state dict has no 'uncond_map'")
+            um = state_dict["uncond_map"].detach().float()
+            if tuple(um.shape) != tuple(self.cfg["controlnet"]["map_size"]):
+                raise ValueError(f"uncond_map has shape {tuple(um.shape)}, config map_size is {tuple(self.cfg['controlnet']['map_size'])}")
+            self._uncond_map = um
+
     def _extra_config(self, js):
         cn = self.cfg["controlnet"]
         js.update(camera_in_dim=cn["camera_in_dim"], camera_out_dim=cn["camera_out_dim"], map_size=list(cn["map_size"]),
@@ -27,9 +40,15 @@ class BEVControlNetModel(MdxModel):
                   uncond_cam_in_dim=list(cn["uncond_cam_in_dim"]),
                   cam_embedder_param=dict(input_dims=3, num_freqs=cn["cam_embedder_num_freqs"], include_input=True, log_sampling=True),
                   bbox_embedder_param=dict(n_classes=cn["bbox"]["n_classes"], class_token_dim=cn["bbox"]["class_token_dim"],
-                                           embedder_num_freq=cn["bbox"]["embedder_num_freq"], proj_dims=list(cn["bbox"]["proj_dims"])))
+                                           embedder_num_freq=cn["bbox"]["embedder_num_freq"], proj_dims=list(cn["bbox"]["proj_dims"]),
+                                           minmax_normalize=bool(cn["bbox"].get("minmax_normalize", False)), mode="all-xyz"))
+        if cn.get("use_uncond_map"):
+            js.update(use_uncond_map=cn["use_uncond_map"], drop_cond_ratio=0.25)
         if cn.get("map_embedder_cls"):
             js.update(map_embedder_cls=cn["map_embedder_cls"], map_embedder_param={k: list(v) for k, v in cn["map_embedder_param"].items()})
+
+    def _extra_tensors(self):
+        return {} if self._uncond_map is None else {"uncond_map": self._uncond_map}
 
     @property
     def uncond_cam_num(self) -> int:
@@ -67,7 +86,10 @@ class BEVControlNetModel(MdxModel):
                     pad = torch.zeros_like(v[:, :, :1]).expand(-1, -1, token_num, *v.shape[3:])
                     v = torch.cat([v, pad], dim=2)
                 ret["bboxes_3d_data"][key] = v
-        ret["image"] = image          # use_uncond_map is null in the shipped config (SDv1.5mv_rawbox.yaml:35)
+        if self._uncond_map is None:  # use_uncond_map is null in the shipped config (SDv1.5mv_rawbox.yaml:36): the map is kept
+            ret["image"] = image
+        else:                         # substitute_with_uncond_map(image, None): every sample's map <- uncond_map (:378-395, :677)
+            ret["image"] = self._uncond_map.to(image.device, image.dtype)[None].expand_as(image).clone()
         for k, v in kwargs.items():
             ret[k] = v
         return ret
@@ -84,10 +106,13 @@ class BEVControlNetModel(MdxModel):
         b, n_cam, _, h, w = sample.shape
         L = 0 if bboxes_3d_data is None else bboxes_3d_data["bboxes"].shape[2]
         key = (b, L, h, w, float(conditioning_scale))
-        if key not in self._plans:
-            self._plans[key] = ControlNetPlan(self.cfg, self.packed(), self._device, b, L, (h, w), conditioning_scale,
-                                              n_text=encoder_hidden_states.shape[1])
-        down, mid, ctx = self._plans[key].run(sample, timestep, camera_param, bboxes_3d_data, encoder_hidden_states, controlnet_cond)
+        plan = self._plans.get(key)
+        if plan is None:
+            with torch.cuda.device(self._device):
+                plan = ControlNetPlan(self.cfg, self.packed(), self._device, b, L, (h, w), conditioning_scale,
+                                      n_text=encoder_hidden_states.shape[1])
+            self._plans.put(key, plan)
+        down, mid, ctx = plan.run(sample, timestep, camera_param, bboxes_3d_data, encoder_hidden_states, controlnet_cond)
         odt = sample.dtype if sample.is_floating_point() else self._dtype
         down = [d.to(odt).clone() for d in down]
         mid = mid.to(odt).clone()

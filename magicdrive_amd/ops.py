@@ -512,7 +512,20 @@ def build_program(ops) -> L.Program:
 def run_ops(ops, stream: Optional[int] = None) -> None:
     """Eagerly launch a list of IR ops on `stream` (default: torch's current stream)."""
     if stream is None:
-        stream = torch.cuda.current_stream().cuda_stream
+        dev = None
+        for op in ops:                       # launch on the device that owns the operands, not on whatever device is current
+            for v in vars(op).values():
+                if isinstance(v, torch.Tensor) and v.is_cuda:
+                    dev = v.device
+                    break
+            if dev is not None:
+                break
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            for op in ops:
+                code, desc = op.lower()
+                L.call_op(code, desc, stream)
+        return
     for op in ops:
         code, desc = op.lower()
         L.call_op(code, desc, stream)

@@ -6,9 +6,11 @@ List[List[PIL]] (B x N_cam) for output_type="pil", ndarray (B,N,H,W,3) for "np",
 one libmdx op program per step (magicdrive_amd.denoiser.SamplerPlan), replayed as a hipGraph; everything
 timestep-independent runs once in a prologue program.
 
-Scope notes: CLIP text encoding and the VAE decode are outside the built hot path; they are
-used as ordinary torch modules when the caller supplies them (`prompt_embeds=` / `output_type="latent"`
-bypass them).  Fused schedulers: DDIM eta=0 (the north-star config) and UniPC (what tools/test.py installs); others raise.
+Scope notes: CLIP text encoding is outside the built hot path (an ordinary torch module when the caller supplies
+it; `prompt_embeds=` bypasses it).  The VAE decode runs on the HIP kernels: `from_pretrained` attaches
+`magicdrive_amd.networks.autoencoder_kl.AutoencoderKL` from `<sd15>/vae` exactly where the reference's `from_pretrained` attaches
+diffusers' (misc/test_utils.py:118-126); a caller-supplied torch VAE is still accepted.
+Fused schedulers: DDIM eta=0 (the north-star config) and UniPC (what tools/test.py installs); others raise.
 """
 from __future__ import annotations
 
@@ -21,7 +23,7 @@ from typing import Any, Callable, Dict, List, Optional, Union
 import numpy as np
 import torch
 
-from ..denoiser import SamplerPlan
+from ..denoiser import PlanCache, SamplerPlan, device_stream
 from ..schedulers import DDIMScheduler, UniPCMultistepScheduler
 
 
@@ -52,23 +54,39 @@ class StableDiffusionBEVControlNetPipeline:
         self.vae_scale_factor = 8
         self._progress_bar_config: Dict[str, Any] = {}
         self._device = torch.device("cpu")
-        self._plans: Dict[tuple, SamplerPlan] = {}
+        # Plans (op programs + activation pool + captured hipGraph) are cached per batch geometry.  The reference's eval flow pads
+        # boxes to the per-batch maximum (configs/runner/default.yaml:61 bbox_max_length null), so L_box changes from batch to batch:
+        # the cache is a small LRU and an evicted plan releases its graph and buffers.
+        self._plans = PlanCache()
         self.use_graph = True
 
     # ---- construction / housekeeping the reference's callers use (misc/test_utils.py:94-138) ----
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path: str, controlnet=None, unet=None, safety_checker=None,
                         feature_extractor=None, torch_dtype=torch.bfloat16, vae=None, text_encoder=None, tokenizer=None, **kw):
+        """`pipe_cls.from_pretrained(<sd15 dir>, controlnet=, unet=, safety_checker=None, feature_extractor=None, torch_dtype=)` —
+        the call `build_pipe` makes (magicdrive/misc/test_utils.py:118-126).  Reads the SD-1.5 directory layout: `scheduler/
+        scheduler_config.json`, `vae/` (decoded on the HIP kernels), `text_encoder/` + `tokenizer/` (transformers; optional)."""
         root = pretrained_model_name_or_path
         sch = DDIMScheduler()
         p = os.path.join(root, "scheduler", "scheduler_config.json")
         if os.path.exists(p):
             with open(p) as f:
                 sch = DDIMScheduler.from_config(json.load(f))
+        if vae is None and os.path.exists(os.path.join(root, "vae", "config.json")):
+            from ..networks.autoencoder_kl import AutoencoderKL
+            vae = AutoencoderKL.from_pretrained(os.path.join(root, "vae"), torch_dtype=torch_dtype)
         if text_encoder is None and os.path.isdir(os.path.join(root, "text_encoder")):
             import transformers
             text_encoder = transformers.CLIPTextModel.from_pretrained(os.path.join(root, "text_encoder")).eval()
+            if torch_dtype is not None:
+                text_encoder = text_encoder.to(dtype=torch_dtype)
+        if tokenizer is None and os.path.isdir(os.path.join(root, "tokenizer")):
+            import transformers
             tokenizer = transformers.CLIPTokenizer.from_pretrained(os.path.join(root, "tokenizer"))
+        for m in (unet, controlnet):
+            if m is not None and torch_dtype is not None:
+                m.to(torch_dtype)
         return cls(vae=vae, text_encoder=text_encoder, unet=unet, controlnet=controlnet, scheduler=sch, tokenizer=tokenizer)
 
     def to(self, device):
@@ -130,9 +148,16 @@ class StableDiffusionBEVControlNetPipeline:
         """pipeline_controlnet.py:665-680 + utils/torch_utils.py:36-77: drawn on the generator's device (CPU by
         default, so seeds are device independent), then moved."""
         shape = (batch_size, num_channels_latents, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if isinstance(generator, (list, tuple)) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                             f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
         if latents is None:
-            gdev = generator.device if isinstance(generator, torch.Generator) else torch.device("cpu")
-            latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype)
+            if isinstance(generator, (list, tuple)):      # one generator per scene (`fix_seed_within_batch`, misc/test_utils.py:224-237):
+                gdev = generator[0].device                 # randn_tensor draws (1, ...) from each in turn (torch_utils.py:64-71)
+                latents = torch.cat([torch.randn((1,) + shape[1:], generator=g, device=gdev, dtype=dtype) for g in generator], dim=0)
+            else:
+                gdev = generator.device if isinstance(generator, torch.Generator) else torch.device("cpu")
+                latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype)
         else:
             assert tuple(latents.shape) == shape, f"latents {tuple(latents.shape)} != {shape}"
         return latents.to(device) * self.scheduler.init_noise_sigma
@@ -192,6 +217,8 @@ class StableDiffusionBEVControlNetPipeline:
             raise NotImplementedError(f"{type(self.scheduler).__name__}: fused steps exist for magicdrive_amd.schedulers.DDIMScheduler and UniPCMultistepScheduler")
         if self._device.type != "cuda":
             raise RuntimeError("pipeline.to('cuda') first: the sampler has no CPU path")
+        if output_type != "latent" and self.vae is None:      # fail BEFORE the sampling loop, not after it
+            raise ValueError("no VAE attached: use output_type='latent', pass vae= to the pipeline, or build it with from_pretrained(<sd15 dir>)")
         device = self._device
         if prompt is not None and isinstance(prompt, str):
             batch_size = 1
@@ -250,26 +277,28 @@ class StableDiffusionBEVControlNetPipeline:
         key = (b, do_cfg, L_box, h, w, n_steps, float(guidance_scale), float(controlnet_conditioning_scale), text.shape[1], sched_kind, gv_mode)
         plan = self._plans.get(key)
         if plan is None:
-            plan = SamplerPlan(self.unet.cfg, self.unet.packed(), self.controlnet.packed(), device, b, do_cfg, L_box, (h, w),
-                               num_steps=n_steps, guidance_scale=guidance_scale,
-                               conditioning_scale=float(controlnet_conditioning_scale), n_text=text.shape[1], scheduler_kind=sched_kind,
-                               given_view_mode=gv_mode)
-            plan.compile()
-            self._plans[key] = plan
+            with torch.cuda.device(device):
+                plan = SamplerPlan(self.unet.cfg, self.unet.packed(), self.controlnet.packed(), device, b, do_cfg, L_box, (h, w),
+                                   num_steps=n_steps, guidance_scale=guidance_scale,
+                                   conditioning_scale=float(controlnet_conditioning_scale), n_text=text.shape[1], scheduler_kind=sched_kind,
+                                   given_view_mode=gv_mode)
+                plan.compile()
+            self._plans.put(key, plan)
         plan.load_inputs(latents, camera_param, text, image, boxes, timesteps, self.scheduler.coefficient_table(),
                          given_mask=gv_mask, given_latents=gv_lat)
-        st = torch.cuda.current_stream().cuda_stream
-        plan.prologue.run(st)
-        with self.progress_bar(total=num_inference_steps) as bar:
-            for i, t in enumerate(timesteps):
-                if self.use_graph:
-                    plan.step.launch(st)
-                else:
-                    plan.step.run(st)
-                bar.update()
-                if callback is not None and i % callback_steps == 0:
-                    callback(i, t, plan.latents().to(prompt_embeds.dtype))
-        latents = plan.latents().to(prompt_embeds.dtype)
+        with torch.cuda.device(device):                       # launches, graph replays and torch copies all target the pipeline's device
+            st = device_stream(device)
+            plan.prologue.run(st)
+            with self.progress_bar(total=num_inference_steps) as bar:
+                for i, t in enumerate(timesteps):
+                    if self.use_graph:
+                        plan.step.launch(st)
+                    else:
+                        plan.step.run(st)
+                    bar.update()
+                    if callback is not None and i % callback_steps == 0:
+                        callback(i, t, plan.latents().to(prompt_embeds.dtype))
+            latents = plan.latents().to(prompt_embeds.dtype)
         if output_type == "latent":
             out, nsfw = latents, None
         else:

@@ -45,16 +45,33 @@ class DDIMScheduler:
         self.num_inference_steps: Optional[int] = None
         self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
 
+    # diffusers' own defaults (scheduling_ddim.py:172-192): what a scheduler_config.json that omits a key means.  (The constructor's
+    # defaults above are SD-1.5's values, for `DDIMScheduler()` without a config.)
+    _DIFFUSERS_DEFAULTS = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", clip_sample=True,
+                               set_alpha_to_one=True, steps_offset=0, prediction_type="epsilon")
+
     @classmethod
     def from_config(cls, config):
-        keys = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "clip_sample", "set_alpha_to_one", "steps_offset", "prediction_type")
+        """From a diffusers scheduler config (dict or object).  Keys that change the sampled trajectory and are not built raise
+        instead of being dropped: timestep_spacing != 'leading', trained_betas, rescale_betas_zero_snr, thresholding,
+        clip_sample=True (also diffusers' default when the key is absent), non-epsilon prediction."""
         get = (lambda k: config[k]) if isinstance(config, dict) else (lambda k: getattr(config, k))
-        kw = {}
-        for k in keys:
+
+        def opt(k, default):
             try:
-                kw[k] = get(k)
+                v = get(k)
             except (KeyError, AttributeError):
-                pass
+                return default
+            return default if v is None else v
+        if opt("timestep_spacing", "leading") != "leading":
+            raise NotImplementedError(f"DDIM timestep_spacing={opt('timestep_spacing', None)!r}: only 'leading' (SD-1.5) is built")
+        if opt("trained_betas", None) is not None:
+            raise NotImplementedError("DDIM trained_betas is not built")
+        if opt("rescale_betas_zero_snr", False):
+            raise NotImplementedError("DDIM rescale_betas_zero_snr is not built")
+        if opt("thresholding", False):
+            raise NotImplementedError("DDIM thresholding is not built")
+        kw = {k: opt(k, d) for k, d in cls._DIFFUSERS_DEFAULTS.items()}
         return cls(**kw)
 
     def set_timesteps(self, num_inference_steps: int, device=None):
@@ -64,12 +81,16 @@ class DDIMScheduler:
         step_ratio = self.num_train_timesteps // num_inference_steps
         ts = (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.int64)
         self.timesteps = torch.from_numpy(ts) + self.steps_offset
+        self._table = None                      # per-step coefficient rows, rebuilt lazily; device copies cached per device
+        self._table_dev = {}
         return self.timesteps
 
     def scale_model_input(self, sample, timestep=None):
         return sample
 
     def alpha_pair(self, t: int):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
         prev_t = t - self.num_train_timesteps // self.num_inference_steps
         a_t = self.alphas_cumprod[t]
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
@@ -77,12 +98,15 @@ class DDIMScheduler:
 
     def coefficient_table(self) -> torch.Tensor:
         """fp32 [n_steps, 4]: sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev) per inference step."""
-        rows = []
-        for t in self.timesteps.tolist():
-            a_t, a_p = self.alpha_pair(int(t))
-            a_t, a_p = float(a_t), float(a_p)
-            rows.append([a_t ** 0.5, (1 - a_t) ** 0.5, a_p ** 0.5, (1 - a_p) ** 0.5])
-        return torch.tensor(rows, dtype=torch.float32)
+        if getattr(self, "_table", None) is None:
+            rows = []
+            for t in self.timesteps.tolist():
+                a_t, a_p = self.alpha_pair(int(t))
+                a_t, a_p = float(a_t), float(a_p)
+                rows.append([a_t ** 0.5, (1 - a_t) ** 0.5, a_p ** 0.5, (1 - a_p) ** 0.5])
+            self._table = torch.tensor(rows, dtype=torch.float32)
+            self._table_dev = {}
+        return self._table
 
     def step(self, model_output, timestep, sample, eta: float = 0.0, return_dict: bool = True):
         """Single DDIM update through the same fused HIP kernel the pipeline uses (for user code that drives
@@ -92,14 +116,28 @@ class DDIMScheduler:
         if not (model_output.is_cuda and sample.is_cuda):
             raise RuntimeError("DDIMScheduler.step runs on the GPU kernel; pass CUDA tensors")
         from . import ops as O
-        a_t, a_p = self.alpha_pair(int(timestep))
-        a_t, a_p = float(a_t), float(a_p)
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
         dev = sample.device
-        coef = torch.tensor([[a_t ** 0.5, (1 - a_t) ** 0.5, a_p ** 0.5, (1 - a_p) ** 0.5]], dtype=torch.float32, device=dev)
+        # the whole coefficient table lives on the device (one upload per set_timesteps); the kernel picks the row by index, so a
+        # host-side timestep costs no device sync and no per-call allocation of coefficients
+        tab = self.coefficient_table()
+        coef = self._table_dev.get(dev)
+        if coef is None:
+            coef = self._table_dev[dev] = tab.to(dev)
+        if isinstance(timestep, torch.Tensor) and timestep.is_cuda:
+            idx_t = (self.timesteps.to(dev) == timestep.reshape(-1)[0].to(torch.int64)).nonzero()      # stays on the device
+            if idx_t.numel() == 0:      # (forces a sync only on the error path)
+                raise ValueError(f"timestep {int(timestep)} is not in this scheduler's timestep list")
+            step = idx_t.reshape(-1)[:1].to(torch.int32)
+        else:
+            hits = (self.timesteps == int(timestep)).nonzero()
+            if hits.numel() == 0:
+                raise ValueError(f"timestep {int(timestep)} is not in this scheduler's timestep list")
+            step = torch.tensor([int(hits[0])], dtype=torch.int32, device=dev)
         x = sample.detach().to(torch.float32).contiguous().clone()
         eps = model_output.detach().to(torch.float32).contiguous()
-        step = torch.zeros(1, dtype=torch.int32, device=dev)
-        O.run_ops([O.DdimStep(x.view(-1), eps.view(-1), coef, step)])
+        O.run_ops([O.DdimStep(x.view(-1), eps.view(-1), coef, step.clone())])
         prev = x.to(sample.dtype)
         if not return_dict:
             return (prev,)

@@ -128,6 +128,13 @@ class VaeDecodePlan:
         """z (n_img, 4, h, w), already divided by the scaling factor -> images (n_img, 3, 8h, 8w) fp32, un-clamped."""
         if self.program is None:
             self.compile()
-        self.z_in.copy_(z.to(self.device, F32))
-        self.program.run(torch.cuda.current_stream().cuda_stream)
-        return self.out_nhwc.permute(0, 3, 1, 2).contiguous()
+        with torch.cuda.device(self.device):
+            self.z_in.copy_(z.to(self.device, F32))
+            self.program.run(torch.cuda.current_stream(self.device).cuda_stream)
+            return self.out_nhwc.permute(0, 3, 1, 2).contiguous()
+
+    def release(self):
+        if self.program is not None:
+            self.program.destroy()
+        self.program = None
+        self.ops, self.keep = [], []

@@ -172,3 +172,167 @@ def test_prepare_latents_is_seed_and_device_independent():
     a = pipe.prepare_latents(2, 4, 224, 400, torch.float32, "cpu", torch.Generator().manual_seed(3))
     b = torch.randn(2, 4, 28, 50, generator=torch.Generator().manual_seed(3))
     assert torch.equal(a, b)
+
+
+# ---- round 2: the reference's construction sequence, generator lists, config keys that change the samples ----------------------
+def _write_sd15_dir(root, with_vae=True):
+    """A tiny directory in the SD-1.5 layout `build_pipe` points `pretrained_model_name_or_path` at."""
+    import json
+    os.makedirs(root / "scheduler")
+    with open(root / "scheduler" / "scheduler_config.json", "w") as f:      # SD-1.5's PNDM config keys (runwayml/stable-diffusion-v1-5)
+        json.dump({"_class_name": "PNDMScheduler", "_diffusers_version": "0.6.0", "beta_end": 0.012, "beta_schedule": "scaled_linear",
+                   "beta_start": 0.00085, "num_train_timesteps": 1000, "set_alpha_to_one": False, "skip_prk_steps": True, "steps_offset": 1,
+                   "trained_betas": None, "clip_sample": False}, f)
+    if with_vae:
+        from magicdrive_amd.networks.autoencoder_kl import AutoencoderKL
+        AutoencoderKL.from_config(spec.VAE_TINY_CONFIG, 5).save_pretrained(str(root / "vae"))
+
+
+def test_build_pipe_call_sequence_replayed(tmp_path):
+    """magicdrive/misc/test_utils.py:94-138 `build_pipe`, call for call, against a tiny SD-1.5-layout directory and a tiny checkpoint:
+    the three config strings, from_pretrained(torch_dtype=fp16), eval(), pipe_cls.from_pretrained(sd15, controlnet=, unet=,
+    safety_checker=None, feature_extractor=None, torch_dtype=), the UniPC swap, enable_xformers, progress-bar config."""
+    from types import SimpleNamespace
+    from magicdrive_amd.networks.autoencoder_kl import AutoencoderKL
+    tcfg = spec.TINY_CONFIG
+    ckpt = tmp_path / "ckpt"
+    UNet2DConditionModelMultiview.from_config(tcfg, seed=0).save_pretrained(str(ckpt / "unet"))
+    BEVControlNetModel.from_config(tcfg, seed=1).save_pretrained(str(ckpt / "controlnet"))
+    _write_sd15_dir(tmp_path / "sd15")
+    cfg = SimpleNamespace(resume_from_checkpoint=str(ckpt) + "/",
+                          model=SimpleNamespace(model_module="magicdrive_amd.networks.unet_addon_rawbox.BEVControlNetModel",
+                                                unet_module="magicdrive_amd.networks.unet_2d_condition_multiview.UNet2DConditionModelMultiview",
+                                                pipe_module="magicdrive_amd.pipeline.pipeline_bev_controlnet.StableDiffusionBEVControlNetPipeline",
+                                                controlnet_dir="controlnet", unet_dir="unet", pretrained_model_name_or_path=str(tmp_path / "sd15")),
+                          runner=SimpleNamespace(enable_xformers_memory_efficient_attention=True))
+    # ---- build_pipe body (:94-138) ----
+    weight_dtype = torch.float16
+    if cfg.resume_from_checkpoint.endswith("/"):
+        cfg.resume_from_checkpoint = cfg.resume_from_checkpoint[:-1]
+    pipe_param = {}
+    model_cls = load_module(cfg.model.model_module)
+    controlnet = model_cls.from_pretrained(os.path.join(cfg.resume_from_checkpoint, cfg.model.controlnet_dir), torch_dtype=weight_dtype)
+    controlnet.eval()
+    pipe_param["controlnet"] = controlnet
+    unet_cls = load_module(cfg.model.unet_module)
+    unet = unet_cls.from_pretrained(os.path.join(cfg.resume_from_checkpoint, cfg.model.unet_dir), torch_dtype=weight_dtype)
+    unet.eval()
+    pipe_param["unet"] = unet
+    pipe_cls = load_module(cfg.model.pipe_module)
+    pipe = pipe_cls.from_pretrained(cfg.model.pretrained_model_name_or_path, **pipe_param, safety_checker=None, feature_extractor=None,
+                                    torch_dtype=weight_dtype)
+    pipe.scheduler = schedulers.UniPCMultistepScheduler.from_config(pipe.scheduler.config)      # (:129, with the magicdrive_amd import)
+    if cfg.runner.enable_xformers_memory_efficient_attention:
+        pipe.enable_xformers_memory_efficient_attention()
+    pipe = pipe.to("cpu")                                                                        # `.to(device)`; no GPU in this test
+    # ---- what run_one_batch_pipe / the validators then rely on ----
+    assert isinstance(pipe.vae, AutoencoderKL), "from_pretrained must attach <sd15>/vae (default output_type='pil' decodes with it)"
+    ref_vae = AutoencoderKL.from_pretrained(str(tmp_path / "sd15" / "vae"))
+    assert all(torch.equal(pipe.vae.state_dict()[k], ref_vae.state_dict()[k]) for k in ref_vae.state_dict())
+    assert pipe.vae.dtype == weight_dtype and pipe.unet.dtype == weight_dtype and pipe.controlnet.dtype == weight_dtype
+    assert isinstance(pipe.scheduler, schedulers.UniPCMultistepScheduler) and pipe.scheduler.config["beta_schedule"] == "scaled_linear"
+    assert pipe.tokenizer is None and pipe.unet is unet and pipe.controlnet is controlnet and pipe.unet.config.in_channels == 4
+    from_utils_cfg = pipe._progress_bar_config if hasattr(pipe, "_progress_bar_config") else {}     # update_progress_bar_config (:65-71)
+    from_utils_cfg.update(dict(leave=False)); pipe.set_progress_bar_config(**from_utils_cfg)
+    pipe.enable_vae_slicing()                                                                        # val_set_gen.py:78
+    # no VAE in the directory and none passed: the failure must come BEFORE sampling (needs a device, so only the check order is visible here)
+    _write_sd15_dir(tmp_path / "sd15_novae", with_vae=False)
+    p2 = pipe_cls.from_pretrained(str(tmp_path / "sd15_novae"), **pipe_param, safety_checker=None, feature_extractor=None, torch_dtype=weight_dtype)
+    assert p2.vae is None and isinstance(p2.scheduler, schedulers.DDIMScheduler)
+    assert torch.allclose(p2.scheduler.alphas_cumprod, schedulers.DDIMScheduler().alphas_cumprod)
+
+
+def test_prepare_latents_list_of_generators():
+    """`fix_seed_within_batch` (misc/test_utils.py:224-237) passes one generator per scene; randn_tensor draws (1, ...) from each
+    (third_party/diffusers/src/diffusers/utils/torch_utils.py:64-71)."""
+    cfg = spec.TINY_CONFIG
+    pipe = StableDiffusionBEVControlNetPipeline(unet=UNet2DConditionModelMultiview.from_config(cfg), controlnet=BEVControlNetModel.from_config(cfg, 1))
+    gens = [torch.Generator().manual_seed(s) for s in (11, 12, 13)]
+    a = pipe.prepare_latents(3, 4, 224, 400, torch.float32, "cpu", gens)
+    exp = torch.cat([torch.randn(1, 4, 28, 50, generator=torch.Generator().manual_seed(s)) for s in (11, 12, 13)])
+    assert torch.equal(a, exp)
+    # the reference's other branch builds the list from torch.manual_seed(seed): the SAME global generator three times
+    b = pipe.prepare_latents(3, 4, 224, 400, torch.float32, "cpu", [torch.manual_seed(7) for _ in range(3)])
+    torch.manual_seed(7)
+    assert torch.equal(b, torch.cat([torch.randn(1, 4, 28, 50) for _ in range(3)]))
+    with pytest.raises(ValueError):
+        pipe.prepare_latents(2, 4, 224, 400, torch.float32, "cpu", gens)
+
+
+def test_config_keys_that_change_samples_are_honoured_or_refused(tmp_path):
+    import json
+    cfg = spec.TINY_CONFIG
+    c = BEVControlNetModel.from_config(cfg, seed=1)
+    c.save_pretrained(str(tmp_path / "cn"))
+    p = tmp_path / "cn" / "config.json"
+    js = json.load(open(p))
+    assert js["bbox_embedder_param"]["minmax_normalize"] is False
+    # minmax_normalize: class default True when the key is absent (bbox_embedder.py:42)
+    js2 = json.loads(json.dumps(js)); del js2["bbox_embedder_param"]["minmax_normalize"]
+    json.dump(js2, open(p, "w"))
+    assert BEVControlNetModel.from_pretrained(str(tmp_path / "cn")).cfg["controlnet"]["bbox"]["minmax_normalize"] is True
+    # use_uncond_map + drop_cond_ratio > 0: the checkpoint must carry uncond_map, and CFG substitutes it for the uncond half's map
+    js3 = json.loads(json.dumps(js)); js3.update(use_uncond_map="negative1", drop_cond_ratio=0.25)
+    json.dump(js3, open(p, "w"))
+    with pytest.raises(KeyError):
+        BEVControlNetModel.from_pretrained(str(tmp_path / "cn"))
+    sd = dict(c.state_dict()); sd["uncond_map"] = -torch.ones(*cfg["controlnet"]["map_size"])
+    cfg_um = {**cfg, "controlnet": {**cfg["controlnet"], "use_uncond_map": "negative1"}}
+    cu = BEVControlNetModel(cfg_um, sd)
+    sc = synthetic.make_scene_batch(2, ctx_dim=64, max_len=3)
+    kw = cu.add_uncond_to_kwargs(camera_param=sc["camera_param"], bboxes_3d_data=sc["bboxes_3d_data"], image=sc["bev_map"])
+    assert kw["image"].shape == sc["bev_map"].shape and (kw["image"] == -1).all()
+    cu.save_pretrained(str(tmp_path / "cn_um"))
+    cu2 = BEVControlNetModel.from_pretrained(str(tmp_path / "cn_um"))
+    assert torch.equal(cu2._uncond_map, cu._uncond_map)
+    js4 = json.loads(json.dumps(js)); js4.update(use_uncond_map="bogus", drop_cond_ratio=0.25)
+    json.dump(js4, open(p, "w"))
+    with pytest.raises(TypeError):
+        BEVControlNetModel.from_pretrained(str(tmp_path / "cn"))
+    # scheduler keys
+    sd15 = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    for bad in (dict(timestep_spacing="trailing"), dict(trained_betas=[0.1, 0.2]), dict(rescale_betas_zero_snr=True), dict(clip_sample=True)):
+        with pytest.raises(NotImplementedError):
+            schedulers.DDIMScheduler.from_config({**sd15, **bad})
+    with pytest.raises(NotImplementedError):          # diffusers' default for an absent clip_sample is True
+        schedulers.DDIMScheduler.from_config({k: v for k, v in sd15.items() if k != "clip_sample"})
+    s = schedulers.DDIMScheduler()
+    with pytest.raises(ValueError):
+        s.alpha_pair(981)
+    with pytest.raises(ValueError):
+        s.coefficient_table()
+
+
+def test_minmax_normalize_is_applied_to_box_inputs():
+    """ConditioningBuffers.load: normalizer('all-xyz') on the raw corners (bbox_embedder.py:10-25), before the Fourier kernel."""
+    from magicdrive_amd.denoiser import ConditioningBuffers
+
+    class Stub:
+        pass
+    st = Stub(); st.minmax_normalize = True; st.n_scene, st.n_cam, st.L, st.S, st.n_text = 1, 2, 3, 1 + 4 + 3, 4
+    st.cam_in = torch.zeros(2, 7, 3); st.ctx = torch.zeros(2, st.S, 8, dtype=torch.bfloat16); st.map_in = torch.zeros(1, 2, 4, 4)
+    st.box_in = torch.zeros(6, 8, 3); st.box_cls = torch.zeros(6, dtype=torch.int64); st.box_mask = torch.zeros(6, dtype=torch.uint8)
+    bb = torch.randn(1, 2, 3, 8, 3) * 30
+    boxes = dict(bboxes=bb, classes=torch.ones(1, 2, 3, dtype=torch.long), masks=torch.ones(1, 2, 3, dtype=torch.bool))
+    ConditioningBuffers.load(st, torch.zeros(1, 2, 3, 7), torch.zeros(1, 4, 8), torch.zeros(1, 2, 4, 4), boxes)
+    exp = (bb - torch.tensor([-200.0, -300.0, -20.0])) / torch.tensor([350.0, 650.0, 80.0])
+    assert torch.allclose(st.box_in, exp.reshape(6, 8, 3))
+    st.minmax_normalize = False
+    ConditioningBuffers.load(st, torch.zeros(1, 2, 3, 7), torch.zeros(1, 4, 8), torch.zeros(1, 2, 4, 4), boxes)
+    assert torch.equal(st.box_in, bb.reshape(6, 8, 3))
+
+
+def test_plan_cache_is_a_small_lru_that_releases_evicted_plans():
+    from magicdrive_amd.denoiser import PlanCache
+    released = []
+
+    class P:
+        def __init__(self, n): self.n = n
+        def release(self): released.append(self.n)
+    c = PlanCache(maxsize=2)
+    c.put("a", P(1)); c.put("b", P(2))
+    assert c.get("a").n == 1            # touch a: b is now the oldest
+    c.put("c", P(3))
+    assert released == [2] and "a" in c and "c" in c and "b" not in c and len(c) == 2
+    c.clear()
+    assert sorted(released) == [1, 2, 3] and len(c) == 0
