@@ -40,6 +40,24 @@ def build_pipeline(cfg, device, scheduler="ddim"):
     return pipe.to(device), unet, cn
 
 
+def pmc_traffic(kernel_name):
+    """HBM-side bytes of ONE launch of `kernel_name` from the committed rocprofv3 --pmc passes (profiles/r02_pmc_summary.json:
+    FETCH_SIZE x 2 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, separate passes).  Counters cannot be collected
+    inside a timed run; the summary records the shape it was measured on next to the algorithmic bytes of that launch."""
+    p = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+    if not os.path.exists(p):
+        return None
+    try:
+        with open(p) as f:
+            rows = json.load(f).get("kernels", {})
+    except Exception:
+        return None
+    for k, v in rows.items():
+        if kernel_name.startswith(k):
+            return v
+    return None
+
+
 def per_op_profile(plan, reps=3):
     """HIP-event timing of every launch of the step program on the stream it is launched on."""
     from magicdrive_amd import _lib as L, flops as FL
@@ -71,7 +89,28 @@ def per_op_profile(plan, reps=3):
     return fam, kern, rows
 
 
-def cpu_baseline(cfg, n_steps_timed=2):
+def cpu_cfg1(cfg, cores, steps=20):
+    """BASELINE.json configs[0] in full: ONE 224x400 view through the vanilla SD-1.5 UNet (no ControlNet, no cross-view attention:
+    the multi-view state dict minus its attn4 / norm4 / connector tensors), 20-step DDIM, on the CPU oracle."""
+    from magicdrive_amd.networks import spec
+    from oracle import denoiser as D
+    usd = {k: v for k, v in spec.random_state_dict(spec.unet_param_shapes(cfg), 0).items()
+           if ".attn4." not in k and ".norm4." not in k and ".connector." not in k}
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(1, 4, 28, 50, generator=g)
+    ehs = torch.randn(1, 77, cfg["cross_attention_dim"], generator=g)
+    sch = D.DDIM()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for t in sch.set_timesteps(steps).tolist():
+            x = sch.step(D.unet_forward(usd, cfg, x, t, ehs), t, x)
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(x).all()
+    return {"seconds": round(dt, 2), "views_per_s": round(1.0 / dt, 4), "steps": steps, "cores": cores,
+            "what": "configs[0]: single 224x400 view, vanilla SD-1.5 UNet, 20-step DDIM, CPU oracle fp32, run in full"}
+
+
+def cpu_baseline(cfg, n_steps_timed=3):
     """The CPU oracle (restatement of the reference's diffusers path, fp32) on this host's cores: one warm-up
     denoise step + `n_steps_timed` timed steps of ONE scene of the same workload, extrapolated to 50 steps."""
     from magicdrive_amd import synthetic
@@ -98,9 +137,11 @@ def cpu_baseline(cfg, n_steps_timed=2):
     for i in range(n_steps_timed):
         one_step(961 - 20 * i)
     dt = (time.perf_counter() - t0) / n_steps_timed
+    cfg1 = cpu_cfg1(cfg, cores)
     torch.set_num_threads(prev_threads)
     return {"value": 1.0 / (50 * dt), "unit": "scenes/s", "cores": cores, "kind": "port",
-            "sample": f"1 scene, text-only config, {n_steps_timed} timed denoise steps after 1 warm-up ({dt:.2f} s/step, torch {torch.__version__} fp32), extrapolated x50"}
+            "sample": f"1 scene, text-only config, {n_steps_timed} timed denoise steps after 1 warm-up ({dt:.2f} s/step, torch {torch.__version__} fp32), extrapolated x50",
+            "cfg1_single_view_20step": cfg1}
 
 
 def main():
@@ -117,7 +158,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-profile", action="store_true")
     ap.add_argument("--ops-json", type=str, default="")
-    ap.add_argument("--full-cond", action="store_true", help="configs[2] shape: camera + 32 boxes + map + CFG 2.0 (parity-test config, not the headline)")
+    ap.add_argument("--full-cond", action="store_true", help="run configs[2] (camera + 32 boxes + map + CFG 2.0) AS the timed workload instead of configs[1]")
+    ap.add_argument("--full-cond-scenes", type=int, default=32,
+                    help="after the headline measurement also time ONE configs[2] call of this many scenes per GPU (CFG doubles the views: 32 scenes = "
+                         "the headline's 384 views) and report it as config.full_cond_scenes_per_s; 0 skips it")
+    ap.add_argument("--no-consistency-check", action="store_true")
     args = ap.parse_args()
 
     from magicdrive_amd import distributed as DD
@@ -157,9 +202,39 @@ def main():
     assert torch.isfinite(res).all(), "non-finite latents"
     scenes_per_s = n_total * args.steps / dt
 
+    # ---- outside the timed region: is the measured configuration computing the same thing as the oracle-verified one? --------------
+    # Scenes are independent, so scene 0 of this rank's batch must reproduce a ONE-scene call on the same inputs (the configuration
+    # tests/test_e2e_gpu.py::test_real_size_ddim_loop_sd15 checks against the CPU oracle) — whatever main loops the big batch routes to.
+    consistency = None
+    if not args.no_consistency_check and b > 1:
+        sl = slice(0, 1)
+        one = pipe(prompt=None, image=bev[sl], camera_param=None if cam is None else cam[sl], height=224, width=400, num_inference_steps=args.ddim_steps,
+                   guidance_scale=gs, latents=lat[sl], prompt_embeds=prompt[sl], negative_prompt_embeds=neg[sl], output_type="latent",
+                   bev_controlnet_kwargs={"bboxes_3d_data": {k: v[sl] for k, v in boxes.items()}} if boxes is not None else {}).images.float()
+        mine0 = res[mine[0]:mine[0] + 1].float().to(one.device) if res.shape[0] == n_total else res[:1].float().to(one.device)
+        consistency = max(((mine0[:, v] - one[:, v]).norm() / (one[:, v].norm() + 1e-20)).item() for v in range(one.shape[1]))
+        assert consistency < 5e-2, f"scene 0 of the {b}-scene batch differs from the 1-scene call by {consistency:.3e} (per-view rel L2)"
+    full_cond = None
+    if args.full_cond_scenes > 0 and not args.full_cond:
+        nb = args.full_cond_scenes
+        fsc = [synthetic.make_scene_batch(1, seed=1234 + i, max_len=32) for i in DD.shard_scenes(nb * world, rank, world)]
+        fcat = lambda k: torch.cat([s_[k] for s_ in fsc]).to(dev)
+        fbox = {k: torch.cat([s_["bboxes_3d_data"][k] for s_ in fsc]).to(dev) for k in ("bboxes", "classes", "masks")}
+        fkw = dict(prompt=None, image=fcat("bev_map"), camera_param=fcat("camera_param"), height=224, width=400, num_inference_steps=args.ddim_steps,
+                   guidance_scale=2.0, latents=fcat("latents"), prompt_embeds=fcat("prompt_embeds"), negative_prompt_embeds=fcat("negative_prompt_embeds"),
+                   output_type="latent", bev_controlnet_kwargs={"bboxes_3d_data": fbox})
+        pipe(**fkw)                                              # builds + captures the plan, warms up
+        DD.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fout = pipe(**fkw).images
+        torch.cuda.synchronize(); DD.barrier()
+        fdt = DD.max_over_ranks(time.perf_counter() - t1, dev)
+        assert torch.isfinite(fout).all()
+        full_cond = {"scenes_per_s": nb * world / fdt, "scenes_per_gpu": nb, "seconds_per_call": fdt}
+
     if rank != 0:
         return
-    plan = next(iter(pipe._plans.values()))
+    plan = next(pl for pl in pipe._plans.values() if pl.b == b and pl.do_cfg == (gs > 1.0 and cam is not None))
     f_step = FL.program_flops(plan.step_ops)
     f_pro = FL.program_flops(plan.prologue_ops)
     f_scene = (args.ddim_steps * f_step["total"] + f_pro["total"]) / b          # per scene, incl. CFG duplication if any
@@ -173,7 +248,12 @@ def main():
                    "controlnet_params_M": round(cn.num_parameters() / 1e6, 1), "parallelism": f"scene-sharded x{world}",
                    "hipgraph": pipe.use_graph, "output_type": "latent",
                    "tflop_per_scene": round(f_scene / 1e12, 3),
-                   "mfma_frac_end_to_end": round(f_scene * scenes_per_s / world / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
+                   "mfma_frac_end_to_end": round(f_scene * scenes_per_s / world / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                   "batch_consistency_rel": None if consistency is None else round(consistency, 5),
+                   "full_cond_scenes_per_s": None if full_cond is None else round(full_cond["scenes_per_s"], 4),
+                   "full_cond": None if full_cond is None else
+                   {"workload": "configs[2]: 6-view 224x400, camera + 32 boxes + BEV map, CFG 2.0, same sampler", "scenes_per_gpu": full_cond["scenes_per_gpu"],
+                    "seconds_per_call": round(full_cond["seconds_per_call"], 3)}},
     }
     if not args.no_op_profile:
         fam, kern, rows = per_op_profile(plan)
@@ -183,7 +263,7 @@ def main():
         if d["mfma"] and d["flops"] > 0:
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                               "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(name),
                                "launches_per_step": d["launches"], "avg_launch_us": 1e3 * d["ms"] / d["launches"]}
         else:
             ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9

@@ -382,6 +382,17 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
         }
         return bn_out != 0;
     };
+    if (xl_mode >= 2 && p.splitk <= 1 && p.batch <= 1 && !(p.K == 320 && !conv && !xl_k320)) {
+        // "whenever supported" (tests / benchmarking): ahead of the automatic split-K below, which would otherwise claim small grids
+        GCParams q = p;
+        q.splitk = 1;
+        int bn_f;
+        const int keep = p.splitk;
+        p.splitk = 1;
+        const bool ok = try_xl(bn_f);
+        p.splitk = keep;
+        if (ok) return launch_gemm_xl(q, conv, bn_f, st);
+    }
     const bool ws_first = !conv && ws_mode > 0 && p.splitk <= 1 && ws_supported(p) && (ws_mode >= 2 || p.M >= 8192);
     if (impl == 0 && ws_first && !(xl_k320 && xl_mode > 0))
         return launch_gemm_ws(p, st);

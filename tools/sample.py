@@ -1,0 +1,144 @@
+#!/usr/bin/env python
+"""tools/sample.py — the mm-free equivalent of the reference's sampling entry points (tools/test.py:38-72, demo/run.py:33-90):
+load a checkpoint in the reference layout, read the training run's hydra overrides, feed preprocessed `.pth` samples
+(demo/readme.md:3-22) through StableDiffusionBEVControlNetPipeline on the MI355X path and save the six views per scene.
+
+  python tools/sample.py --ckpt <ckpt dir with unet/ controlnet/ hydra/overrides.yaml> --sd15 <stable-diffusion-v1-5 dir> \
+         --data <folder of *.pth> --out <dir> [key=value overrides as for tools/test.py] [--scheduler unipc|ddim] [--prompt-embeds]
+
+No hydra / omegaconf / mmdet3d: the config tree of the reference is not rebuilt (SURVEY.md §8 out of scope) — only the handful of
+keys the sampling loop reads are resolved, in the reference's order (checkpoint overrides first, command line last, tools/test.py:46-54):
+  seed, runner.validation_times, runner.pipeline_param.{guidance_scale,num_inference_steps,...}, dataset.image_size / +exp=HxW,
+  fix_seed_within_batch, runner.bbox_max_length.
+Without a text encoder in --sd15 the prompts cannot be embedded; pass --prompt-embeds to sample with zero embeddings (plumbing /
+throughput runs) instead of failing.
+"""
+import argparse
+import os
+import sys
+from typing import Dict, Iterator, List, Sequence
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+DEFAULTS = dict(seed=42, validation_times=4, guidance_scale=2.0, num_inference_steps=20, image_size=(224, 400), fix_seed_within_batch=False,
+                bbox_max_length=None)          # configs/test_config.yaml + configs/runner/default.yaml:54-61
+
+
+def _parse(v: str):
+    lo = v.strip().lower()
+    if lo in ("null", "none", "~"):
+        return None
+    if lo in ("true", "false"):
+        return lo == "true"
+    try:
+        return int(v)
+    except ValueError:
+        try:
+            return float(v)
+        except ValueError:
+            return v
+
+
+def resolve_run_config(ckpt_dir: str, cli_overrides: Sequence[str]) -> Dict:
+    """Checkpoint overrides, then the command line's (tools/test.py:46-54), reduced to the keys the sampling loop reads."""
+    from magicdrive_amd.dataset import load_overrides
+    ov = load_overrides(ckpt_dir)
+    for it in cli_overrides:
+        k, _, v = it.partition("=")
+        ov[k.lstrip("+")] = v
+    run = dict(DEFAULTS)
+    for k, v in ov.items():
+        if k == "exp" and "x" in v:                                  # +exp=224x400 / 272x736 / 424x800abox0.1_nockpt (configs/exp/*.yaml)
+            h, w = v.split("x")[:2]
+            w = "".join(ch for ch in w if ch.isdigit() or ch == "_").split("_")[0]
+            digits = "".join(c for c in w if c.isdigit())
+            run["image_size"] = (int(h), int(digits))
+        elif k == "dataset.image_size":
+            run["image_size"] = tuple(int(x) for x in v.strip("[]() ").split(","))
+        elif k == "seed":
+            run["seed"] = _parse(v)
+        elif k == "fix_seed_within_batch":
+            run["fix_seed_within_batch"] = bool(_parse(v))
+        elif k == "runner.validation_times":
+            run["validation_times"] = int(v)
+        elif k == "runner.bbox_max_length":
+            run["bbox_max_length"] = _parse(v)
+        elif k.startswith("runner.pipeline_param."):
+            run[k[len("runner.pipeline_param."):]] = _parse(v)
+    return run
+
+
+def iter_pipe_kwargs(dataset, run: Dict, batch_size: int = 1) -> Iterator[Dict]:
+    """Batches of samples -> keyword arguments of StableDiffusionBEVControlNetPipeline.__call__, as run_one_batch /
+    run_one_batch_pipe assemble them (magicdrive/misc/test_utils.py:191-255, :258-330)."""
+    from magicdrive_amd.dataset import collate_samples, preprocess_fn
+    extra = {k: v for k, v in run.items() if k not in DEFAULTS or k in ("guidance_scale", "num_inference_steps")}
+    for i0 in range(0, len(dataset), batch_size):
+        batch = collate_samples([preprocess_fn(dataset[i]) for i in range(i0, min(i0 + batch_size, len(dataset)))])
+        yield dict(prompt=batch["captions"], image=batch["bev_map_with_aux"], camera_param=batch["camera_param"],
+                   height=run["image_size"][0], width=run["image_size"][1], bev_controlnet_kwargs=batch["kwargs"],
+                   bbox_max_length=run["bbox_max_length"], **extra)
+
+
+def build_pipe(ckpt: str, sd15: str, scheduler: str, device):
+    """The reference's build_pipe sequence (magicdrive/misc/test_utils.py:94-138) with the magicdrive_amd config strings."""
+    from magicdrive_amd import schedulers
+    from magicdrive_amd.misc.common import load_module
+    model_cls = load_module("magicdrive_amd.networks.unet_addon_rawbox.BEVControlNetModel")
+    unet_cls = load_module("magicdrive_amd.networks.unet_2d_condition_multiview.UNet2DConditionModelMultiview")
+    pipe_cls = load_module("magicdrive_amd.pipeline.pipeline_bev_controlnet.StableDiffusionBEVControlNetPipeline")
+    ckpt = ckpt[:-1] if ckpt.endswith("/") else ckpt
+    controlnet = model_cls.from_pretrained(os.path.join(ckpt, "controlnet"), torch_dtype=torch.float16).eval()
+    unet = unet_cls.from_pretrained(os.path.join(ckpt, "unet"), torch_dtype=torch.float16).eval()
+    pipe = pipe_cls.from_pretrained(sd15, controlnet=controlnet, unet=unet, safety_checker=None, feature_extractor=None, torch_dtype=torch.float16)
+    if scheduler == "unipc":
+        pipe.scheduler = schedulers.UniPCMultistepScheduler.from_config(pipe.scheduler.config)
+    pipe.enable_xformers_memory_efficient_attention()
+    return pipe.to(device)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--ckpt", required=True); ap.add_argument("--sd15", required=True)
+    ap.add_argument("--data", required=True); ap.add_argument("--out", required=True)
+    ap.add_argument("--scheduler", choices=["unipc", "ddim"], default="unipc")
+    ap.add_argument("--batch-size", type=int, default=1)
+    ap.add_argument("--prompt-embeds", action="store_true", help="no text encoder available: sample with zero prompt embeddings")
+    ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("overrides", nargs="*")
+    a = ap.parse_args(argv)
+    from magicdrive_amd.dataset import FolderSet
+    run = resolve_run_config(a.ckpt, a.overrides)
+    pipe = build_pipe(a.ckpt, a.sd15, a.scheduler, a.device)
+    data = FolderSet(a.data)
+    os.makedirs(a.out, exist_ok=True)
+    total = 0
+    glob_gen = torch.Generator().manual_seed(run["seed"]) if run["seed"] is not None else None
+    for kw in iter_pipe_kwargs(data, run, a.batch_size):
+        bs = kw["image"].shape[0]
+        if pipe.text_encoder is None:
+            if not a.prompt_embeds:
+                raise SystemExit(f"{a.sd15} has no text_encoder/: pass --prompt-embeds to sample with zero embeddings")
+            D = pipe.unet.cfg["cross_attention_dim"]
+            kw.update(prompt=None, prompt_embeds=torch.zeros(bs, 77, D), negative_prompt_embeds=torch.zeros(bs, 77, D))
+        for ti in range(run["validation_times"]):
+            if glob_gen is None:
+                gen = None
+            elif run["fix_seed_within_batch"]:               # one generator per scene (misc/test_utils.py:224-237)
+                gen = [torch.Generator().manual_seed(int(torch.randint(0x7ffffffffffffff0, [1], generator=glob_gen))) for _ in range(bs)]
+            else:
+                gen = torch.Generator().manual_seed(int(torch.randint(0x7ffffffffffffff0, [1], generator=glob_gen)))
+            images = pipe(generator=gen, **kw).images                      # List[List[PIL]]: scene x view
+            for bi, views in enumerate(images):
+                for vi, im in enumerate(views):
+                    im.save(os.path.join(a.out, f"{total + bi}_gen{ti}_view{vi}.png"))
+        total += bs
+    print(f"sampled {total} scenes x {run['validation_times']} -> {a.out}")
+
+
+if __name__ == "__main__":
+    main()
