@@ -11,7 +11,7 @@ import os
 from typing import Dict, List, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmdx.so")
+LIB_PATH = os.environ.get("MDX_LIB_PATH") or os.path.join(_HERE, "libmdx.so")      # MDX_LIB_PATH: A/B a second build (tools only)
 
 ABI_VERSION = 4
 
