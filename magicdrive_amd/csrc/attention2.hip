@@ -1,0 +1,467 @@
+// attention2.hip — the lean fused attention forward for the UNet's big token counts (head dim 40 / 80, Tq >= 256) on gfx950.
+//
+// Why a second kernel: the round-2 counters of attention.hip (profiles/README.md) show it issue-bound, not matrix- or memory-bound:
+// ~500 instructions per (wave, 64-kv tile) of which ~140 are the algorithm (14 MFMAs, 33 exp, 32 fma, 16 max, 16 cvt, 14 LDS
+// reads); the rest is staging predication, per-tile address arithmetic, kv masks and register glue around the 8-byte V^T reads —
+// and with all of its MFMAs / exps removed the kernel runs at the same speed.  This kernel keeps the algorithm (S^T = K Q^T on
+// 32x32x16 MFMAs so a lane owns one query: lane-local online softmax, fp32 statistics, exp2 with folded scale; two-source
+// "cross-view" mode with separate softmax per neighbour, summed) and removes the overhead:
+//   * K and V^T tiles go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, inline asm as in gemm_xl.hip): no staging registers,
+//     no ds_write pass, no per-chunk predicates — rows / kv chunks past the end are lanes whose voffset is out of range (zero fill);
+//     three LDS buffers, tiles issued two ahead, ONE counted vmcnt and ONE barrier per tile;
+//   * every per-lane address (DMA source offsets, fragment read offsets) is computed once per kernel;
+//   * O^T += V^T P^T runs on 16x16x32 MFMAs: the head dim pads to a multiple of 16 instead of 32 (d = 40: 48 rows instead of 64,
+//     -25 % PV work) and V^T fragments are single conflict-free ds_read_b128 (XOR-swizzled 128-byte rows, as in xl_layout.h);
+//     P^T moves from the 32x32 accumulator layout to the 16x16 B-operand layout with 4 v_permlane32_swap + 4 v_permlane16_swap
+//     per 32 kv (see p_to_b_operand);
+//   * the row sums l = sum_kv p come out of the PV MFMAs through a row of ones in the padded V^T tile (d % 16 != 0);
+//   * the kv mask (-inf for kv >= Tk) and the V^T pad-column scrub exist only in a peeled copy of the loop body for the last tile.
+// Numerics: identical to attention.hip except that l is accumulated from the bf16-rounded probabilities (the same values the
+// numerator uses) instead of the fp32 ones.
+//
+// Replaces xformers' CUTLASS fMHA as called by XFormersAttnProcessor (diffusers/models/attention_processor.py:1165-1171), incl.
+// MagicDrive's cross-view attention (magicdrive/networks/blocks.py:106-222); same C entry point (mdx_attention_bf16, include/mdx.h).
+#include "common.h"
+#include "launch.h"
+#include "xl_layout.h"
+#include "attn2.h"
+#include <cstdlib>
+
+namespace mdx {
+
+
+typedef __attribute__((ext_vector_type(4))) unsigned a2_rsrc_t;
+typedef __attribute__((address_space(3))) void a2_lds_t;
+constexpr unsigned A2_OOB = 0x80000000u, A2_RECORDS = 0x80000000u;
+constexpr int A2_KV = 64, A2_NW = 4, A2_NT = 256, A2_NBUF = 3;
+
+__device__ __forceinline__ a2_rsrc_t a2_make_rsrc(const void* base) {
+    const unsigned long long a = (unsigned long long)base;
+    a2_rsrc_t r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    r.z = A2_RECORDS;
+    r.w = 0x00020000u;
+    return r;
+}
+// one 1-KiB LDS-DMA piece (see xl_glds in gemm_xl.hip for why this is inline asm and how completion is counted)
+__device__ __forceinline__ void a2_glds(const a2_rsrc_t rs, unsigned lds_addr, unsigned voff, int soff) {
+    unsigned keep;
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
+        : "memory");
+}
+template <int N>
+__device__ __forceinline__ void a2_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// P^T from the 32x32x16 accumulator layout to two 16x16x32 B operands, in place.
+// In: the lane's 16 probabilities of one 32-kv sub-tile packed in pairs pk[u], u = 0..7: lane (q = l & 31, h = l >> 5) holds
+//     kv 8 (u >> 1) + 2 (u & 1) + {0, 1} + 4 h of the sub-tile, i.e. {0-3, 8-11, 16-19, 24-27} + 4 h — stored as
+//     x = (pk0, pk1, pk4, pk5), y = (pk2, pk3, pk6, pk7), so that every swap below exchanges like components of x and y (or two
+//     components of the same vector) and the results ARE the operands: no register moves.
+// Out: x / y = B operands (k = kv 32, n = q 16) of query tiles q = 0..15 / 16..31: lane (n = l & 15, c = l >> 4) holds the 8
+//     consecutive kv 8c .. 8c+7 of query 16 t + n.
+// Step 1 (v_permlane32_swap, lanes l <-> l + 32: the two halves of one query): pk[u].upper <-> pk[u + 4].lower, u = 0..3: the lower
+//     lane collects kv 0..15, the upper 16..31.  Now chunk A = (pk0, pk1, pk4, pk5) = kv 0..7 (lower lanes) / 16..23 (upper),
+//     chunk B = (pk2, pk3, pk6, pk7) = kv 8..15 / 24..31.
+// Step 2 (v_permlane16_swap, lanes l <-> l ^ 16): a lane keeps the chunk of its own 16-lane row for one query tile and trades the
+//     other chunk for the one its row needs of the other query tile.
+__device__ __forceinline__ void p_to_b_operand(Frag8& x, Frag8& y) {
+    { auto r = __builtin_amdgcn_permlane32_swap(x.u.x, x.u.z, false, false); x.u.x = r[0]; x.u.z = r[1]; }   // pk0 <-> pk4
+    { auto r = __builtin_amdgcn_permlane32_swap(x.u.y, x.u.w, false, false); x.u.y = r[0]; x.u.w = r[1]; }   // pk1 <-> pk5
+    { auto r = __builtin_amdgcn_permlane32_swap(y.u.x, y.u.z, false, false); y.u.x = r[0]; y.u.z = r[1]; }   // pk2 <-> pk6
+    { auto r = __builtin_amdgcn_permlane32_swap(y.u.y, y.u.w, false, false); y.u.y = r[0]; y.u.w = r[1]; }   // pk3 <-> pk7
+    { auto r = __builtin_amdgcn_permlane16_swap(x.u.x, y.u.x, false, false); x.u.x = r[0]; y.u.x = r[1]; }   // pk0 <-> pk2
+    { auto r = __builtin_amdgcn_permlane16_swap(x.u.y, y.u.y, false, false); x.u.y = r[0]; y.u.y = r[1]; }   // pk1 <-> pk3
+    { auto r = __builtin_amdgcn_permlane16_swap(x.u.z, y.u.z, false, false); x.u.z = r[0]; y.u.z = r[1]; }   // pk4 <-> pk6
+    { auto r = __builtin_amdgcn_permlane16_swap(x.u.w, y.u.w, false, false); x.u.w = r[0]; y.u.w = r[1]; }   // pk5 <-> pk7
+}
+
+// A2_ABL: compile-time ablation bits for timing experiments only (tools/attn_ablate.sh builds side libraries with -DA2_ABL=..;
+// results are WRONG with any bit set): 1 no exp, 2 no operand permute, 4 no rescale, 8 no QK MFMA, 16 no PV MFMA, 64 no steady-state DMA
+#ifndef A2_ABL
+#define A2_ABL 0
+#endif
+constexpr float A2_DEFER = 4.0f;   // log2 units: the running max is only raised (and O rescaled) when a tile exceeds it by more than this
+
+// D8 = d / 8 (5 or 10); QT = 32-query tiles per wave; one workgroup = 4 waves = 128 QT queries of one (batch, head).
+// QT = 2 halves, per query, everything that is per (workgroup, kv tile): the DMA pieces, the K / V^T fragment reads, the barrier —
+// and the per-workgroup prologue / epilogue; it runs at 2 waves per SIMD (<= 256 VGPRs).
+template <int D8, bool TWO, int QT>
+__global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kernel(Attn2Params p) {
+    constexpr int D = D8 * 8;
+    constexpr int D16 = (D + 15) / 16;             // QK k-steps of 16 and PV row tiles of 16
+    constexpr int KROW = D * 2;                    // K tile row bytes (contiguous rows: the DMA image is lane-linear)
+    constexpr int K_BYTES = A2_KV * KROW;          // d = 40: 5120
+    constexpr int VROWS = D16 * 16;                // V^T tile rows incl. the pad rows
+    constexpr int V_BYTES = VROWS * 128;           // 128 bytes = 64 kv per row, 16-byte slots XOR-swizzled by (row >> 1) & 7
+    constexpr int PAD_TAIL = 64;                   // the last K row's QK reads run past it when d % 16 != 0: keep them inside the buffer
+    constexpr int BUF = K_BYTES + PAD_TAIL + V_BYTES;
+    constexpr bool ONES = (D % 16) != 0;           // a spare V^T row of ones carries the row sums
+    constexpr int KP = D8, VP = D8;                // 1-KiB pieces per tile: K 64 * D8 chunks, V^T D rows * 8 chunks
+    constexpr int PPW = (KP + VP + A2_NW - 1) / A2_NW;     // pieces per wave per tile (the excess are dummies into scratch)
+    constexpr int SCRATCH = A2_NBUF * BUF;         // 1 KiB scratch for the dummy pieces
+    constexpr int QW = 32 * QT;                    // queries per wave
+    static_assert(SCRATCH + 1024 <= 65536, "LDS budget: d = 40 -> 35 KB (4 workgroups per CU), d = 80 -> 61 KB (2)");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SCRATCH + 1024];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    int qb, h, b;
+    {   // XCD-aware order: all query blocks of one (batch, head) on one XCD, back to back (its K / V^T stay in that L2)
+        const int L = blockIdx.x, xcd = L & 7, idx = L >> 3;
+        const int bh = (idx / p.qblocks) * 8 + xcd;
+        if (bh >= p.B * p.H) return;
+        qb = idx % p.qblocks; b = bh / p.H; h = bh - b * p.H;
+    }
+    const int q0w = qb * (A2_NW * QW) + wave * QW;           // this wave's first query
+    // 32-query tiles of this wave that hold a real query (wave-uniform): the waves past Tq still stage and synchronise
+    int nact = (p.Tq - q0w + 31) >> 5;
+    nact = __builtin_amdgcn_readfirstlane(nact < 0 ? 0 : (nact > QT ? QT : nact));
+    unsigned lds0 = (unsigned)(unsigned long long)(a2_lds_t*)smem;
+    if (A2_ABL) asm volatile("" : "+s"(lds0));
+
+    // ---- zero the LDS image once (pad rows / pad columns are never restaged), then the ones row ----
+    for (int c = tid; c < (SCRATCH + 1024) / 16; c += A2_NT) *(uint4*)(smem + c * 16) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (ONES) {
+        for (int c = tid; c < A2_NBUF * 8; c += A2_NT) {       // row D of every buffer's V^T tile: 8 slots of 16 bytes (the swizzle permutes them within the row)
+            const int bufi = c >> 3, slot = c & 7;
+            *(uint4*)(smem + bufi * BUF + K_BYTES + PAD_TAIL + D * 128 + slot * 16) = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+        }
+    }
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane -> query column, 8 consecutive dims ----
+    Frag8 qf[QT][D16];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int q = q0w + qt * 32 + col;
+        const bf16_t* qp = p.Q + (long)b * p.sQ + (long)(q < p.Tq ? q : 0) * p.ldq + (long)h * D;
+#pragma unroll
+        for (int ks = 0; ks < D16; ++ks) {
+            const int dd = ks * 16 + half * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q < p.Tq && dd < D) v = *(const uint4*)(qp + dd);
+            qf[qt][ks].u = v;
+        }
+    }
+    // The compiler cannot see the hand-counted LDS-DMA traffic on the VM counter: left alone it guards the first in-loop use of the Q
+    // registers with `s_waitcnt vmcnt(0)` on EVERY iteration (the loads are outside the loop), which drains the tile just issued and
+    // puts its whole latency on the critical path.  Consuming the registers here settles its bookkeeping before the loop.
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < D16; ++ks) asm volatile("" : "+v"(qf[qt][ks].u.x), "+v"(qf[qt][ks].u.y), "+v"(qf[qt][ks].u.z), "+v"(qf[qt][ks].u.w));
+
+    // ---- DMA bookkeeping: this wave's pieces (piece index pc = wave * PPW + j; K pieces first, then V^T, then dummies) ----
+    unsigned pv_off[PPW];          // per-lane byte offset inside the (b, h) K or V^T matrix at tile 0
+    int p_lds[PPW];                // wave-uniform LDS byte offset inside a buffer
+    int p_kind[PPW];               // 0 K, 1 V^T, 2 dummy (wave-uniform)
+    int p_row[PPW], p_kv[PPW];     // K: tile row of this lane's chunk; V^T: first kv of this lane's chunk (last-tile range checks)
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int pc = wave * PPW + j;
+        if (pc < KP) {
+            const int n = pc * 64 + lane;                      // linear 16-byte chunk of the K tile
+            const int row = n / D8, ch = n - row * D8;
+            p_kind[j] = 0; p_lds[j] = pc * 1024; p_row[j] = row; p_kv[j] = 0;
+            pv_off[j] = (unsigned)((row * p.ldk + ch * 8) * 2);
+        } else if (pc < KP + VP) {
+            const int row0 = (pc - KP) * 8;
+            const int row = mdx_xl::piece_lane_row(row0, lane), ch = mdx_xl::piece_lane_chunk(row0, lane);
+            p_kind[j] = 1; p_lds[j] = K_BYTES + PAD_TAIL + row0 * 128; p_row[j] = row; p_kv[j] = ch * 8;
+            pv_off[j] = (unsigned)((row * p.ldv + ch * 8) * 2);
+        } else {
+            p_kind[j] = 2; p_lds[j] = SCRATCH; p_row[j] = 0; p_kv[j] = 0; pv_off[j] = A2_OOB;
+        }
+    }
+    a2_rsrc_t rsK, rsV;
+    auto set_source = [&](int sidx) {
+        const int bkv = p.kvmap ? p.kvmap[b * p.nsrc + sidx] : b;
+        rsK = a2_make_rsrc(p.K + (long)bkv * p.sK + (long)h * D);
+        rsV = a2_make_rsrc(p.Vt + (long)bkv * p.sV + (long)h * D * p.ldv);
+    };
+    const int ntile = (p.Tk + A2_KV - 1) / A2_KV;
+    const int total = ntile * p.nsrc;
+    const int ldk2 = (int)p.ldk * 2;
+    // issue tile `t` of the current source into ring slot `slot`: branch-free (descriptor / tile offset / destination by scalar select)
+    auto issue = [&](int t, int slot) {
+        const int j0 = t * A2_KV;
+        const bool last = j0 + A2_KV > p.Tk;
+        const unsigned dst = lds0 + slot * BUF;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            unsigned vo = pv_off[j];
+            if (last) {                                       // rows / kv chunks past the end: zero fill
+                const int lim = p_kind[j] == 0 ? p_row[j] : p_kv[j];
+                if (p_kind[j] != 2 && j0 + lim >= p.Tk) vo = A2_OOB;
+            }
+            const bool isK = p_kind[j] != 1;                  // the dummy pieces go through the K descriptor (all lanes out of range)
+            a2_rsrc_t rs;
+            rs.x = isK ? rsK.x : rsV.x; rs.y = isK ? rsK.y : rsV.y; rs.z = A2_RECORDS; rs.w = 0x00020000u;
+            const int soff = p_kind[j] == 0 ? j0 * ldk2 : (p_kind[j] == 1 ? j0 * 2 : 0);
+            const unsigned ldsa = p_kind[j] == 2 ? lds0 + p_lds[j] : dst + p_lds[j];
+            a2_glds(rs, ldsa, vo, soff);
+        }
+    };
+
+    // ---- fragment read offsets ----
+    int k_rd[2];                                               // S^T sub-tile s: K rows s * 32 + col, this half's 16 bytes of k-step 0
+#pragma unroll
+    for (int s = 0; s < 2; ++s) k_rd[s] = (s * 32 + col) * KROW + half * 16;
+    const int v_rd0 = K_BYTES + PAD_TAIL + mdx_xl::frag_off(0, lane, 0), v_rd1 = K_BYTES + PAD_TAIL + mdx_xl::frag_off(0, lane, 1);
+
+    f32x4_t oacc[QT][D16][2];
+    // cross-view: the first neighbour's normalised output waits here, rounded to bf16 (the reference adds two fp16 attention outputs,
+    // blocks.py:213-217) — half the registers of an fp32 copy, which is what keeps the 64-query kernel spill-free
+    unsigned osum[TWO ? QT : 1][TWO ? D16 : 1][2][2];
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        m_run[qt] = -INFINITY; l_run[qt] = 0.f;
+#pragma unroll
+        for (int i = 0; i < D16; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    oacc[qt][i][t][e] = 0.f;
+                }
+    }
+
+    // One kv tile for the first NQ_ query tiles of the wave: scores, online softmax, PV.  The K / V^T fragments are read once and used
+    // by every query tile.  LAST adds the kv >= Tk mask (the V^T pad columns were scrubbed by the caller).
+    // Online softmax with a deferred maximum: m_run is raised only when a tile exceeds it by more than A2_DEFER (wave-uniform
+    // decision), so most tiles skip the O rescale and its two cross-lane fetches.  Until then probabilities are relative to the older
+    // maximum (at most 2^A2_DEFER instead of 1) — the numerator and the row sum carry the same factor and it cancels in O = (P V) / l.
+#define A2_TILE(LAST, NQ_, slot_, j0_)                                                                                 \
+    {                                                                                                                  \
+        const unsigned char* sb_ = smem + (slot_) * BUF;                                                               \
+        Frag8 kf_[2][D16], vf_[2][D16];                                                                                \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                  \
+            _Pragma("unroll") for (int ks = 0; ks < D16; ++ks) kf_[s][ks].u = *(const uint4*)(sb_ + k_rd[s] + ks * 32); \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                  \
+            _Pragma("unroll") for (int i = 0; i < D16; ++i) vf_[s][i].u = *(const uint4*)(sb_ + (s ? v_rd1 : v_rd0) + i * 2048); \
+        _Pragma("unroll") for (int qt = 0; qt < NQ_; ++qt) {                                                           \
+            f32x16_t sacc[2];                                                                                          \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                            \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) sacc[s][r] = 0.f;                                       \
+                _Pragma("unroll") for (int ks = 0; ks < D16; ++ks) {                                                   \
+                    if (A2_ABL & 8) sacc[s][ks] += __uint_as_float(kf_[s][ks].u.x ^ qf[qt][ks].u.x);                   \
+                    else sacc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf_[s][ks].v, qf[qt][ks].v, sacc[s], 0, 0, 0); \
+                }                                                                                                      \
+            }                                                                                                          \
+            if (LAST) {                                                                                                \
+                _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                          \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                     \
+                        if ((j0_) + s * 32 + mfma32_row(r, lane) >= p.Tk) sacc[s][r] = -INFINITY;                      \
+            }                                                                                                          \
+            float mx = -INFINITY;                                                                                      \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                              \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[s][r]);                             \
+            {   /* max with the other half of this query (lane ^ 32): one v_permlane32_swap instead of a ds_bpermute */  \
+                const unsigned mu_ = __float_as_uint(mx);                                                              \
+                auto sw_ = __builtin_amdgcn_permlane32_swap(mu_, mu_, false, false);                                   \
+                mx = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1])) * p.scale_log2;                           \
+            }                                                                                                          \
+            float alpha = 1.0f;                                                                                        \
+            if (__builtin_amdgcn_ballot_w64(mx > m_run[qt] + A2_DEFER) != 0 && !(A2_ABL & 4)) {                        \
+                const float m_new = fmaxf(m_run[qt], mx);                                                              \
+                alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);           /* first tile: exp2(-inf) = 0 on zeros */ \
+                m_run[qt] = m_new;                                                                                     \
+                /* the accumulators are in the 16x16 layout (lane -> query 16 t + (lane & 15)): fetch that query's alpha */ \
+                const float al0 = __shfl(alpha, lane & 15, 64), al1 = __shfl(alpha, 16 + (lane & 15), 64);              \
+                /* in place (asm): as plain C the rare arm gets its own result registers and the common arm pays 24 copies */ \
+                _Pragma("unroll") for (int i = 0; i < D16; ++i)                                                        \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                    \
+                        asm volatile("v_mul_f32 %0, %0, %1" : "+v"(oacc[qt][i][0][e]) : "v"(al0));                     \
+                        asm volatile("v_mul_f32 %0, %0, %1" : "+v"(oacc[qt][i][1][e]) : "v"(al1));                     \
+                    }                                                                                                  \
+            }                                                                                                          \
+            const float mneg_ = -m_run[qt];                                                                            \
+            float psum = 0.f;                                                                                          \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                            \
+                Frag8 b0, b1;                                                                                          \
+                _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                        \
+                    float p0 = __builtin_fmaf(sacc[s][2 * u], p.scale_log2, mneg_);                                    \
+                    float p1 = __builtin_fmaf(sacc[s][2 * u + 1], p.scale_log2, mneg_);                                \
+                    if (!(A2_ABL & 1)) { p0 = __builtin_amdgcn_exp2f(p0); p1 = __builtin_amdgcn_exp2f(p1); }           \
+                    if (!ONES) psum += p0 + p1;                                                                        \
+                    const unsigned pk_ = pack2bf(p0, p1);                                                              \
+                    /* x = (pk0, pk1, pk4, pk5), y = (pk2, pk3, pk6, pk7): see p_to_b_operand */                        \
+                    if (u == 0) b0.u.x = pk_; if (u == 1) b0.u.y = pk_; if (u == 4) b0.u.z = pk_; if (u == 5) b0.u.w = pk_; \
+                    if (u == 2) b1.u.x = pk_; if (u == 3) b1.u.y = pk_; if (u == 6) b1.u.z = pk_; if (u == 7) b1.u.w = pk_; \
+                }                                                                                                      \
+                if (!(A2_ABL & 2)) p_to_b_operand(b0, b1);                                                             \
+                _Pragma("unroll") for (int i = 0; i < D16; ++i) {                                                      \
+                    if (A2_ABL & 16) { oacc[qt][i][0][0] += __uint_as_float(vf_[s][i].u.x ^ b0.u.x ^ b0.u.y ^ b0.u.z ^ b0.u.w); oacc[qt][i][1][0] += __uint_as_float(vf_[s][i].u.y ^ b1.u.x ^ b1.u.y ^ b1.u.z ^ b1.u.w); } \
+                    else {                                                                                             \
+                        oacc[qt][i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf_[s][i].v, b0.v, oacc[qt][i][0], 0, 0, 0); \
+                        oacc[qt][i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf_[s][i].v, b1.v, oacc[qt][i][1], 0, 0, 0); \
+                    }                                                                                                  \
+                }                                                                                                      \
+            }                                                                                                          \
+            if (!ONES) l_run[qt] = l_run[qt] * alpha + psum;                                                           \
+        }                                                                                                              \
+    }
+    // ---- prologue: tiles 0 and 1 of the stream in flight ----
+    int ds = 0;                          // source the descriptors currently describe
+    set_source(0);
+    int it = 0, is_ = 0;                 // issue cursor: tile inside its source, source index
+    auto issue_next = [&](int slot_) {
+        if (is_ != ds) { set_source(is_); ds = is_; }
+        issue(it, slot_);
+        if (++it == ntile) { it = 0; ++is_; }
+    };
+    issue_next(0);
+    if (total > 1) issue_next(1);
+    int g = 0;                           // tile of the whole stream (both sources) being multiplied
+    int slot = 0;
+    // start of tile g: its pieces have landed for every wave, every wave is done with tile g - 1, tile g + 2 goes out
+    auto tile_sync = [&]() {
+        if (g + 1 < total) a2_wait_vmcnt<PPW>(); else a2_wait_vmcnt<0>();      // at most the one younger tile's pieces outstanding
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (g + 2 < total && !(A2_ABL & 64)) {
+            int s2 = slot + 2; if (s2 >= A2_NBUF) s2 -= A2_NBUF;
+            issue_next(s2);
+        }
+    };
+    auto tile_done = [&]() { ++g; if (++slot == A2_NBUF) slot = 0; };
+    const int nfull = p.Tk / A2_KV;      // full tiles per source; a partial one follows when Tk % 64 != 0
+
+    // The loop nest of one source, for the first NQ_ query tiles of the wave.  The full tiles run in a loop with ONE body (so the
+    // accumulators stay in place: with the masked body as a second arm of the same loop the compiler copies all of them every
+    // iteration); the partial last tile is peeled behind it.
+#define A2_SOURCE(NQ_)                                                                                                 \
+    {                                                                                                                  \
+        for (int t = 0; t < nfull; ++t) {                                                                              \
+            tile_sync();                                                                                               \
+            A2_TILE(false, NQ_, slot, t * A2_KV)                                                                       \
+            tile_done();                                                                                               \
+        }                                                                                                              \
+        if (nfull < ntile) {                                                                                           \
+            tile_sync();                                                                                               \
+            /* scrub the V^T pad columns (kv >= Tk inside the last partially valid 16-byte chunk may hold anything, and 0 * NaN is NaN) */ \
+            const int kv_lo = p.Tk - nfull * A2_KV;             /* first invalid kv inside the tile (1..63) */          \
+            if ((kv_lo & 7) != 0) {                                                                                    \
+                const int chunk = kv_lo >> 3, e0 = kv_lo & 7;                                                          \
+                for (int r = tid; r < D; r += A2_NT) {                                                                 \
+                    bf16_t* rowp = (bf16_t*)(smem + slot * BUF + K_BYTES + PAD_TAIL + r * 128 + ((chunk ^ mdx_xl::swz(r)) << 4)); \
+                    for (int e = e0; e < 8; ++e) rowp[e] = 0;                                                          \
+                }                                                                                                      \
+                __syncthreads();                                                                                       \
+            }                                                                                                          \
+            A2_TILE(true, NQ_, slot, nfull * A2_KV)                                                                    \
+            tile_done();                                                                                               \
+        }                                                                                                              \
+    }
+
+    for (int src = 0; src < p.nsrc; ++src) {
+        if (QT == 2 && nact == 2) A2_SOURCE((QT == 2 ? 2 : 1))
+        else if (nact >= 1) A2_SOURCE(1)
+        else A2_SOURCE(0)
+        // ---- end of a source: normalise, accumulate (cross-view), reset ----
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float inv0, inv1;
+            if (ONES) {
+                // row D of O^T = sum of the (bf16) probabilities: tile D / 16, local row D % 16 = 8 -> lanes 32..47, register 0
+                constexpr int LT = ONES ? D / 16 : 0;
+                inv0 = 1.0f / __shfl(oacc[qt][LT][0][0], 32 + (lane & 15), 64);
+                inv1 = 1.0f / __shfl(oacc[qt][LT][1][0], 32 + (lane & 15), 64);
+            } else {
+                const float l_tot = l_run[qt] + __shfl_xor(l_run[qt], 32, 64);          // per S-layout lane: query lane & 31
+                const float inv = 1.0f / l_tot;
+                inv0 = __shfl(inv, lane & 15, 64); inv1 = __shfl(inv, 16 + (lane & 15), 64);
+            }
+#pragma unroll
+            for (int i = 0; i < D16; ++i)
+#pragma unroll
+                for (int tq = 0; tq < 2; ++tq) {
+                    const float inv = tq ? inv1 : inv0;
+                    f32x4_t& a = oacc[qt][i][tq];
+                    if (TWO && src == 0) {                     // first neighbour done: park it, restart the accumulators
+                        osum[TWO ? qt : 0][TWO ? i : 0][tq][0] = pack2bf(a[0] * inv, a[1] * inv);
+                        osum[TWO ? qt : 0][TWO ? i : 0][tq][1] = pack2bf(a[2] * inv, a[3] * inv);
+                        a[0] = 0.f; a[1] = 0.f; a[2] = 0.f; a[3] = 0.f;
+                    } else {
+                        a[0] *= inv; a[1] *= inv; a[2] *= inv; a[3] *= inv;
+                        if (TWO) {
+                            const unsigned u0 = osum[TWO ? qt : 0][TWO ? i : 0][tq][0], u1 = osum[TWO ? qt : 0][TWO ? i : 0][tq][1];
+                            a[0] += __uint_as_float(u0 << 16); a[1] += __uint_as_float(u0 & 0xffff0000u);
+                            a[2] += __uint_as_float(u1 << 16); a[3] += __uint_as_float(u1 & 0xffff0000u);
+                        }
+                    }
+                }
+            m_run[qt] = -INFINITY; l_run[qt] = 0.f;
+        }
+    }
+#undef A2_SOURCE
+#undef A2_TILE
+    a2_wait_vmcnt<0>();
+
+    // ---- store O[q][h * d + dd]: 16x16 layout: lane -> query 16 t + (lane & 15), rows dd = 16 i + 4 (lane >> 4) + e ----
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int tq = 0; tq < 2; ++tq) {
+            const int qq = q0w + qt * 32 + tq * 16 + (lane & 15);
+            if (qq >= p.Tq) continue;
+            bf16_t* op = p.O + (long)b * p.sO + (long)qq * p.ldo + (long)h * D;
+#pragma unroll
+            for (int i = 0; i < D16; ++i) {
+                const int dd = i * 16 + 4 * (lane >> 4);
+                if (dd < D) {
+                    const f32x4_t& src = oacc[qt][i][tq];
+                    uint2 ov;
+                    ov.x = pack2bf(src[0], src[1]);
+                    ov.y = pack2bf(src[2], src[3]);
+                    *(uint2*)(op + dd) = ov;
+                }
+            }
+        }
+}
+
+template <int D8, int QT>
+static int launch_attn2_d(const Attn2Params& p, hipStream_t st) {
+    Attn2Params q = p;
+    q.qblocks = (p.Tq + A2_NW * 32 * QT - 1) / (A2_NW * 32 * QT);
+    const dim3 grid((unsigned)(((long)p.B * p.H + 7) / 8 * 8 * q.qblocks), 1, 1);
+    if (p.nsrc == 2) hipLaunchKernelGGL((attn2_kernel<D8, true, QT>), grid, dim3(A2_NT), 0, st, q);
+    else hipLaunchKernelGGL((attn2_kernel<D8, false, QT>), grid, dim3(A2_NT), 0, st, q);
+    char tag[64];
+    snprintf(tag, sizeof tag, "attn2_kernel<%d,%s,q%d>", D8 * 8, p.nsrc == 2 ? "xview" : "self", 32 * QT);
+    return check_launch(tag);
+}
+
+// Shapes the lean kernel takes (everything else stays on attention.hip): head dim 40 or 80, enough query blocks to fill the chip,
+// 16-byte aligned K rows / V^T rows, matrices within the 2 GiB DMA window.
+bool attn2_supported(const Attn2Params& p) {
+    static const int on = [] { const char* e = getenv("MDX_ATTN2"); return e ? atoi(e) : 1; }();
+    static const int d80 = [] { const char* e = getenv("MDX_ATTN2_D80"); return e ? atoi(e) : 0; }();   // d = 80: slower than attention.hip so far
+    if (!on || (p.d != 40 && !(p.d == 80 && d80))) return false;
+    if (p.Tq < 256 || (long)((p.Tq + 127) / 128) * p.H * p.B < 128) return false;
+    if ((p.ldk % 8) || (p.ldv % 8) || (p.sK % 8) || (p.sV % 8) || (p.ldv < ((p.Tk + 7) / 8) * 8)) return false;
+    if ((long)p.Tk * p.ldk * 2 >= 0x40000000L || (long)p.d * p.H * p.ldv * 2 >= 0x40000000L) return false;
+    return true;
+}
+
+int launch_attn2(const Attn2Params& p, hipStream_t st) {
+    // 64 queries per wave (see attn2_kernel) when there are enough queries per head; MDX_ATTN2_QT=1 forces 32
+    static const int qt = [] { const char* e = getenv("MDX_ATTN2_QT"); return e ? atoi(e) : 2; }();
+    const bool two = qt == 2 && p.Tq >= 512 && p.d == 40;
+    if (p.d == 40) return two ? launch_attn2_d<5, 2>(p, st) : launch_attn2_d<5, 1>(p, st);
+    return launch_attn2_d<10, 1>(p, st);
+}
+
+}  // namespace mdx

@@ -1,0 +1,16 @@
+// attn2.h — parameters of the lean attention kernel (attention2.hip), shared with the dispatcher in attention.hip
+#pragma once
+#include "common.h"
+namespace mdx {
+struct Attn2Params {
+    const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
+    const int* kvmap;
+    int B, H, Tq, Tk, d, nsrc;
+    long ldq, sQ, ldk, sK, ldv, sV, ldo, sO;
+    float scale_log2;  // scale * log2(e)
+    int qblocks;       // query blocks per (batch, head), filled in by launch_attn2
+
+};
+bool attn2_supported(const Attn2Params& p);
+int launch_attn2(const Attn2Params& p, hipStream_t st);
+}  // namespace mdx

@@ -1,5 +1,5 @@
 """Worker of tests/test_routes_gpu.py::test_forced_routes: the library reads its routing switches (MDX_GEMM_XL, MDX_XL_BN, ...) from the
-environment ONCE per process, so every forced route runs in its own interpreter.  Usage: python tests/route_worker.py xl320|xl256|xl160|noxl
+environment ONCE per process, so every forced route runs in its own interpreter.  Usage: python tests/route_worker.py xl320|xl256|xl160|noxl|attn_q32|attn_d80|attn_old
 Prints ROUTE_WORKER_OK on success; any failure raises."""
 import os
 import sys
@@ -82,6 +82,17 @@ elif mode == "noxl":
     conv_case(600, 4, 7, 320, 320, expect="conv3x3_kernel")                                   # 4x7 images
     conv_case(22, 28, 28, 640, 640, expect="conv3x3_kernel")                                  # 28-px rows straddling 128-row tiles
     gemm_case(537600, 320, 320, res=True, expect="gemm_ws_kernel<plain>")                     # bench row count
+elif mode in ("attn_q32", "attn_d80", "attn_old"):
+    # attention2.hip's other instantiations (32-query waves; head dim 80) and attention.hip at the same shapes, through the tests
+    # of tests/test_kernels_gpu.py (their route assertion follows this process's switches)
+    import test_kernels_gpu as T
+    assert {"attn_q32": os.environ.get("MDX_ATTN2_QT") == "1", "attn_d80": os.environ.get("MDX_ATTN2_D80") == "1",
+            "attn_old": os.environ.get("MDX_ATTN2") == "0"}[mode]
+    for case in T.ATTN2_CASES:
+        T.test_attention2(dev, *case)
+    T.test_attention2_softmax_rescale_branch(dev)
+    for case in [(1, 8, 1400, 40), (3, 8, 350, 80), (2, 8, 700, 40)]:
+        T.test_attention2_crossview(dev, *case)
 else:
     raise SystemExit(f"unknown mode {mode}")
 print("ROUTE_WORKER_OK")

@@ -535,3 +535,85 @@ def test_cfg_ddim_bf16_padded_model_input(dev):
     exp = x.cpu().view(npx, Cc).to(BF)           # the copy is the bf16 rounding of the kernel's own fp32 result
     assert torch.equal(xin[:npx, :Cc].cpu(), exp) and torch.equal(xin[npx:, :Cc].cpu(), exp)
     assert (xin[:, Cc:].float() == 7.0).all(), "pad channels must not be touched"
+
+
+# ---- attention2.hip (head dim 40, >= 128 workgroups; 80 behind MDX_ATTN2_D80): routes asserted, the rare branches forced ---------
+def attn2_route(d, Tq, xview=False):
+    """Kernel mdx_attention_bf16 must pick for (d, Tq) under this process's switches (the library reads them once per process;
+    tests/test_routes_gpu.py::test_forced_routes re-runs these tests with MDX_ATTN2_QT=1 and MDX_ATTN2_D80=1 in worker processes)."""
+    import os
+    mode = "xview" if xview else "self"
+    if os.environ.get("MDX_ATTN2", "1") == "0" or (d == 80 and os.environ.get("MDX_ATTN2_D80", "0") == "0"):
+        return "attn_kernel<"                                       # attention.hip (prefix)
+    q = 64 if (d == 40 and Tq >= 512 and os.environ.get("MDX_ATTN2_QT", "2") == "2") else 32
+    return f"attn2_kernel<{d},{mode},q{q}>"
+
+
+ATTN2_CASES = [
+    (6, 8, 1400, 1400, 40),      # 22 tiles, the last one 56 kv wide; 64-query waves: the last workgroup has 2 idle waves and a half wave
+    (6, 8, 1400, 78, 40),        # context: 2 tiles, pad columns inside a 16-byte chunk (NaN-poisoned below)
+    (6, 8, 1400, 64, 40),        # exactly one full tile: no masked tile at all
+    (6, 8, 1400, 129, 40),       # last tile 1 kv wide
+    (6, 8, 350, 350, 80),
+    (6, 8, 350, 110, 80),
+    (3, 8, 777, 333, 40),        # ragged query block (777 = 3 x 256 + 9 = 6 x 128 + 9)
+    (6, 8, 300, 300, 40),        # below 512 queries: 32-query waves
+]
+
+
+@pytest.mark.parametrize("B,heads,Tq,Tk,d", ATTN2_CASES)
+def test_attention2(dev, B, heads, Tq, Tk, d):
+    Cc = heads * d
+    q = rnd(B, Tq, Cc, seed=1); k = rnd(B, Tk, Cc, seed=2); v = rnd(B, Tk, Cc, seed=3)
+    ldv = PK.round_up(Tk, 8)
+    vt = torch.full((B, Cc, ldv), float("nan"), dtype=BF, device=dev)   # garbage in the kv pad must not leak
+    vt[:, :, :Tk] = v.transpose(1, 2)
+    o = torch.full((B, Tq, Cc), float("nan"), dtype=BF, device=dev)
+    O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=Tk, scale=d ** -0.5)])
+    kern = (L.lib().mdx_last_kernel() or b"").decode()
+    torch.cuda.synchronize()
+    assert kern.startswith(attn2_route(d, Tq)), kern
+    ref = ref_attention(q.float().cpu(), k.float().cpu(), v.float().cpu(), heads, d ** -0.5)
+    close(o, ref, rtol=2e-2, atol_rel=2e-2, name=f"attn2 {B},{heads},{Tq},{Tk},{d}")
+
+
+def test_attention2_softmax_rescale_branch(dev):
+    """cdna guide rule 26 on the new kernel: the running max jumps in a LATE kv tile for one query (and early for another) by far more
+    than the deferral threshold, so the O accumulators (16x16 layout) must be rescaled with the alpha of the right query lane — while
+    the other queries of the same wave, whose max did not move, are multiplied by exactly 1; fp64 reference."""
+    B, heads, Tq, Tk, d = 6, 8, 512, 448, 40
+    Cc = heads * d
+    q = rnd(B, Tq, Cc, seed=1); k = rnd(B, Tk, Cc, seed=2); v = rnd(B, Tk, Cc, seed=3)
+    for h in range(heads):
+        k[0, 400, h * d:(h + 1) * d] = q[0, 5 + h, h * d:(h + 1) * d] * 6.0       # spike in the 7th tile for query 5 + h of head h
+        k[1, 10, h * d:(h + 1) * d] = q[1, 200 + 17 * h, h * d:(h + 1) * d] * 6.0  # an early one that later tiles must not disturb
+    vt = torch.zeros(B, Cc, Tk, dtype=BF, device=dev); vt[:] = v.transpose(1, 2)
+    o = torch.zeros(B, Tq, Cc, dtype=BF, device=dev)
+    O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=Tk, scale=d ** -0.5)])
+    kern = (L.lib().mdx_last_kernel() or b"").decode()
+    torch.cuda.synchronize()
+    assert kern.startswith(attn2_route(40, Tq)), kern
+    ref = ref_attention(q.double().cpu(), k.double().cpu(), v.double().cpu(), heads, d ** -0.5)
+    close(o, ref, rtol=2e-2, atol_rel=2e-2, name="attn2 rescale")
+
+
+@pytest.mark.parametrize("b,heads,T,d", [(1, 8, 1400, 40), (3, 8, 350, 80), (2, 8, 700, 40)])
+def test_attention2_crossview(dev, b, heads, T, d):
+    ncam = 6
+    pair = {0: [5, 1], 1: [0, 2], 2: [1, 3], 3: [2, 4], 4: [3, 5], 5: [4, 0]}
+    Cc = heads * d; B = b * ncam
+    q = rnd(B, T, Cc, seed=1); k = rnd(B, T, Cc, seed=2); v = rnd(B, T, Cc, seed=3)
+    vt = torch.full((B, Cc, PK.round_up(T, 8)), float("nan"), dtype=BF, device=dev); vt[:, :, :T] = v.transpose(1, 2)
+    kvmap = torch.tensor([(i // ncam) * ncam + pair[i % ncam][s] for i in range(B) for s in range(2)], dtype=torch.int32, device=dev)
+    o = torch.zeros(B, T, Cc, dtype=BF, device=dev)
+    O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=T, scale=d ** -0.5, kvmap=kvmap, nsrc=2)])
+    kern = (L.lib().mdx_last_kernel() or b"").decode()
+    torch.cuda.synchronize()
+    assert kern.startswith(attn2_route(d, T, xview=True)), kern
+    qc, kc, vc = q.float().cpu(), k.float().cpu(), v.float().cpu()
+    ref = torch.zeros(B, T, Cc)
+    for i in range(B):
+        for s in range(2):
+            j = (i // ncam) * ncam + pair[i % ncam][s]
+            ref[i] += ref_attention(qc[i:i + 1], kc[j:j + 1], vc[j:j + 1], heads, d ** -0.5)[0]
+    close(o, ref, rtol=2e-2, atol_rel=2e-2, name="attn2 cross-view")

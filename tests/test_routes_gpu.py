@@ -152,6 +152,9 @@ def test_xl_conv(dev, B, H, W, Cin, Cout, stride, res, temb, expect):
     ("xl256", {"MDX_GEMM_XL": "2", "MDX_XL_BN": "256"}),
     ("xl160", {"MDX_GEMM_XL": "2", "MDX_XL_BN": "160"}),
     ("noxl", {"MDX_GEMM_XL": "0"}),
+    ("attn_q32", {"MDX_ATTN2_QT": "1"}),
+    ("attn_d80", {"MDX_ATTN2_D80": "1"}),
+    ("attn_old", {"MDX_ATTN2": "0"}),
 ])
 def test_forced_routes(dev, mode, env):
     import os
