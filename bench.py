@@ -163,6 +163,9 @@ def main():
                     help="after the headline measurement also time ONE configs[2] call of this many scenes per GPU (CFG doubles the views: 32 scenes = "
                          "the headline's 384 views) and report it as config.full_cond_scenes_per_s; 0 skips it")
     ap.add_argument("--no-consistency-check", action="store_true")
+    ap.add_argument("--vae-scenes", type=int, default=8,
+                    help="outside the timed region: decode this many scenes' latents with the HIP AutoencoderKL (VAE_SD15_CONFIG, random weights) — what output_type='np' "
+                         "adds per scene (config.vae_decode_ms_per_scene, config.scenes_per_s_incl_vae_decode); 0 skips it")
     args = ap.parse_args()
 
     from magicdrive_amd import distributed as DD
@@ -232,6 +235,20 @@ def main():
         assert torch.isfinite(fout).all()
         full_cond = {"scenes_per_s": nb * world / fdt, "scenes_per_gpu": nb, "seconds_per_call": fdt}
 
+    vae_ms = None
+    if args.vae_scenes > 0:
+        from magicdrive_amd.networks.autoencoder_kl import AutoencoderKL
+        vae = AutoencoderKL.from_config(spec.VAE_SD15_CONFIG, 7).to(dev)
+        nv = min(args.vae_scenes, b)
+        zl = (res[:nv].to(dev).float() / 0.18215).reshape(-1, 4, 28, 50)            # decode_latents, pipeline_bev_controlnet.py:100-112
+        img = vae.decode(zl).sample                                                  # plan build + warm-up
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        img = vae.decode(zl).sample
+        img = (img / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).float().cpu()          # the pipeline's "np" output incl. the device -> host copy
+        vae_ms = 1e3 * (time.perf_counter() - t2) / nv
+        assert img.shape == (6 * nv, 224, 400, 3) and torch.isfinite(img).all()
+        del vae, img, zl
     if rank != 0:
         return
     plan = next(pl for pl in pipe._plans.values() if pl.b == b and pl.do_cfg == (gs > 1.0 and cam is not None))
@@ -250,6 +267,8 @@ def main():
                    "tflop_per_scene": round(f_scene / 1e12, 3),
                    "mfma_frac_end_to_end": round(f_scene * scenes_per_s / world / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                    "batch_consistency_rel": None if consistency is None else round(consistency, 5),
+                   "vae_decode_ms_per_scene": None if vae_ms is None else round(vae_ms, 2),
+                   "scenes_per_s_incl_vae_decode": None if vae_ms is None else round(1.0 / (world / scenes_per_s + vae_ms * 1e-3) * world, 4),
                    "full_cond_scenes_per_s": None if full_cond is None else round(full_cond["scenes_per_s"], 4),
                    "full_cond": None if full_cond is None else
                    {"workload": "configs[2]: 6-view 224x400, camera + 32 boxes + BEV map, CFG 2.0, same sampler", "scenes_per_gpu": full_cond["scenes_per_gpu"],

@@ -138,71 +138,87 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_kernel(GNParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Two-stage GroupNorm for the big (HBM/Infinity-Cache-bound) feature maps: every global access is a full
-// 16-byte-per-lane coalesced row segment (the one-workgroup-per-group kernel above reads 20-byte pieces at a
-// 640-byte stride when C/G = 10).  Deterministic: no atomics, partials combined in a fixed order (Chan).
-//   stage 1  gn_stats_kernel : grid (chunks, B); a chunk = PCH pixels x C staged in LDS; thread (g, s) reduces
-//            its group over pixels s, s+SUB, ... -> (n, mean, M2) per (b, chunk, g)
-//   stage 2  gn_apply_kernel : grid (chunks, B); combines the chunk partials of its b, builds per-channel
-//            scale/shift in LDS, then y = [silu](x * scale[c] + shift[c]) with 16-byte loads/stores.
+// Two-stage GroupNorm for the big (HBM/Infinity-Cache-bound) feature maps: pure streaming, every global access a full 16-byte-per-lane
+// coalesced row segment (the one-workgroup-per-group kernel above reads 20-byte pieces at a 640-byte stride when C/G = 10), several
+// loads in flight per lane, no LDS staging.  Deterministic: no atomics, partials combined in a fixed order (Chan).
+// Thread layout of both stages: the workgroup covers ROWS = 256 / (C/8) pixel rows at a time, thread (r, cc) owns the SAME 8 channels
+// cc*8.. of rows r, r + ROWS, ... of its chunk — so the per-channel state (sums in stage 1, scale / shift in stage 2) lives in
+// registers.  C/8 > 256 (C = 2560): a thread owns NCV = 2 channel vectors.
+//   stage 1  gn_stats_kernel : grid (chunks, B); per-channel sums of (x - pivot_g) and (x - pivot_g)^2 in registers (pivot_g = the
+//            group's first element of the chunk: keeps E[d^2] - E[d]^2 well conditioned in fp32), reduced over rows and over the
+//            group's channels through LDS in a fixed order -> (n, mean, M2) per (b, chunk, g)
+//   stage 2  gn_apply_kernel : grid (chunks, B); combines the chunk partials of its b, then y = [silu](x * scale[c] + shift[c]).
 struct GN2Params {
     const bf16_t* X; bf16_t* Y; const float* gamma; const float* beta; float* part;   // part: [B][nchunk][G][3]
     int B, HW, C, G, PCH, nchunk; long ldx, ldy; float eps; int silu;
 };
 
-constexpr int GN2_TILE = 16384;   // elements staged per workgroup (32 KiB of LDS)
+constexpr int GN2_MAXC = 4096;    // channels (LDS: 2 x rows x C floats in stage 1 with rows x C <= 2048 .. see gn2_rows)
+constexpr int GN2_U = 4;          // pixel rows in flight per thread
 
+__device__ __forceinline__ int gn2_rows(int C8) { return C8 >= 256 ? 1 : 256 / C8; }
+
+template <int NCV>
 __global__ __launch_bounds__(256) void gn_stats_kernel(GN2Params p) {
-    __shared__ __attribute__((aligned(16))) bf16_t tile[GN2_TILE];
-    __shared__ float red[256 * 3];
+    __shared__ float ls1[256 * 8 * NCV], ls2[256 * 8 * NCV];       // [row][C] sums (rows * C <= 2048 * NCV)
+    __shared__ float lpiv[256];                                    // per group pivot (G <= 256)
     const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int px0 = chunk * p.PCH;
     const int npx = min(p.PCH, p.HW - px0);
-    const int C8 = p.C / 8;
+    const int C8 = p.C / 8, cpg = p.C / p.G;
+    const int rows = gn2_rows(C8);
     const bf16_t* xb = p.X + ((long)b * p.HW + px0) * p.ldx;
-    for (int i = tid; i < npx * C8; i += 256) {
-        const int px = i / C8, cc = i - px * C8;
-        *(uint4*)(tile + px * p.C + cc * 8) = *(const uint4*)(xb + (long)px * p.ldx + cc * 8);
+    if (tid < p.G) lpiv[tid] = bf2f(xb[tid * cpg]);
+    __syncthreads();
+    const int r0 = NCV == 1 ? tid / C8 : 0;
+    const bool active = NCV == 1 ? r0 < rows : true;
+    float s1[NCV][8], s2[NCV][8], pv[NCV][8];
+    int cc[NCV];
+#pragma unroll
+    for (int k = 0; k < NCV; ++k) {
+        cc[k] = NCV == 1 ? tid - r0 * C8 : tid + 256 * k;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[k][e] = 0.f; s2[k][e] = 0.f; pv[k][e] = (cc[k] < C8) ? lpiv[(cc[k] * 8 + e) / cpg] : 0.f; }
+    }
+    if (active) {
+        const int ldx = (int)p.ldx;
+        for (int px = r0; px < npx; px += rows * GN2_U) {
+            Frag8 f[GN2_U][NCV];
+#pragma unroll
+            for (int u = 0; u < GN2_U; ++u)
+#pragma unroll
+                for (int k = 0; k < NCV; ++k)
+                    if (px + u * rows < npx && cc[k] < C8) f[u][k].u = *(const uint4*)(xb + (long)(px + u * rows) * ldx + cc[k] * 8);
+#pragma unroll
+            for (int u = 0; u < GN2_U; ++u)
+#pragma unroll
+                for (int k = 0; k < NCV; ++k)
+                    if (px + u * rows < npx && cc[k] < C8) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float d = bf2f(f[u][k].h[e]) - pv[k][e]; s1[k][e] += d; s2[k][e] = __builtin_fmaf(d, d, s2[k][e]); }
+                    }
+        }
+#pragma unroll
+        for (int k = 0; k < NCV; ++k)
+            if (cc[k] < C8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ls1[r0 * p.C + cc[k] * 8 + e] = s1[k][e]; ls2[r0 * p.C + cc[k] * 8 + e] = s2[k][e]; }
+            }
     }
     __syncthreads();
-    const int SUB = 256 / p.G;                 // pixel sub-slots per group
-    const int g = tid % p.G, sl = tid / p.G;
-    const int cpg = p.C / p.G;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    if (sl < SUB) {
-        const float pivot = bf2f(tile[g * cpg]);
-        float s1 = 0.f, s2 = 0.f;
-        int cnt = 0;
-        for (int px = sl; px < npx; px += SUB) {
-            const bf16_t* t = tile + px * p.C + g * cpg;
-            for (int c = 0; c < cpg; c += 2) {          // cpg is even for every shape routed here
-                const uint32_t u = *(const uint32_t*)(t + c);
-                const float a = bf2f((bf16_t)(u & 0xffff)) - pivot, d = bf2f((bf16_t)(u >> 16)) - pivot;
-                s1 += a + d; s2 += a * a + d * d;
-            }
-            cnt += cpg;
-        }
-        if (cnt > 0) { n = (float)cnt; mean = pivot + s1 / n; m2 = fmaxf(s2 - s1 * s1 / n, 0.f); }
-    }
-    red[tid * 3] = n; red[tid * 3 + 1] = mean; red[tid * 3 + 2] = m2;
-    __syncthreads();
-    if (tid < p.G) {                            // fixed-order Chan combine of the SUB sub-slots
-        float na = 0.f, ma = 0.f, qa = 0.f;
-        for (int s2i = 0; s2i < SUB; ++s2i) {
-            const float nb = red[(s2i * p.G + tid) * 3], mb = red[(s2i * p.G + tid) * 3 + 1], qb = red[(s2i * p.G + tid) * 3 + 2];
-            if (nb > 0.f) {
-                const float nn = na + nb, dl = mb - ma;
-                ma += dl * nb / nn; qa += qb + dl * dl * na * nb / nn; na = nn;
-            }
-        }
+    if (tid < p.G) {                            // fixed order: channels of the group, rows inside a channel
+        float a1 = 0.f, a2 = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c)
+            for (int r = 0; r < rows; ++r) { a1 += ls1[r * p.C + c]; a2 += ls2[r * p.C + c]; }
+        const float n = (float)npx * (float)cpg;
         float* o = p.part + (((long)b * p.nchunk + chunk) * p.G + tid) * 3;
-        o[0] = na; o[1] = ma; o[2] = qa;
+        o[0] = n; o[1] = lpiv[tid] + a1 / n; o[2] = fmaxf(a2 - a1 * a1 / n, 0.f);
     }
 }
 
+template <int NCV>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GN2Params p) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // [G] mean, [G] rstd, [C] scale, [C] shift
-    float* gmean = sm; float* grstd = sm + p.G; float* sc = sm + 2 * p.G; float* sh = sc + p.C;
+    __shared__ float gmean[256], grstd[256];
     const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     if (tid < p.G) {
         float na = 0.f, ma = 0.f, qa = 0.f;
@@ -218,34 +234,49 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GN2Params p) {
         grstd[tid] = rsqrtf(qa / na + p.eps);
     }
     __syncthreads();
-    const int cpg = p.C / p.G;
-    for (int c = tid; c < p.C; c += 256) {
-        const int g = c / cpg;
-        const float s = grstd[g] * p.gamma[c];
-        sc[c] = s; sh[c] = p.beta[c] - gmean[g] * s;
-    }
-    __syncthreads();
-    const int px0 = chunk * p.PCH;
-    const int npx = min(p.PCH, p.HW - px0);
-    const int C8 = p.C / 8;
-    const bf16_t* xb = p.X + ((long)b * p.HW + px0) * p.ldx;
-    bf16_t* yb = p.Y + ((long)b * p.HW + px0) * p.ldy;
-    for (int i = tid; i < npx * C8; i += 256) {
-        const int px = i / C8, cc = i - px * C8;
-        Frag8 f; f.u = *(const uint4*)(xb + (long)px * p.ldx + cc * 8);
-        const float4 s0 = *(const float4*)(sc + cc * 8), s1 = *(const float4*)(sc + cc * 8 + 4);
-        const float4 h0 = *(const float4*)(sh + cc * 8), h1 = *(const float4*)(sh + cc * 8 + 4);
-        const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-        float o[8];
+    const int C8 = p.C / 8, cpg = p.C / p.G;
+    const int rows = gn2_rows(C8);
+    const int r0 = NCV == 1 ? tid / C8 : 0;
+    if (NCV == 1 && r0 >= rows) return;
+    float sc[NCV][8], sh[NCV][8];
+    int cc[NCV];
+#pragma unroll
+    for (int k = 0; k < NCV; ++k) {
+        cc[k] = NCV == 1 ? tid - r0 * C8 : tid + 256 * k;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float y = bf2f(f.h[e]) * sv[e] + hv[e];
-            if (p.silu) y = silu_f(y);
-            o[e] = y;
+            const int c = cc[k] * 8 + e;
+            if (cc[k] < C8) { const int g = c / cpg; const float s = grstd[g] * p.gamma[c]; sc[k][e] = s; sh[k][e] = p.beta[c] - gmean[g] * s; }
+            else { sc[k][e] = 0.f; sh[k][e] = 0.f; }
         }
-        uint4 u; u.x = pack2bf(o[0], o[1]); u.y = pack2bf(o[2], o[3]); u.z = pack2bf(o[4], o[5]); u.w = pack2bf(o[6], o[7]);
-        *(uint4*)(yb + (long)px * p.ldy + cc * 8) = u;
+    }
+    const int px0 = chunk * p.PCH;
+    const int npx = min(p.PCH, p.HW - px0);
+    const bf16_t* xb = p.X + ((long)b * p.HW + px0) * p.ldx;
+    bf16_t* yb = p.Y + ((long)b * p.HW + px0) * p.ldy;
+    const int ldx = (int)p.ldx, ldy = (int)p.ldy;
+    for (int px = r0; px < npx; px += rows * GN2_U) {
+        Frag8 f[GN2_U][NCV];
+#pragma unroll
+        for (int u = 0; u < GN2_U; ++u)
+#pragma unroll
+            for (int k = 0; k < NCV; ++k)
+                if (px + u * rows < npx && cc[k] < C8) f[u][k].u = *(const uint4*)(xb + (long)(px + u * rows) * ldx + cc[k] * 8);
+#pragma unroll
+        for (int u = 0; u < GN2_U; ++u)
+#pragma unroll
+            for (int k = 0; k < NCV; ++k)
+                if (px + u * rows < npx && cc[k] < C8) {
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float y = __builtin_fmaf(bf2f(f[u][k].h[e]), sc[k][e], sh[k][e]);
+                        if (p.silu) y = silu_f(y);
+                        o[e] = y;
+                    }
+                    uint4 w; w.x = pack2bf(o[0], o[1]); w.y = pack2bf(o[2], o[3]); w.z = pack2bf(o[4], o[5]); w.w = pack2bf(o[6], o[7]);
+                    *(uint4*)(yb + (long)(px + u * rows) * ldy + cc[k] * 8) = w;
+                }
     }
 }
 
@@ -254,48 +285,74 @@ struct LNParams {
     int M, C; long ldx, ldy; float eps;
 };
 
-// one wave per row; C % 8 == 0, C <= 8 * 64 * MAXV
-template <int MAXV>
+// RPW rows per wave, processed together so that RPW * MAXV 16-byte loads per lane are in flight (one row per wave leaves the kernel
+// latency-bound at ~60 % of the streaming rate); C % 8 == 0, C <= 8 * 64 * MAXV.  Two-pass statistics in registers, shuffle reductions.
+template <int MAXV, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(LNParams p) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.M) return;
-    const bf16_t* x = p.X + (long)row * p.ldx;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= p.M) return;
     const int nv = p.C / 8;
-    float v[MAXV][8];
-    float s1 = 0.f;
+    float v[RPW][MAXV][8];
+    float s1[RPW];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        int c = lane + 64 * i;
-        if (c < nv) {
-            Frag8 f; f.u = *(const uint4*)(x + c * 8);
+    for (int r = 0; r < RPW; ++r) {
+        s1[r] = 0.f;
+        const bf16_t* x = p.X + (long)(row0 + r) * p.ldx;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { v[i][e] = bf2f(f.h[e]); s1 += v[i][e]; }
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            Frag8 f; f.u = make_uint4(0, 0, 0, 0);
+            if (c < nv && row0 + r < p.M) f.u = *(const uint4*)(x + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[r][i][e] = bf2f(f.h[e]);
         }
     }
-    const float mean = wave_sum(s1) / (float)p.C;
-    float s2 = 0.f;
+    float g[MAXV][8], bt[MAXV][8];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        int c = lane + 64 * i;
-        if (c < nv) {
+        const int c = lane + 64 * i;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { float dlt = v[i][e] - mean; s2 += dlt * dlt; }
-        }
+        for (int e = 0; e < 8; ++e) { g[i][e] = c < nv ? p.gamma[c * 8 + e] : 0.f; bt[i][e] = c < nv ? p.beta[c * 8 + e] : 0.f; }
     }
-    const float rstd = rsqrtf(wave_sum(s2) / (float)p.C + p.eps);
-    bf16_t* y = p.Y + (long)row * p.ldy;
+    const float invC = 1.0f / (float)p.C;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        int c = lane + 64 * i;
-        if (c < nv) {
-            Frag8 f;
+    for (int r = 0; r < RPW; ++r)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float o = (v[i][e] - mean) * rstd * p.gamma[c * 8 + e] + p.beta[c * 8 + e];
-                f.h[e] = f2bf(o);
+        for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s1[r] += v[r][i][e];           // lanes / vectors past C hold zeros
+    float mean[RPW], rstd[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) mean[r] = wave_sum(s1[r]) * invC;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float dlt = v[r][i][e] - mean[r]; s2 = __builtin_fmaf(dlt, dlt, s2); }
             }
-            *(uint4*)(y + c * 8) = f.u;
+        }
+        rstd[r] = s2;
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) rstd[r] = rsqrtf(wave_sum(rstd[r]) * invC + p.eps);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        if (row0 + r >= p.M) break;
+        bf16_t* y = p.Y + (long)(row0 + r) * p.ldy;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                Frag8 f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f.h[e] = f2bf((v[r][i][e] - mean[r]) * rstd[r] * g[i][e] + bt[i][e]);
+                *(uint4*)(y + c * 8) = f.u;
+            }
         }
     }
 }
@@ -317,20 +374,28 @@ extern "C" int mdx_groupnorm_bf16(const MdxGroupNormDesc* d, void* stream) {
     // big maps: two-stage coalesced path (needs 16-byte rows, even cpg, G | 256, a partials workspace)
     static const int two_stage = [] { const char* e = getenv("MDX_GN_TWO_STAGE"); return e ? atoi(e) : 1; }();
     const long elems = (long)p.HW * p.C;
-    if (two_stage && d->ws && elems >= 32768 && p.C % 8 == 0 && p.C <= GN2_TILE && cpg % 2 == 0 && 256 % p.G == 0 && p.ldx % 8 == 0 && p.ldy % 8 == 0 &&
+    if (two_stage && d->ws && elems >= 32768 && p.C % 8 == 0 && p.C <= GN2_MAXC && p.G <= 256 && p.ldx % 8 == 0 && p.ldy % 8 == 0 &&
         ((uintptr_t)p.X & 15) == 0 && ((uintptr_t)p.Y & 15) == 0) {
         GN2Params q;
         q.X = p.X; q.Y = p.Y; q.gamma = p.gamma; q.beta = p.beta; q.part = (float*)d->ws;
         q.B = p.B; q.HW = p.HW; q.C = p.C; q.G = p.G; q.ldx = p.ldx; q.ldy = p.ldy; q.eps = p.eps; q.silu = p.silu;
-        q.PCH = GN2_TILE / p.C; if (q.PCH > p.HW) q.PCH = p.HW;
+        // chunks: about 4096 workgroups in the grid, at least GN2_U passes of the workgroup's rows each
+        const int C8 = p.C / 8, rows = C8 >= 256 ? 1 : 256 / C8;
+        int target = (int)(4096 / p.B); if (target < 1) target = 1;
+        int pch = (p.HW + target - 1) / target;
+        if (pch < rows * GN2_U) pch = rows * GN2_U;
+        pch = (pch + rows - 1) / rows * rows;
+        if (pch > p.HW) pch = p.HW;
+        q.PCH = pch;
         q.nchunk = (p.HW + q.PCH - 1) / q.PCH;
         if ((long)p.B * q.nchunk * p.G * 3 * (long)sizeof(float) <= d->ws_bytes) {
             dim3 grid2(q.nchunk, p.B);
-            hipLaunchKernelGGL(gn_stats_kernel, grid2, dim3(256), 0, st, q);
+            if (C8 > 256) hipLaunchKernelGGL(gn_stats_kernel<2>, grid2, dim3(256), 0, st, q);
+            else hipLaunchKernelGGL(gn_stats_kernel<1>, grid2, dim3(256), 0, st, q);
             int rc = check_launch("gn_stats_kernel", false);
             if (rc) return rc;
-            size_t sm = (size_t)(2 * p.G + 2 * p.C) * sizeof(float);
-            hipLaunchKernelGGL(gn_apply_kernel, grid2, dim3(256), sm, st, q);
+            if (C8 > 256) hipLaunchKernelGGL(gn_apply_kernel<2>, grid2, dim3(256), 0, st, q);
+            else hipLaunchKernelGGL(gn_apply_kernel<1>, grid2, dim3(256), 0, st, q);
             return check_launch("gn_stats_kernel+gn_apply_kernel");
         }
     }
@@ -390,10 +455,11 @@ extern "C" int mdx_layernorm_bf16(const MdxLayerNormDesc* d, void* stream) {
     LNParams p;
     p.X = (const bf16_t*)d->X; p.Y = (bf16_t*)d->Y; p.gamma = d->gamma; p.beta = d->beta;
     p.M = (int)d->M; p.C = (int)d->C; p.ldx = d->ldx; p.ldy = d->ldy; p.eps = (float)d->eps;
-    dim3 grid((p.M + 3) / 4);
+    const int rpw = p.C <= 512 ? 4 : (p.C <= 1024 ? 2 : 1);
+    dim3 grid((p.M + 4 * rpw - 1) / (4 * rpw));
     hipStream_t st = (hipStream_t)stream;
-    if (p.C <= 512) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, st, p);
-    else if (p.C <= 1024) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, p);
+    if (p.C <= 512) hipLaunchKernelGGL((layernorm_kernel<1, 4>), grid, dim3(256), 0, st, p);
+    else if (p.C <= 1024) hipLaunchKernelGGL((layernorm_kernel<2, 2>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((layernorm_kernel<4, 1>), grid, dim3(256), 0, st, p);
     return check_launch("layernorm_kernel");
 }

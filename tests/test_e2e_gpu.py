@@ -219,6 +219,24 @@ def test_vae_decode_matches_diffusers_golden(dev):
     assert img.shape == (2, 3, 56, 104) and e < 3e-2
 
 
+def test_vae_decode_real_size_sd15(dev):
+    """The SD-1.5 AutoencoderKL decoder (VAE_SD15_CONFIG: 128/256/512/512 channels, 83.7 M parameters) on one scene's 6 x (4, 28, 50)
+    latents -> 6 x (3, 224, 400) images, HIP op program vs the CPU oracle's restatement of diffusers' decode (random weights)."""
+    from magicdrive_amd.networks.autoencoder_kl import AutoencoderKL
+    vcfg = spec.VAE_SD15_CONFIG
+    vae = AutoencoderKL.from_config(vcfg, 11).to(dev)
+    z = torch.randn(6, 4, 28, 50, generator=torch.Generator().manual_seed(2)) * 0.8
+    img = vae.decode(z.to(dev)).sample
+    torch.cuda.synchronize()
+    sd = spec.random_state_dict(spec.vae_decoder_param_shapes(vcfg), 11)
+    with torch.no_grad():
+        ref = D.vae_decode(sd, vcfg, z)
+    assert img.shape == (6, 3, 224, 400)
+    e = max(rel_l2(img[v], ref[v]) for v in range(6))
+    print(f"[SD-1.5 VAE decode, 6 views 224x400 vs oracle] worst per-view rel L2 {e:.4f}")
+    assert e < 3e-2
+
+
 def test_pipeline_images_through_hip_vae(dev):
     """output_type="np" / "pil" with the HIP AutoencoderKL attached: the whole reference __call__ contract incl. decode_latents
     (pipeline_bev_controlnet.py:100-112, :466-498) runs on libmdx; images = clamp(decode(latents / 0.18215) / 2 + 0.5)."""

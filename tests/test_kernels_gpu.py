@@ -306,9 +306,14 @@ def test_attention_crossview_two_sources(dev, b, heads, T, d):
 
 
 @pytest.mark.parametrize("B,HW,Cc,G,silu,eps", [(2, 1400, 320, 32, True, 1e-5), (2, 350, 1920, 32, True, 1e-5), (3, 91, 1280, 32, False, 1e-6),
-                                                   (2, 100, 32, 32, True, 1e-5), (1, 28, 2560, 32, True, 1e-5), (2, 64, 64, 8, False, 1e-5)])
+                                                   (2, 100, 32, 32, True, 1e-5), (1, 28, 2560, 32, True, 1e-5), (2, 64, 64, 8, False, 1e-5),
+                                                   # the streaming two-stage kernels: 960-channel concat input, many images (chunking
+                                                   # by batch), 2560 channels (two channel vectors per thread), chunk tails (HW = 1399)
+                                                   (2, 1400, 960, 32, True, 1e-5), (40, 350, 640, 32, True, 1e-5), (7, 91, 2560, 32, True, 1e-5),
+                                                   (3, 1399, 320, 32, False, 1e-6), (600, 28, 1280, 32, True, 1e-5)])
 def test_groupnorm(dev, B, HW, Cc, G, silu, eps):
     x = (rnd(B, HW, Cc, seed=1).float() * 2 + 0.7).to(BF)
+    if Cc == 960: x = (x.float() + 6.0).to(BF)                      # |mean| >> std: the pivot keeps the variance conditioned
     gam = rnd(Cc, seed=2, dtype=torch.float32); bet = rnd(Cc, seed=3, dtype=torch.float32)
     y = torch.zeros_like(x)
     O.run_ops([O.GroupNorm(x, y, gam, bet, groups=G, eps=eps, silu=silu)])
@@ -332,7 +337,7 @@ def test_groupnorm_channel_slice_view(dev):
     close(y, ref, name="groupnorm view")
 
 
-@pytest.mark.parametrize("M,Cc", [(8400, 320), (2100, 640), (546, 1280), (37, 64), (5, 2048)])
+@pytest.mark.parametrize("M,Cc", [(8400, 320), (2100, 640), (546, 1280), (37, 64), (5, 2048), (8403, 320), (2101, 640), (1, 320)])
 def test_layernorm(dev, M, Cc):
     x = (rnd(M, Cc, seed=1).float() * 3 - 0.5).to(BF)
     gam = rnd(Cc, seed=2, dtype=torch.float32); bet = rnd(Cc, seed=3, dtype=torch.float32)
