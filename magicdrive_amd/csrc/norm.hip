@@ -141,9 +141,10 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_kernel(GNParams p) {
 // Two-stage GroupNorm for the big (HBM/Infinity-Cache-bound) feature maps: pure streaming, every global access a full 16-byte-per-lane
 // coalesced row segment (the one-workgroup-per-group kernel above reads 20-byte pieces at a 640-byte stride when C/G = 10), several
 // loads in flight per lane, no LDS staging.  Deterministic: no atomics, partials combined in a fixed order (Chan).
-// Thread layout of both stages: the workgroup covers ROWS = 256 / (C/8) pixel rows at a time, thread (r, cc) owns the SAME 8 channels
-// cc*8.. of rows r, r + ROWS, ... of its chunk — so the per-channel state (sums in stage 1, scale / shift in stage 2) lives in
-// registers.  C/8 > 256 (C = 2560): a thread owns NCV = 2 channel vectors.
+// Thread layout of both stages: the workgroup is ROWS x (C/8) threads (ROWS = 256 / (C/8), at least 1: 160 - 320 threads; measured:
+// 320-thread workgroups with more rows are slower), thread
+// (r, cc) owns the SAME 8 channels cc*8.. of pixel rows r, r + ROWS, ... of its chunk — so the per-channel state (sums in stage 1,
+// scale / shift in stage 2) lives in registers.  C/8 > 320 (C > 2560): 320 threads, a thread owns NCV = 2 channel vectors.
 //   stage 1  gn_stats_kernel : grid (chunks, B); per-channel sums of (x - pivot_g) and (x - pivot_g)^2 in registers (pivot_g = the
 //            group's first element of the chunk: keeps E[d^2] - E[d]^2 well conditioned in fp32), reduced over rows and over the
 //            group's channels through LDS in a fixed order -> (n, mean, M2) per (b, chunk, g)
@@ -153,14 +154,15 @@ struct GN2Params {
     int B, HW, C, G, PCH, nchunk; long ldx, ldy; float eps; int silu;
 };
 
-constexpr int GN2_MAXC = 4096;    // channels (LDS: 2 x rows x C floats in stage 1 with rows x C <= 2048 .. see gn2_rows)
+constexpr int GN2_NT = 320;       // most threads per workgroup
+constexpr int GN2_MAXC = 5120;    // channels (stage 1 LDS: 2 x rows x C floats, rows x C <= 2560 NCV)
 constexpr int GN2_U = 4;          // pixel rows in flight per thread
 
-__device__ __forceinline__ int gn2_rows(int C8) { return C8 >= 256 ? 1 : 256 / C8; }
+__host__ __device__ __forceinline__ int gn2_rows(int C8) { return C8 >= 256 ? 1 : 256 / C8; }
 
 template <int NCV>
-__global__ __launch_bounds__(256) void gn_stats_kernel(GN2Params p) {
-    __shared__ float ls1[256 * 8 * NCV], ls2[256 * 8 * NCV];       // [row][C] sums (rows * C <= 2048 * NCV)
+__global__ __launch_bounds__(GN2_NT) void gn_stats_kernel(GN2Params p) {
+    __shared__ float ls1[GN2_NT * 8 * NCV], ls2[GN2_NT * 8 * NCV];       // [row][C] sums (rows * C <= 2560 * NCV)
     __shared__ float lpiv[256];                                    // per group pivot (G <= 256)
     const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int px0 = chunk * p.PCH;
@@ -176,27 +178,32 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GN2Params p) {
     int cc[NCV];
 #pragma unroll
     for (int k = 0; k < NCV; ++k) {
-        cc[k] = NCV == 1 ? tid - r0 * C8 : tid + 256 * k;
+        cc[k] = NCV == 1 ? tid - r0 * C8 : tid + GN2_NT * k;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s1[k][e] = 0.f; s2[k][e] = 0.f; pv[k][e] = (cc[k] < C8) ? lpiv[(cc[k] * 8 + e) / cpg] : 0.f; }
     }
     if (active) {
         const int ldx = (int)p.ldx;
+        int ccl[NCV];
+#pragma unroll
+        for (int k = 0; k < NCV; ++k) ccl[k] = cc[k] < C8 ? cc[k] : C8 - 1;
         for (int px = r0; px < npx; px += rows * GN2_U) {
+            // unconditional loads from clamped addresses, masked on use (a guarded load becomes its own branch with a full wait inside)
             Frag8 f[GN2_U][NCV];
 #pragma unroll
+            for (int u = 0; u < GN2_U; ++u) {
+                const int pxu = px + u * rows < npx ? px + u * rows : npx - 1;
+#pragma unroll
+                for (int k = 0; k < NCV; ++k) f[u][k].u = *(const uint4*)(xb + (long)pxu * ldx + ccl[k] * 8);
+            }
+#pragma unroll
             for (int u = 0; u < GN2_U; ++u)
 #pragma unroll
-                for (int k = 0; k < NCV; ++k)
-                    if (px + u * rows < npx && cc[k] < C8) f[u][k].u = *(const uint4*)(xb + (long)(px + u * rows) * ldx + cc[k] * 8);
+                for (int k = 0; k < NCV; ++k) {
+                    const float m = (px + u * rows < npx && cc[k] < C8) ? 1.f : 0.f;
 #pragma unroll
-            for (int u = 0; u < GN2_U; ++u)
-#pragma unroll
-                for (int k = 0; k < NCV; ++k)
-                    if (px + u * rows < npx && cc[k] < C8) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) { const float d = bf2f(f[u][k].h[e]) - pv[k][e]; s1[k][e] += d; s2[k][e] = __builtin_fmaf(d, d, s2[k][e]); }
-                    }
+                    for (int e = 0; e < 8; ++e) { const float d = (bf2f(f[u][k].h[e]) - pv[k][e]) * m; s1[k][e] += d; s2[k][e] = __builtin_fmaf(d, d, s2[k][e]); }
+                }
         }
 #pragma unroll
         for (int k = 0; k < NCV; ++k)
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GN2Params p) {
 }
 
 template <int NCV>
-__global__ __launch_bounds__(256) void gn_apply_kernel(GN2Params p) {
+__global__ __launch_bounds__(GN2_NT) void gn_apply_kernel(GN2Params p) {
     __shared__ float gmean[256], grstd[256];
     const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     if (tid < p.G) {
@@ -239,15 +246,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GN2Params p) {
     const int r0 = NCV == 1 ? tid / C8 : 0;
     if (NCV == 1 && r0 >= rows) return;
     float sc[NCV][8], sh[NCV][8];
-    int cc[NCV];
+    int cc[NCV], ccl[NCV];
 #pragma unroll
     for (int k = 0; k < NCV; ++k) {
-        cc[k] = NCV == 1 ? tid - r0 * C8 : tid + 256 * k;
+        cc[k] = NCV == 1 ? tid - r0 * C8 : tid + GN2_NT * k;
+        ccl[k] = cc[k] < C8 ? cc[k] : C8 - 1;
+        const float4 g0 = *(const float4*)(p.gamma + ccl[k] * 8), g1 = *(const float4*)(p.gamma + ccl[k] * 8 + 4);
+        const float4 b0 = *(const float4*)(p.beta + ccl[k] * 8), b1 = *(const float4*)(p.beta + ccl[k] * 8 + 4);
+        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int c = cc[k] * 8 + e;
-            if (cc[k] < C8) { const int g = c / cpg; const float s = grstd[g] * p.gamma[c]; sc[k][e] = s; sh[k][e] = p.beta[c] - gmean[g] * s; }
-            else { sc[k][e] = 0.f; sh[k][e] = 0.f; }
+            const int g = (ccl[k] * 8 + e) / cpg;
+            const float s = grstd[g] * gv[e];
+            sc[k][e] = s; sh[k][e] = bv[e] - gmean[g] * s;
         }
     }
     const int px0 = chunk * p.PCH;
@@ -258,25 +269,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GN2Params p) {
     for (int px = r0; px < npx; px += rows * GN2_U) {
         Frag8 f[GN2_U][NCV];
 #pragma unroll
+        for (int u = 0; u < GN2_U; ++u) {
+            const int pxu = px + u * rows < npx ? px + u * rows : npx - 1;
+#pragma unroll
+            for (int k = 0; k < NCV; ++k) f[u][k].u = *(const uint4*)(xb + (long)pxu * ldx + ccl[k] * 8);
+        }
+#pragma unroll
         for (int u = 0; u < GN2_U; ++u)
 #pragma unroll
-            for (int k = 0; k < NCV; ++k)
-                if (px + u * rows < npx && cc[k] < C8) f[u][k].u = *(const uint4*)(xb + (long)(px + u * rows) * ldx + cc[k] * 8);
+            for (int k = 0; k < NCV; ++k) {
+                float o[8];
 #pragma unroll
-        for (int u = 0; u < GN2_U; ++u)
-#pragma unroll
-            for (int k = 0; k < NCV; ++k)
-                if (px + u * rows < npx && cc[k] < C8) {
-                    float o[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float y = __builtin_fmaf(bf2f(f[u][k].h[e]), sc[k][e], sh[k][e]);
-                        if (p.silu) y = silu_f(y);
-                        o[e] = y;
-                    }
-                    uint4 w; w.x = pack2bf(o[0], o[1]); w.y = pack2bf(o[2], o[3]); w.z = pack2bf(o[4], o[5]); w.w = pack2bf(o[6], o[7]);
-                    *(uint4*)(yb + (long)(px + u * rows) * ldy + cc[k] * 8) = w;
+                for (int e = 0; e < 8; ++e) {
+                    float y = __builtin_fmaf(bf2f(f[u][k].h[e]), sc[k][e], sh[k][e]);
+                    if (p.silu) y = silu_f(y);
+                    o[e] = y;
                 }
+                uint4 w; w.x = pack2bf(o[0], o[1]); w.y = pack2bf(o[2], o[3]); w.z = pack2bf(o[4], o[5]); w.w = pack2bf(o[6], o[7]);
+                if (px + u * rows < npx && cc[k] < C8) *(uint4*)(yb + (long)(px + u * rows) * ldy + cc[k] * 8) = w;
+            }
     }
 }
 
@@ -293,27 +304,39 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LNParams p) {
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
     if (row0 >= p.M) return;
     const int nv = p.C / 8;
+    // every load is unconditional (clamped address, value masked afterwards): as `if (valid) load` the compiler wraps each load in its own
+    // exec-masked branch with a full wait inside, i.e. one memory latency after the other
     float v[RPW][MAXV][8];
     float s1[RPW];
+    Frag8 f[RPW][MAXV];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-        s1[r] = 0.f;
-        const bf16_t* x = p.X + (long)(row0 + r) * p.ldx;
+        const int row = row0 + r < p.M ? row0 + r : p.M - 1;
+        const bf16_t* x = p.X + (long)row * p.ldx;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c = lane + 64 * i;
-            Frag8 f; f.u = make_uint4(0, 0, 0, 0);
-            if (c < nv && row0 + r < p.M) f.u = *(const uint4*)(x + c * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[r][i][e] = bf2f(f.h[e]);
+            f[r][i].u = *(const uint4*)(x + (c < nv ? c : 0) * 8);
         }
     }
     float g[MAXV][8], bt[MAXV][8];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int c = lane + 64 * i;
+        const int c = lane + 64 * i, cl = c < nv ? c : 0;
+        const float4 g0 = *(const float4*)(p.gamma + cl * 8), g1 = *(const float4*)(p.gamma + cl * 8 + 4);
+        const float4 b0 = *(const float4*)(p.beta + cl * 8), b1 = *(const float4*)(p.beta + cl * 8 + 4);
+        g[i][0] = g0.x; g[i][1] = g0.y; g[i][2] = g0.z; g[i][3] = g0.w; g[i][4] = g1.x; g[i][5] = g1.y; g[i][6] = g1.z; g[i][7] = g1.w;
+        bt[i][0] = b0.x; bt[i][1] = b0.y; bt[i][2] = b0.z; bt[i][3] = b0.w; bt[i][4] = b1.x; bt[i][5] = b1.y; bt[i][6] = b1.z; bt[i][7] = b1.w;
+    }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { g[i][e] = c < nv ? p.gamma[c * 8 + e] : 0.f; bt[i][e] = c < nv ? p.beta[c * 8 + e] : 0.f; }
+    for (int r = 0; r < RPW; ++r) {
+        s1[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const bool ok = lane + 64 * i < nv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[r][i][e] = ok ? bf2f(f[r][i].h[e]) : 0.f;
+        }
     }
     const float invC = 1.0f / (float)p.C;
 #pragma unroll
@@ -371,16 +394,17 @@ extern "C" int mdx_groupnorm_bf16(const MdxGroupNormDesc* d, void* stream) {
     p.eps = (float)d->eps; p.silu = (int)d->silu;
     const int cpg = p.C / p.G;
     hipStream_t st = (hipStream_t)stream;
-    // big maps: two-stage coalesced path (needs 16-byte rows, even cpg, G | 256, a partials workspace)
+    // big maps: two-stage streaming path (needs 16-byte rows, G <= 240 = the smallest workgroup, a partials workspace)
     static const int two_stage = [] { const char* e = getenv("MDX_GN_TWO_STAGE"); return e ? atoi(e) : 1; }();
     const long elems = (long)p.HW * p.C;
-    if (two_stage && d->ws && elems >= 32768 && p.C % 8 == 0 && p.C <= GN2_MAXC && p.G <= 256 && p.ldx % 8 == 0 && p.ldy % 8 == 0 &&
+    if (two_stage && d->ws && elems >= 32768 && p.C % 8 == 0 && p.C <= GN2_MAXC && p.G <= 240 && p.ldx % 8 == 0 && p.ldy % 8 == 0 &&
         ((uintptr_t)p.X & 15) == 0 && ((uintptr_t)p.Y & 15) == 0) {
         GN2Params q;
         q.X = p.X; q.Y = p.Y; q.gamma = p.gamma; q.beta = p.beta; q.part = (float*)d->ws;
         q.B = p.B; q.HW = p.HW; q.C = p.C; q.G = p.G; q.ldx = p.ldx; q.ldy = p.ldy; q.eps = p.eps; q.silu = p.silu;
         // chunks: about 4096 workgroups in the grid, at least GN2_U passes of the workgroup's rows each
-        const int C8 = p.C / 8, rows = C8 >= 256 ? 1 : 256 / C8;
+        const int C8 = p.C / 8, rows = gn2_rows(C8);
+        const int nt = C8 > GN2_NT ? GN2_NT : rows * C8;
         int target = (int)(4096 / p.B); if (target < 1) target = 1;
         int pch = (p.HW + target - 1) / target;
         if (pch < rows * GN2_U) pch = rows * GN2_U;
@@ -390,12 +414,12 @@ extern "C" int mdx_groupnorm_bf16(const MdxGroupNormDesc* d, void* stream) {
         q.nchunk = (p.HW + q.PCH - 1) / q.PCH;
         if ((long)p.B * q.nchunk * p.G * 3 * (long)sizeof(float) <= d->ws_bytes) {
             dim3 grid2(q.nchunk, p.B);
-            if (C8 > 256) hipLaunchKernelGGL(gn_stats_kernel<2>, grid2, dim3(256), 0, st, q);
-            else hipLaunchKernelGGL(gn_stats_kernel<1>, grid2, dim3(256), 0, st, q);
+            if (C8 > GN2_NT) hipLaunchKernelGGL(gn_stats_kernel<2>, grid2, dim3(nt), 0, st, q);
+            else hipLaunchKernelGGL(gn_stats_kernel<1>, grid2, dim3(nt), 0, st, q);
             int rc = check_launch("gn_stats_kernel", false);
             if (rc) return rc;
-            if (C8 > 256) hipLaunchKernelGGL(gn_apply_kernel<2>, grid2, dim3(256), 0, st, q);
-            else hipLaunchKernelGGL(gn_apply_kernel<1>, grid2, dim3(256), 0, st, q);
+            if (C8 > GN2_NT) hipLaunchKernelGGL(gn_apply_kernel<2>, grid2, dim3(nt), 0, st, q);
+            else hipLaunchKernelGGL(gn_apply_kernel<1>, grid2, dim3(nt), 0, st, q);
             return check_launch("gn_stats_kernel+gn_apply_kernel");
         }
     }
