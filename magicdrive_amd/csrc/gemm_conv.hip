@@ -516,6 +516,24 @@ static int check_common(int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_
     return MDX_OK;
 }
 
+// One XL launch for a batch-flattened GEMM (see mdx_gemm_bf16); MDX_EUNSUPPORTED when the XL kernel does not take the shape.
+static int launch_gemm_flat(const mdx::GCParams& q, hipStream_t st) {
+    using namespace mdx;
+    static const int xl_mode = [] { const char* e = getenv("MDX_GEMM_XL"); return e ? atoi(e) : 1; }();
+    if (xl_mode <= 0) return MDX_EUNSUPPORTED;
+    double best = 1e300; int bn_best = 0;
+    for (int bn : {320, 256, 160}) {
+        if (!xl_supported(q, false, bn)) continue;
+        const long t = (long)((q.M + 255) / 256) * ((q.N + bn - 1) / bn);
+        if (t < 128) continue;
+        const double a = bn == 320 ? 23.7 : bn == 256 ? 13.4 : 16.6, b = bn == 320 ? 1.896 : bn == 256 ? 1.565 : 1.116;
+        const double c = (double)((t + 255) / 256) * (a + b * q.K / 64.0);
+        if (c < best) { best = c; bn_best = bn; }
+    }
+    if (!bn_best) return MDX_EUNSUPPORTED;
+    return launch_gemm_xl(q, false, bn_best, st);
+}
+
 extern "C" int mdx_gemm_bf16(const MdxGemmDesc* d, void* stream) {
     if (!d || !d->A || !d->W || !d->C) return set_error(MDX_EINVAL, "mdx_gemm_bf16: null operand");
     int rc = check_common(d->K, d->lda, d->ldw, d->ldc, d->ldr, d->A, d->W, d->C, d->N);
@@ -544,6 +562,17 @@ extern "C" int mdx_gemm_bf16(const MdxGemmDesc* d, void* stream) {
         { GCParams q = p; const long nout = d->vt_from;      // wide-path check of the C part
           q.wide = (nout % 8) == 0 && (p.ldc % 8) == 0 && (((uintptr_t)p.C) & 15) == 0;
           return launch_gemm_ws(q, (hipStream_t)stream); }
+    }
+    // Batched GEMM with a shared A and W batches that are rows of ONE matrix (the per-view V^T projections at levels 1 and 2: 384
+    // products of 640 x 350 x 640): run it as a single GEMM over all batches' columns on the XL main loop, the epilogue scattering
+    // each column to its batch (GCParams.col_split).  MDX_GEMM_FLATTEN=0 keeps the per-batch launches.
+    static const int flatten = [] { const char* e = getenv("MDX_GEMM_FLATTEN"); return e ? atoi(e) : 1; }();
+    if (flatten && p.batch > 1 && p.sA == 0 && p.sW == (long)p.N * p.ldw && !p.bias && !p.temb && !p.R && !p.epi && !p.c_f32 && p.splitk <= 1 &&
+        (long)p.batch * p.N < 0x7fffff00L && ((long)p.batch * p.N) % 4 == 0) {
+        GCParams q = p;
+        q.col_split = p.N; q.N = p.batch * p.N; q.batch = 1; q.sW = 0; q.wide = 0;
+        int rcq = launch_gemm_flat(q, (hipStream_t)stream);
+        if (rcq != MDX_EUNSUPPORTED) return rcq;
     }
     return launch_gemm_conv(p, false, (hipStream_t)stream);
 }

@@ -28,6 +28,10 @@ struct GCParams {
     int wide;                     // epilogue may use 16-byte global accesses for C / R (alignment + N % 8 checked by the launcher)
     // fused q/k/v projection (MdxGemmDesc.Vt): raw columns >= vt_from are stored transposed to Vt[m / vt_T][n - vt_from][m % vt_T]
     bf16_t* Vt; int vt_from, vt_T; long vt_ld, vt_stride;
+    // batch-flattened GEMM (gemm_xl.hip only): N counts the columns of ALL batches (W is one [batch * col_split][K] matrix, A is shared);
+    // output column n lands in batch n / col_split at column n % col_split: C + (n / col_split) * sC + m * ldc + n % col_split.
+    // 0 = off.  Used for the level-1/2 V^T projections: V^T[b][c][t] = sum_k Wv[c][k] X[b][t][k] as ONE GEMM over all views.
+    int col_split;
     int dbg;                      // debug knobs of gemm_pp.hip (MDX_PP_DBG): 1 skip LDS stores, 2 skip global loads, 4 skip MFMAs
 };
 

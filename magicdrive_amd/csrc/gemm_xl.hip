@@ -586,7 +586,35 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
         }
         __syncthreads();
         const int mh = m0 + hh * HROWS;
-        if (p.wide) {
+        if (p.col_split) {
+            // batch-flattened output: a tile's columns are tokens of consecutive images; column n -> image n / cs, token n % cs.
+            // 4-byte stores of token pairs when cs is even (pairs never straddle an image, addresses stay 4-byte aligned), single
+            // elements otherwise; a wave instruction still covers contiguous row segments.  No bias / residual in this mode.
+            const int cs = p.col_split;
+            const bool pairs = (cs & 1) == 0;
+            const int cpr = BNo >> 1;
+            const int total = HROWS * cpr;
+            const int bfirst = n0 / cs;
+            const int tfirst = n0 - bfirst * cs;
+#pragma unroll 1
+            for (int idx = tid; idx < total; idx += NTH) {
+                const int row = idx / cpr, c2 = (idx - row * cpr) * 2;
+                if (mh + row >= p.M || n0 + c2 >= p.N) continue;
+                const unsigned v = *(const unsigned*)(Cs + row * CSTR + c2);
+                int b = bfirst, t = tfirst + c2;
+                while (t >= cs) { t -= cs; ++b; }
+                bf16_t* dst = Cg + (long)b * p.sC + (long)(mh + row) * p.ldc + t;
+                if (pairs) {
+                    *(unsigned*)dst = v;
+                } else {
+                    *dst = (bf16_t)(v & 0xffffu);
+                    if (n0 + c2 + 1 < p.N) {
+                        if (t + 1 < cs) dst[1] = (bf16_t)(v >> 16);
+                        else Cg[(long)(b + 1) * p.sC + (long)(mh + row) * p.ldc] = (bf16_t)(v >> 16);
+                    }
+                }
+            }
+        } else if (p.wide) {
             const int cpr = BNo >> 3;
             const int total = HROWS * cpr;
 #pragma unroll 1
@@ -670,6 +698,7 @@ static int launch_xl(const GCParams& p, hipStream_t st) {
 // Can the XL main loop run this problem at all?  (The caller's cost model decides whether it should.)  bn = 256 or 160.
 bool xl_supported(const GCParams& p, bool conv, int bn) {
     if (p.batch > 1 || p.splitk > 1 || p.c_f32 || (p.N % 4) || (p.K % 64) || p.Vt) return false;
+    if (p.col_split && (conv || p.bias || p.temb || p.R || p.epi || (p.sC & 1) || (p.ldc & 1) || p.col_split < 16)) return false;
     if (bn != 256 && bn != 160 && bn != 320) return false;
     if (p.epi == 1 && (bn != 256 || (p.N % 64))) return false;
     if (conv) {

@@ -144,6 +144,23 @@ def test_xl_conv(dev, B, H, W, Cin, Cout, stride, res, temb, expect):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
+# Batch-flattened GEMM (GCParams.col_split): the per-view V^T projections of levels 1 / 2 / mid as ONE XL launch whose epilogue
+# scatters token columns to their view.  Even tokens-per-view (4-byte pair stores), odd (element stores, pairs straddling views),
+# a ragged last tile; the kv pad columns of the destination must stay untouched.
+@pytest.mark.parametrize("Bt,T,Cc", [(60, 350, 640), (240, 91, 1280), (384, 28, 1280), (64, 351, 640)])
+def test_flattened_batched_vt(dev, Bt, T, Cc):
+    ldv = PK.round_up(T, 8)
+    X = rnd(Bt, T, Cc, seed=1); Wv = rnd(Cc, Cc, scale=Cc ** -0.5, seed=2)
+    Vt = torch.full((Bt, Cc, ldv), 7.0, dtype=BF, device=dev)
+    k = run_one(O.Gemm(Wv, X, Vt[:, :, :T]))
+    assert k.startswith("gemm_xl_kernel<256x") and k.endswith(",gemm>"), k
+    ref = torch.einsum("ck,btk->bct", Wv.float(), X.float())
+    close(Vt[:, :, :T], ref, name=f"flattened V^T {Bt}x{T}x{Cc} ({k})")
+    if ldv > T:
+        assert (Vt[:, :, T:].float() == 7.0).all(), "kv pad columns were written"
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
 # Forced routes.  The library reads its routing switches from the environment once per process, so each forced configuration runs
 # tests/route_worker.py in its own interpreter: every XL tile width on small ragged shapes (MDX_GEMM_XL=2: whenever supported), and
 # the round-1 main loops (gemm_pp, conv3x3, gemm_ws) with the XL kernel switched off, at the shapes the round-1 review listed.
