@@ -209,6 +209,24 @@ __global__ __launch_bounds__(256) void ew_vec8_kernel(EWParams p) {
     *(uint4*)yp = y.u;
 }
 
+// bf16 nearest resize, 8 channels (16 bytes) per thread: each output pixel row segment is one coalesced copy of its source pixel's
+// (the scalar path moved 2 bytes per lane: 1.04 ms for the 14x25 -> 28x50 x 640-channel upsample of 384 views, 7x its HBM time)
+__global__ __launch_bounds__(256) void ew_upsample_vec8_kernel(EWParams p) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c8 = p.C / 8;
+    const long total = (long)p.B * p.Ho * p.Wo * c8;
+    if (idx >= total) return;
+    const long pix = idx / c8;
+    const int c = (int)(idx - pix * c8) * 8;
+    const int ox = (int)(pix % p.Wo);
+    const long t = pix / p.Wo;
+    const int oy = (int)(t % p.Ho);
+    const int b = (int)(t / p.Ho);
+    const int iy = p.ymap[oy], ix = p.xmap[ox];
+    const uint4 v = *(const uint4*)((const bf16_t*)p.X + (((long)b * p.Hi + iy) * p.Wi + ix) * p.ldx + c);
+    *(uint4*)((bf16_t*)p.Y + pix * p.ldy + c) = v;
+}
+
 // ------------------------------------------------------------------------------------------
 // Fourier embedding / gather / timestep features / CFG + DDIM
 // ------------------------------------------------------------------------------------------
@@ -417,6 +435,11 @@ extern "C" int mdx_elementwise(const MdxEwDesc* d, void* stream) {
         long nv = p.M * (p.C / 8);
         hipLaunchKernelGGL(ew_vec8_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, p);
         return check_launch("ew_vec8_kernel");
+    }
+    if (p.kind == MDX_EW_UPSAMPLE && !p.x_f32 && !p.y_f32 && p.C % 8 == 0 && p.ldx % 8 == 0 && p.ldy % 8 == 0 &&
+        ((uintptr_t)p.X & 15) == 0 && ((uintptr_t)p.Y & 15) == 0) {
+        hipLaunchKernelGGL(ew_upsample_vec8_kernel, dim3((unsigned)((total / 8 + 255) / 256)), dim3(256), 0, st, p);
+        return check_launch("ew_upsample_vec8_kernel");
     }
     hipLaunchKernelGGL(ew_scalar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
     return check_launch("ew_scalar_kernel");

@@ -367,6 +367,11 @@ def test_elementwise_family(dev):
     O.run_ops([O.Upsample(u, up, PK.nearest_index(4, 7).to(dev), PK.nearest_index(7, 13).to(dev))])
     ref = F.interpolate(u.float().cpu().permute(0, 3, 1, 2), size=(7, 13), mode="nearest").permute(0, 2, 3, 1)
     assert torch.equal(up.float().cpu(), ref)
+    assert (L.lib().mdx_last_kernel() or b"").decode() == "ew_upsample_vec8_kernel"
+    u = rnd(2, 14, 25, 20, seed=6); up = torch.zeros(2, 28, 50, 20, dtype=BF, device=dev)       # C % 8 != 0: the scalar path
+    O.run_ops([O.Upsample(u, up, PK.nearest_index(14, 28).to(dev), PK.nearest_index(25, 50).to(dev))])
+    ref = F.interpolate(u.float().cpu().permute(0, 3, 1, 2), size=(28, 50), mode="nearest").permute(0, 2, 3, 1)
+    assert torch.equal(up.float().cpu(), ref)
     # layouts
     n = rnd(2, 4, 28, 50, seed=7, dtype=torch.float32); h = torch.zeros(2, 28, 50, 4, dtype=torch.float32, device=dev)
     O.run_ops([O.Layout(n, h, True)]); assert torch.equal(h.cpu(), n.permute(0, 2, 3, 1).cpu())
