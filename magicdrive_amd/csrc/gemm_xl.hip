@@ -93,6 +93,11 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
     const int wm = wave % G::WM, wn = wave / G::WM;
     int tile_m, tile_n;
     if (!tile_coords(p, tile_m, tile_n)) return;
+    // MDX_XL_TIMING=1 (tools/xl_timing.py): s_memtime stamps of wave 0 at 0 entry, 1 bookkeeping done (first DMA issue), 2 first slab
+    // landed, 3 main loop done, 4 C tile staged (last half), 5 stores issued — (6 after the epilogue's first barrier, 7 accumulators staged, before the second barrier) — 8 x 8 bytes per workgroup into the caller's workspace
+    unsigned long long ts_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define XL_STAMP(k) if (p.timing) ts_[k] = __builtin_amdgcn_s_memtime();
+    XL_STAMP(0)
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nt = p.K / 64;                                    // K % 64 == 0 (xl_supported)
 
@@ -307,6 +312,30 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
         __builtin_amdgcn_sched_barrier(0);                                                                                        \
     }
 
+    // Per-column addends (bias + the temb rows of the images this tile touches): fetched NOW into registers, written to their LDS rows
+    // (outside the operand ring) in the epilogue — fetched there, their memory round trip sat between the main loop and the staging of
+    // the accumulators.  Not for the 320-wide tile (no registers to spare).
+    constexpr bool ADD_EARLY = BN != 320;
+    constexpr int ADD_N = ADD_EARLY ? (BN + NTH - 1) / NTH : 1;      // one addend row (bias) over the workgroup's threads
+    float addb[ADD_N];                                           // raw loads: NOT touched before the epilogue (a use here would wait for them)
+    const bool geglu_e = p.epi == 1;
+    const bool has_t_e = p.temb != nullptr && !geglu_e;
+    // (only the bias: the temb rows need the step selector first, a dependent round trip that would delay the first slab — tiles with
+    // temb rows fetch their addends in the epilogue as before.)  Issued BEFORE the prologue's DMA pieces so that the hand-counted
+    // vmcnt waits of the main loop, which count the pieces younger than the one waited for, are unaffected.
+    const bool add_early = ADD_EARLY && !has_t_e;
+    if (add_early) {
+#pragma unroll
+        for (int u = 0; u < ADD_N; ++u) addb[u] = 0.f;
+        if (p.bias) {
+#pragma unroll
+            for (int u = 0; u < ADD_N; ++u) {
+                const int idx = u * NTH + tid;
+                addb[u] = p.bias[min(n0 + (idx < BN ? idx : 0), p.N - 1)];
+            }
+        }
+    }
+    XL_STAMP(1)
     if constexpr (BN == 320) {
         // ===== 256 x 320: quadrant order (A0,B0) (A1,B0) (A1,B1) (A0,B1) so that B0 and B1 are never live together (160 accumulators
         // leave room for one A half + 3 B tiles); A0 is read twice per slab (34 instead of 26 fragment reads: LDS port time is not the
@@ -325,6 +354,7 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
         if (nt > 1) xl_wait_vmcnt<INFLIGHT>(); else xl_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        XL_STAMP(2)
         if (grp == 1) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -422,6 +452,7 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
         if (nt > 1) xl_wait_vmcnt<INFLIGHT>(); else xl_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        XL_STAMP(2)
         if (grp == 1) {                                              // the stagger: group 1 runs one barrier behind group 0
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -478,6 +509,7 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
         if (nt > 1) xl_wait_vmcnt<PA + PB0>(); else xl_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        XL_STAMP(2)
         if (grp == 1) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -514,6 +546,7 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
 #undef XL_SEG_END
 #undef XL_MMA_END
 
+    XL_STAMP(3)
     // ---- epilogue ----
     constexpr int NH = (BN == 320) ? 2 : 1;                       // the 320-wide bf16 tile goes through LDS in two 128-row halves
     constexpr int HROWS = BM / NH;
@@ -524,7 +557,13 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
     bf16_t* Cs = (bf16_t*)smem;                                  // [HROWS][CSTR], aliases the (dead) operand ring
     float* addend = (float*)(smem + (size_t)HROWS * (BN + 8) * 2);   // [XL_SLOTS][BN] fp32, behind the largest C staging tile
     const int b0 = has_t ? m0 / p.rows_per_b : 0;
-    {
+    if (add_early) {
+#pragma unroll
+        for (int u = 0; u < ADD_N; ++u) {
+            const int idx = u * NTH + tid;
+            if (idx < BN) addend[idx] = (n0 + idx < p.N) ? addb[u] : 0.f;
+        }
+    } else {
         const int nslots = has_t ? XL_SLOTS : 1;
         const int sel = (has_t && p.sel) ? *p.sel : 0;
         const int bmax = has_t ? (p.M - 1) / p.rows_per_b : 0;
@@ -541,11 +580,48 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
     const int n0o = geglu ? n0 / 2 : n0, Nout = geglu ? p.N / 2 : p.N;
     const bf16_t* Rg = p.R ? (const bf16_t*)p.R : nullptr;
     bf16_t* Cg = (bf16_t*)p.C;
+    // The residual tile is fetched in ONE batch per half — issued before the accumulators are staged when the registers allow (256- and
+    // 160-wide tiles: the latency, an HBM round trip per tile, then overlaps the staging passes and the two barriers): in batches of
+    // four behind the staging it cost four dependent round trips per tile.  Unconditional loads from clamped addresses (a guarded load becomes its own branch + wait).
+    constexpr int RIT = NH == 1 ? (HROWS * (BN / 8) + NTH - 1) / NTH : 1;      // 16-byte chunks of the tile per thread
+    const bool rpref = NH == 1 && Rg != nullptr && p.wide && !geglu;   // not the 320-wide tile: no registers to spare (it keeps batches of four)
+    constexpr int RPASS = 1;
+    constexpr int RPB = (RIT + RPASS - 1) / RPASS;
+    uint4 rpre[RPB];
+    auto fetch_residual = [&](int hh, int pass) {
+        constexpr int cpr = BN >> 3;
+        const int mh_ = m0 + hh * HROWS;
+#pragma unroll
+        for (int u = 0; u < RPB; ++u) {
+            const int idx = (pass * RPB + u) * NTH + tid;
+            int row = idx / cpr;
+            int c8 = (idx - row * cpr) * 8;
+            row = min(min(row, HROWS - 1), p.M - 1 - mh_); if (row < 0) row = 0;
+            if (n0 + c8 + 8 > p.N) c8 = p.N - 8 - n0 < 0 ? 0 : p.N - 8 - n0;
+            rpre[u] = *(const uint4*)(Rg + (long)(mh_ + row) * p.ldr + n0 + c8);
+        }
+    };
 #pragma unroll 1
     for (int hh = 0; hh < NH; ++hh) {
-        __syncthreads();                                         // ring dead / previous half stored; addend visible
+        if (rpref && NH == 1) fetch_residual(hh, 0);
+        // raw barrier + LDS wait only: __syncthreads() also drains the VM counter, i.e. it would sit out the residual fetch just issued
+        xl_wait_lgkm0();
+        __builtin_amdgcn_s_barrier();                            // ring dead / previous half stored (its LDS reads returned); addend visible
+        asm volatile("" ::: "memory");
+        XL_STAMP(6)
         {
             const int fr = lane & 15, fq = lane >> 4;
+            // without temb rows the addends depend on the column only: read the wave's TJ (x2 for GEGLU gates) vectors once, not per row tile
+            constexpr bool HOIST = BN != 320;                     // the 320-wide kernel has no registers to spare
+            float4 a4h[HOIST ? TJ : 1], g4h[HOIST ? TJ : 1];
+            if (HOIST && !has_t) {
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const int nl = wn * TJ * 16 + j * 16 + 4 * fq;
+                    a4h[HOIST ? j : 0] = *(const float4*)(addend + nl);
+                    g4h[HOIST ? j : 0] = geglu ? *(const float4*)(addend + ((nl + 32) < BN ? nl + 32 : nl)) : a4h[HOIST ? j : 0];
+                }
+            }
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int mt_ = wm * TI * 16 + i * 16;            // first row of this MFMA tile inside the block tile
@@ -558,11 +634,11 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
                 for (int j = 0; j < TJ; ++j) {
                     if (geglu && (j & 2)) continue;               // gate tiles (columns 32..63 of a 64 group) are consumed with their value tile
                     const int nl = wn * TJ * 16 + j * 16 + 4 * fq;   // raw column inside the tile
-                    const float4 a4 = *(const float4*)(ad + nl);
+                    const float4 a4 = (has_t || !HOIST) ? *(const float4*)(ad + nl) : a4h[HOIST ? j : 0];
                     const float bb[4] = {a4.x, a4.y, a4.z, a4.w};
                     float o[4];
                     if (geglu) {
-                        const float4 g4 = *(const float4*)(ad + nl + 32);
+                        const float4 g4 = HOIST ? g4h[HOIST ? j : 0] : *(const float4*)(ad + nl + 32);
                         const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -584,7 +660,11 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
                 }
             }
         }
-        __syncthreads();
+        XL_STAMP(7)
+        xl_wait_lgkm0();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        XL_STAMP(4)
         const int mh = m0 + hh * HROWS;
         if (p.col_split) {
             // batch-flattened output: a tile's columns are tokens of consecutive images; column n -> image n / cs, token n % cs.
@@ -612,6 +692,41 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
                         if (t + 1 < cs) dst[1] = (bf16_t)(v >> 16);
                         else Cg[(long)(b + 1) * p.sC + (long)(mh + row) * p.ldc] = (bf16_t)(v >> 16);
                     }
+                }
+            }
+        } else if (rpref) {
+            constexpr int cpr = BN >> 3;
+#pragma unroll 1
+            for (int pass = 0; pass < RPASS; ++pass) {
+                if (NH == 2) fetch_residual(hh, pass);            // 320-wide: 160 accumulators are live before the staging, no room earlier
+#pragma unroll
+                for (int u = 0; u < RPB; ++u) {
+                    const int idx = (pass * RPB + u) * NTH + tid;
+                    const int row = idx / cpr, c8 = (idx - row * cpr) * 8;
+                    if (idx >= HROWS * cpr || mh + row >= p.M || n0 + c8 >= p.N) continue;
+                    uint4 v = *(const uint4*)(Cs + row * CSTR + c8);
+                    v.x = add2bf(v.x, rpre[u].x); v.y = add2bf(v.y, rpre[u].y); v.z = add2bf(v.z, rpre[u].z); v.w = add2bf(v.w, rpre[u].w);
+                    *(uint4*)(Cg + (long)(mh + row) * p.ldc + n0 + c8) = v;
+                }
+            }
+        } else if (BN != 320 && p.wide && !Rg) {
+            // no residual: batches of eight unconditional LDS reads (clamped index), then the guarded stores
+            const int cpr = BNo >> 3;
+            const int total = HROWS * cpr;
+#pragma unroll 1
+            for (int i0 = 0; i0 < total; i0 += 8 * NTH) {
+                uint4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = min(i0 + u * NTH + tid, total - 1);
+                    const int row = idx / cpr;
+                    v[u] = *(const uint4*)(Cs + row * CSTR + (idx - row * cpr) * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = i0 + u * NTH + tid;
+                    const int row = idx / cpr, c8 = (idx - row * cpr) * 8;
+                    if (idx < total && mh + row < p.M && n0o + c8 < Nout) *(uint4*)(Cg + (long)(mh + row) * p.ldc + n0o + c8) = v[u];
                 }
             }
         } else if (p.wide) {
@@ -666,6 +781,13 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
             }
         }
     }
+    XL_STAMP(5)
+    if (p.timing && tid == 0) {
+        unsigned long long* t = p.timing + 8 * (long)blockIdx.x;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = ts_[k];
+    }
+#undef XL_STAMP
 }
 
 // LDS: operand ring (2 slabs) or the bf16 C tile, whichever is larger, + the addend rows
@@ -688,6 +810,9 @@ static int launch_xl(const GCParams& p, hipStream_t st) {
     static const int dbg = [] { const char* e = getenv("MDX_XL_DBG"); return e ? atoi(e) : 0; }();
     q.dbg = dbg;
     q.swz = swz && q.nt > 1 && q.mt >= 64;
+    static const int timing = [] { const char* e = getenv("MDX_XL_TIMING"); return e ? atoi(e) : 0; }();
+    const unsigned nblk_t = q.swz ? (unsigned)((q.mt + 7) / 8 * 8 * q.nt) : (unsigned)(q.mt * q.nt);
+    q.timing = (timing && p.ws && (long)nblk_t * 64 <= p.ws_bytes) ? (unsigned long long*)p.ws : nullptr;
     const unsigned nblk = q.swz ? (unsigned)((q.mt + 7) / 8 * 8 * q.nt) : (unsigned)(q.mt * q.nt);
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), smem, st, q);
     char tag[96];
