@@ -278,7 +278,11 @@ class StableDiffusionBEVControlNetPipeline:
         plan = self._plans.get(key)
         if plan is None:
             with torch.cuda.device(device):
-                plan = SamplerPlan(self.unet.cfg, self.unet.packed(), self.controlnet.packed(), device, b, do_cfg, L_box, (h, w),
+                # the UNet's config.json knows nothing about the conditioning encoders: their geometry (box MLP widths, map embedder
+                # class / size, camera frequencies) is the ControlNet checkpoint's (a tiny or a 272x736 `...Plus` checkpoint loaded with
+                # from_pretrained would otherwise be planned with the SD-1.5 defaults)
+                plan_cfg = dict(self.unet.cfg); plan_cfg["controlnet"] = self.controlnet.cfg["controlnet"]
+                plan = SamplerPlan(plan_cfg, self.unet.packed(), self.controlnet.packed(), device, b, do_cfg, L_box, (h, w),
                                    num_steps=n_steps, guidance_scale=guidance_scale,
                                    conditioning_scale=float(controlnet_conditioning_scale), n_text=text.shape[1], scheduler_kind=sched_kind,
                                    given_view_mode=gv_mode)

@@ -365,3 +365,48 @@ def test_batch_consistency_sd15(dev):
         e = max(rel_l2(big[k:k + 1, v], one[:, v]) for v in range(6))
         print(f"[batch consistency] scene {k} of {nb} vs alone: per-view max rel {e:.4f}")
         assert e < 3e-2, (k, e)
+
+
+def test_sample_driver_end_to_end(dev, tmp_path):
+    """tools/sample.py = the reference's tools/test.py flow on the GPU: a tiny checkpoint in the reference layout with
+    its hydra overrides, a tiny SD-1.5-layout directory (scheduler config + VAE, no text encoder), five `.pth` samples in the demo format
+    (the inputs of tests/golden/sample_preprocess.pt, BEV maps enlarged to the tiny net's 200x200) -> one PNG per scene, view and run."""
+    import importlib.util
+    import os
+    import yaml
+    from PIL import Image
+    from magicdrive_amd.networks.autoencoder_kl import AutoencoderKL
+    from magicdrive_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiview
+    from magicdrive_amd.networks.unet_addon_rawbox import BEVControlNetModel
+    here = os.path.dirname(os.path.abspath(__file__))
+    sp = importlib.util.spec_from_file_location("mdx_tools_sample", os.path.join(os.path.dirname(here), "tools", "sample.py"))
+    sample = importlib.util.module_from_spec(sp); sp.loader.exec_module(sample)
+    cfg = spec.TINY_CONFIG
+    ckpt = tmp_path / "ckpt"
+    UNet2DConditionModelMultiview.from_config(cfg, seed=0).save_pretrained(str(ckpt / "unet"))
+    BEVControlNetModel.from_config(cfg, seed=1).save_pretrained(str(ckpt / "controlnet"))
+    os.makedirs(ckpt / "hydra")
+    with open(ckpt / "hydra" / "overrides.yaml", "w") as f:
+        yaml.safe_dump(["+exp=224x400", "runner.validation_times=2", "seed=7"], f)
+    sd15 = tmp_path / "sd15"
+    os.makedirs(sd15 / "scheduler")
+    with open(sd15 / "scheduler" / "scheduler_config.json", "w") as f:
+        f.write('{"_class_name": "PNDMScheduler", "beta_end": 0.012, "beta_schedule": "scaled_linear", "beta_start": 0.00085, '
+                '"num_train_timesteps": 1000, "set_alpha_to_one": false, "skip_prk_steps": true, "steps_offset": 1, "clip_sample": false}')
+    AutoencoderKL.from_config(spec.VAE_TINY_CONFIG, 5).save_pretrained(str(sd15 / "vae"))
+    data = tmp_path / "data"; os.makedirs(data)
+    G = torch.load(os.path.join(here, "golden", "sample_preprocess.pt"), weights_only=False)
+    for i, case in enumerate(G["cases"]):
+        smp = dict(case["sample"])
+        m = smp["gt_masks_bev"]                                                                            # 8 x 20 x 20 -> 8 x 200 x 200
+        smp["gt_masks_bev"] = m.repeat_interleave(10, 1).repeat_interleave(10, 2) if isinstance(m, torch.Tensor) else np.repeat(np.repeat(m, 10, 1), 10, 2)
+        torch.save(smp, data / f"tok{i}.pth")
+    out = tmp_path / "out"
+    sample.main(["--ckpt", str(ckpt) + "/", "--sd15", str(sd15), "--data", str(data), "--out", str(out), "--scheduler", "unipc", "--batch-size", "2",
+                 "--prompt-embeds", "--device", str(dev), "runner.pipeline_param.num_inference_steps=3", "fix_seed_within_batch=true"])
+    files = sorted(os.listdir(out))
+    assert len(files) == 5 * 2 * 6, files[:8]
+    im = Image.open(out / "3_gen1_view5.png")
+    assert im.size == (400, 224) and np.asarray(im).std() > 0
+    a, b = np.asarray(Image.open(out / "0_gen0_view0.png")), np.asarray(Image.open(out / "0_gen1_view0.png"))
+    assert (a != b).any(), "the two runs of a scene use different seeds"
