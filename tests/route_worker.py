@@ -82,6 +82,7 @@ elif mode == "noxl":
     conv_case(600, 4, 7, 320, 320, expect="conv3x3_kernel")                                   # 4x7 images
     conv_case(22, 28, 28, 640, 640, expect="conv3x3_kernel")                                  # 28-px rows straddling 128-row tiles
     gemm_case(537600, 320, 320, res=True, expect="gemm_ws_kernel<plain>")                     # bench row count
+    geglu_case(26400, 1280, 320, expect="gemm_ws_kernel<geglu>")                              # K = 320 GEGLU on the weight-stationary kernel
 elif mode in ("attn_q32", "attn_d80", "attn_old"):
     # attention2.hip's other instantiations (32-query waves; head dim 80) and attention.hip at the same shapes, through the tests
     # of tests/test_kernels_gpu.py (their route assertion follows this process's switches)

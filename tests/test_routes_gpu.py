@@ -143,6 +143,13 @@ def test_xl_conv(dev, B, H, W, Cin, Cout, stride, res, temb, expect):
     close(y, conv_ref(x, w, b, stride, (1, 1), tb, R), name=f"xl conv {B}x{H}x{W} {Cin}->{Cout}")
 
 
+def test_k320_geglu_large_goes_to_xl(dev):
+    """The level-0 GEGLU shape class (K = 320, >= 1024 tiles of 256 x 256): routed to the XL tile by default (gemm_conv.hip: geglu_xl)."""
+    from route_worker_helpers import geglu_check
+    k = geglu_check(26400, 1280, 320)
+    assert k == "gemm_xl_kernel<256x256,gemm>", k
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # Batch-flattened GEMM (GCParams.col_split): the per-view V^T projections of levels 1 / 2 / mid as ONE XL launch whose epilogue
 # scatters token columns to their view.  Even tokens-per-view (4-byte pair stores), odd (element stores, pairs straddling views),
