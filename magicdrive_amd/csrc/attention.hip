@@ -315,14 +315,22 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
 
 template <int D16>
 static int launch_attn_nw(const AttnParams& p, hipStream_t st) {
-    // 4 waves (128 queries) per workgroup when there are enough rows to fill 256 CUs, else
-    // smaller workgroups so short sequences (91, 28 tokens) still spread over the chip.
+    // 4 waves (128 queries) per workgroup whenever (batch x heads) alone fills the chip — also for 91- and 28-token sequences: every
+    // thread of the workgroup stages K / V^T, so the idle query rows cost less than narrower workgroups lose on staging (384 views,
+    // T = 91, d = 160: 4 waves 103 us, 2 waves 152 us, 1 wave 448 us; T = 28: 39 / 44 / 71 us; cross-view at T = 28: 2 waves 73 vs 108 us).
+    // With few (batch, head) pairs the sequence is split finer so that short sequences still spread over the chip.
     long blocks4 = (long)((p.Tq + 127) / 128) * p.H * p.B;
     static const long thr4 = [] { const char* e = getenv("MDX_ATTN_NW4_BLOCKS"); return e ? atol(e) : 256L; }();
     static const long thr8 = [] { const char* e = getenv("MDX_ATTN_NW8_BLOCKS"); return e ? atol(e) : (1L << 40); }();
     long blocks8 = (long)((p.Tq + 255) / 256) * p.H * p.B;
+    static const int force = [] { const char* e = getenv("MDX_ATTN_NW"); return e ? atoi(e) : 0; }();     // experiments: force 1 / 2 / 4 / 8 waves
+    if (force == 8) return launch_attn<D16, 8>(p, st);
+    if (force == 4) return launch_attn<D16, 4>(p, st);
+    if (force == 2) return launch_attn<D16, 2>(p, st);
+    if (force == 1) return launch_attn<D16, 1>(p, st);
     if (p.Tq >= 512 && blocks8 >= thr8) return launch_attn<D16, 8>(p, st);
     if (p.Tq >= 256 && blocks4 >= thr4) return launch_attn<D16, 4>(p, st);
+    if ((long)p.H * p.B >= 2 * thr4) return (p.Tq <= 32 && p.nsrc == 2) ? launch_attn<D16, 2>(p, st) : launch_attn<D16, 4>(p, st);
     if (p.Tq >= 64) return launch_attn<D16, 2>(p, st);
     return launch_attn<D16, 1>(p, st);
 }

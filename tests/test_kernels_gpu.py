@@ -547,6 +547,46 @@ def test_cfg_ddim_bf16_padded_model_input(dev):
     assert (xin[:, Cc:].float() == 7.0).all(), "pad channels must not be touched"
 
 
+@pytest.mark.parametrize("T,Tk,d,expect", [(91, 91, 160, "attn_kernel<10,4,self>"), (28, 28, 160, "attn_kernel<10,4,self>"), (91, 78, 160, "attn_kernel<10,4,self>"),
+                                            (28, 78, 80, "attn_kernel<5,4,self>")])
+def test_attention_short_sequences_many_heads(dev, T, Tk, d, expect):
+    """Level-2 / mid-block shapes at a batch where (views x heads) alone fills the chip: 128-query workgroups with mostly idle query rows
+    (attention.hip: launch_attn_nw) — rows >= Tq must neither be stored nor disturb the valid ones."""
+    B, heads = 66, 8
+    Cc = heads * d
+    q = rnd(B, T, Cc, seed=1); k = rnd(B, Tk, Cc, seed=2); v = rnd(B, Tk, Cc, seed=3)
+    vt = torch.full((B, Cc, PK.round_up(Tk, 8)), float("nan"), dtype=BF, device=dev); vt[:, :, :Tk] = v.transpose(1, 2)
+    o = torch.full((B, T + 3, Cc), 7.0, dtype=BF, device=dev)
+    O.run_ops([O.Attn(q, k, vt, o[:, :T], heads=heads, Tk=Tk, scale=d ** -0.5)])
+    kern = (L.lib().mdx_last_kernel() or b"").decode()
+    torch.cuda.synchronize()
+    assert kern == expect, kern
+    close(o[:, :T], ref_attention(q.float().cpu(), k.float().cpu(), v.float().cpu(), heads, d ** -0.5), rtol=2e-2, atol_rel=2e-2, name=f"attn short {T},{Tk},{d}")
+    assert (o[:, T:].float() == 7.0).all(), "rows past Tq were written"
+
+
+def test_attention_short_crossview_many_heads(dev):
+    ncam = 6
+    pair = {0: [5, 1], 1: [0, 2], 2: [1, 3], 3: [2, 4], 4: [3, 5], 5: [4, 0]}
+    B, heads, T, d = 66, 8, 28, 160
+    Cc = heads * d
+    q = rnd(B, T, Cc, seed=1); k = rnd(B, T, Cc, seed=2); v = rnd(B, T, Cc, seed=3)
+    vt = torch.zeros(B, Cc, PK.round_up(T, 8), dtype=BF, device=dev); vt[:, :, :T] = v.transpose(1, 2)
+    kvmap = torch.tensor([(i // ncam) * ncam + pair[i % ncam][s] for i in range(B) for s in range(2)], dtype=torch.int32, device=dev)
+    o = torch.zeros(B, T, Cc, dtype=BF, device=dev)
+    O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=T, scale=d ** -0.5, kvmap=kvmap, nsrc=2)])
+    kern = (L.lib().mdx_last_kernel() or b"").decode()
+    torch.cuda.synchronize()
+    assert kern == "attn_kernel<10,2,xview>", kern
+    qc, kc, vc = q.float().cpu(), k.float().cpu(), v.float().cpu()
+    ref = torch.zeros(B, T, Cc)
+    for i in range(B):
+        for s_ in range(2):
+            j = (i // ncam) * ncam + pair[i % ncam][s_]
+            ref[i] += ref_attention(qc[i:i + 1], kc[j:j + 1], vc[j:j + 1], heads, d ** -0.5)[0]
+    close(o, ref, rtol=2e-2, atol_rel=2e-2, name="attn short cross-view")
+
+
 # ---- attention2.hip (head dim 40, >= 128 workgroups; 80 behind MDX_ATTN2_D80): routes asserted, the rare branches forced ---------
 def attn2_route(d, Tq, xview=False):
     """Kernel mdx_attention_bf16 must pick for (d, Tq) under this process's switches (the library reads them once per process;
