@@ -163,6 +163,9 @@ def main():
                     help="after the headline measurement also time ONE configs[2] call of this many scenes per GPU (CFG doubles the views: 32 scenes = "
                          "the headline's 384 views) and report it as config.full_cond_scenes_per_s; 0 skips it")
     ap.add_argument("--no-consistency-check", action="store_true")
+    ap.add_argument("--hires-scenes", type=int, default=0,
+                    help="outside the timed region: also sample this many scenes per GPU of BASELINE configs[3] (6-view 432x768, camera + 32 boxes + BEV map "
+                         "through the ...Plus map encoder, CFG 2.0, same sampler) and report config.hires; 0 (default) skips it — it takes minutes")
     ap.add_argument("--vae-scenes", type=int, default=8,
                     help="outside the timed region: decode this many scenes' latents with the HIP AutoencoderKL (VAE_SD15_CONFIG, random weights) — what output_type='np' "
                          "adds per scene (config.vae_decode_ms_per_scene, config.scenes_per_s_incl_vae_decode); 0 skips it")
@@ -235,6 +238,32 @@ def main():
         assert torch.isfinite(fout).all()
         full_cond = {"scenes_per_s": nb * world / fdt, "scenes_per_gpu": nb, "seconds_per_call": fdt}
 
+    hires = None
+    if args.hires_scenes > 0:
+        hh, hw_ = 432 // 8, 768 // 8
+        hcfg = spec.with_plus_map_embedder(cfg, (hh, hw_))
+        hpipe, _, _ = build_pipeline(hcfg, dev, args.scheduler)
+        hpipe.use_graph = pipe.use_graph
+        nh = args.hires_scenes
+        hsc = [synthetic.make_scene_batch(1, seed=4321 + i, max_len=32, latent_hw=(hh, hw_)) for i in DD.shard_scenes(nh * world, rank, world)]
+        hcat = lambda k: torch.cat([s_[k] for s_ in hsc]).to(dev)
+        hbox = {k: torch.cat([s_["bboxes_3d_data"][k] for s_ in hsc]).to(dev) for k in ("bboxes", "classes", "masks")}
+        hkw = dict(prompt=None, image=hcat("bev_map"), camera_param=hcat("camera_param"), height=432, width=768, num_inference_steps=args.ddim_steps,
+                   guidance_scale=2.0, latents=hcat("latents"), prompt_embeds=hcat("prompt_embeds"), negative_prompt_embeds=hcat("negative_prompt_embeds"),
+                   output_type="latent", bev_controlnet_kwargs={"bboxes_3d_data": hbox})
+        hpipe(**hkw)
+        DD.barrier(); torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        hout = hpipe(**hkw).images
+        torch.cuda.synchronize(); DD.barrier()
+        hdt = DD.max_over_ranks(time.perf_counter() - t3, dev)
+        assert torch.isfinite(hout).all()
+        hplan = next(iter(hpipe._plans.values()))
+        hf = FL.program_flops(hplan.step_ops)["total"] * args.ddim_steps / nh
+        hires = {"workload": "configs[3]: 6-view 432x768 (54x96 latents), camera + 32 boxes + BEV map (...Plus map encoder), CFG 2.0, same sampler",
+                 "scenes_per_gpu": nh, "scenes_per_s": round(nh * world / hdt, 4), "seconds_per_call": round(hdt, 3), "tflop_per_scene": round(hf / 1e12, 1),
+                 "mfma_frac_end_to_end": round(hf * nh / hdt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+        del hpipe
     vae_ms = None
     if args.vae_scenes > 0:
         from magicdrive_amd.networks.autoencoder_kl import AutoencoderKL
@@ -267,6 +296,7 @@ def main():
                    "tflop_per_scene": round(f_scene / 1e12, 3),
                    "mfma_frac_end_to_end": round(f_scene * scenes_per_s / world / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                    "batch_consistency_rel": None if consistency is None else round(consistency, 5),
+                   "hires": hires,
                    "vae_decode_ms_per_scene": None if vae_ms is None else round(vae_ms, 2),
                    "scenes_per_s_incl_vae_decode": None if vae_ms is None else round(1.0 / (world / scenes_per_s + vae_ms * 1e-3) * world, 4),
                    "full_cond_scenes_per_s": None if full_cond is None else round(full_cond["scenes_per_s"], 4),
