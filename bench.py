@@ -149,8 +149,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scenes-per-gpu", type=int, default=64,
-                    help="scenes sampled per rank per pipe() call (throughput grows with the batch: 4.46 / 4.72 / 4.79 scenes/s at 32 / 64 / 128; 64 keeps a call at 13 s)")
+    ap.add_argument("--scenes-per-gpu", type=int, default=128,
+                    help="scenes sampled per rank per pipe() call (throughput grows with the batch — fewer partial rounds of tiles: 6.33 / 6.46 / 6.53 "
+                         "scenes/s at 64 / 96 / 128 in round 2; a 128-scene call takes 20 s)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--scheduler", choices=["ddim", "unipc"], default="ddim",
                     help="ddim = the headline metric's sampler; unipc (with --ddim-steps 20) = what the reference's tools/test.py runs")
@@ -213,13 +214,18 @@ def main():
     # tests/test_e2e_gpu.py::test_real_size_ddim_loop_sd15 checks against the CPU oracle) — whatever main loops the big batch routes to.
     consistency = None
     if not args.no_consistency_check and b > 1:
-        sl = slice(0, 1)
-        one = pipe(prompt=None, image=bev[sl], camera_param=None if cam is None else cam[sl], height=224, width=400, num_inference_steps=args.ddim_steps,
-                   guidance_scale=gs, latents=lat[sl], prompt_embeds=prompt[sl], negative_prompt_embeds=neg[sl], output_type="latent",
-                   bev_controlnet_kwargs={"bboxes_3d_data": {k: v[sl] for k, v in boxes.items()}} if boxes is not None else {}).images.float()
-        mine0 = res[mine[0]:mine[0] + 1].float().to(one.device) if res.shape[0] == n_total else res[:1].float().to(one.device)
-        consistency = max(((mine0[:, v] - one[:, v]).norm() / (one[:, v].norm() + 1e-20)).item() for v in range(one.shape[1]))
-        assert consistency < 5e-2, f"scene 0 of the {b}-scene batch differs from the 1-scene call by {consistency:.3e} (per-view rel L2)"
+        # first, middle and LAST scene of this rank's batch (the last one sits at the highest row indices: index arithmetic, 2 GiB windows)
+        consistency = 0.0
+        for si in sorted({0, b // 2, b - 1}):
+            sl = slice(si, si + 1)
+            one = pipe(prompt=None, image=bev[sl], camera_param=None if cam is None else cam[sl], height=224, width=400, num_inference_steps=args.ddim_steps,
+                       guidance_scale=gs, latents=lat[sl], prompt_embeds=prompt[sl], negative_prompt_embeds=neg[sl], output_type="latent",
+                       bev_controlnet_kwargs={"bboxes_3d_data": {k: v[sl] for k, v in boxes.items()}} if boxes is not None else {}).images.float()
+            row = (mine[si] if res.shape[0] == n_total else si)
+            got = res[row:row + 1].float().to(one.device)
+            c_ = max(((got[:, v] - one[:, v]).norm() / (one[:, v].norm() + 1e-20)).item() for v in range(one.shape[1]))
+            assert c_ < 5e-2, f"scene {si} of the {b}-scene batch differs from the 1-scene call by {c_:.3e} (per-view rel L2)"
+            consistency = max(consistency, c_)
     full_cond = None
     if args.full_cond_scenes > 0 and not args.full_cond:
         nb = args.full_cond_scenes

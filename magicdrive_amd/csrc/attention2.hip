@@ -33,7 +33,10 @@ namespace mdx {
 typedef __attribute__((ext_vector_type(4))) unsigned a2_rsrc_t;
 typedef __attribute__((address_space(3))) void a2_lds_t;
 constexpr unsigned A2_OOB = 0x80000000u, A2_RECORDS = 0x80000000u;
-constexpr int A2_KV = 64, A2_NW = 4, A2_NT = 256, A2_NBUF = 3;
+#ifndef A2_RING
+#define A2_RING 3          // LDS ring depth: tiles g .. g + A2_RING - 2 are in flight / in use while tile g is multiplied
+#endif
+constexpr int A2_KV = 64, A2_NW = 4, A2_NT = 256, A2_NBUF = A2_RING;
 
 __device__ __forceinline__ a2_rsrc_t a2_make_rsrc(const void* base) {
     const unsigned long long a = (unsigned long long)base;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
     constexpr int PPW = (KP + VP + A2_NW - 1) / A2_NW;     // pieces per wave per tile (the excess are dummies into scratch)
     constexpr int SCRATCH = A2_NBUF * BUF;         // 1 KiB scratch for the dummy pieces
     constexpr int QW = 32 * QT;                    // queries per wave
-    static_assert(SCRATCH + 1024 <= 65536, "LDS budget: d = 40 -> 35 KB (4 workgroups per CU), d = 80 -> 61 KB (2)");
+    static_assert(SCRATCH + 1024 <= 65536 || A2_RING > 3, "LDS budget: d = 40 -> 35 KB (4 workgroups per CU), d = 80 -> 61 KB (2)");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SCRATCH + 1024];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -323,16 +326,22 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
         if (++it == ntile) { it = 0; ++is_; }
     };
     issue_next(0);
-    if (total > 1) issue_next(1);
+#pragma unroll
+    for (int k = 1; k < A2_NBUF - 1; ++k)
+        if (total > k) issue_next(k);
     int g = 0;                           // tile of the whole stream (both sources) being multiplied
     int slot = 0;
-    // start of tile g: its pieces have landed for every wave, every wave is done with tile g - 1, tile g + 2 goes out
+    // start of tile g: its pieces have landed for every wave, every wave is done with tile g - 1, tile g + A2_NBUF - 1 goes out
     auto tile_sync = [&]() {
-        if (g + 1 < total) a2_wait_vmcnt<PPW>(); else a2_wait_vmcnt<0>();      // at most the one younger tile's pieces outstanding
+        // at most the A2_NBUF - 2 younger tiles' pieces outstanding (fewer at the end of the stream)
+        const int younger = total - 1 - g;
+        if (younger >= A2_NBUF - 2) a2_wait_vmcnt<PPW * (A2_NBUF - 2)>();
+        else if (A2_NBUF > 3 && younger == 1) a2_wait_vmcnt<PPW>();
+        else a2_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (g + 2 < total && !(A2_ABL & 64)) {
-            int s2 = slot + 2; if (s2 >= A2_NBUF) s2 -= A2_NBUF;
+        if (g + A2_NBUF - 1 < total && !(A2_ABL & 64)) {
+            int s2 = slot + A2_NBUF - 1; if (s2 >= A2_NBUF) s2 -= A2_NBUF;
             issue_next(s2);
         }
     };
