@@ -134,9 +134,11 @@ int mdx_conv2d_direct(const MdxConvDirectDesc* d, void* stream);
  *   K : [Bkv][Tk][..] same addressing with sK, ldk
  *   Vt: [Bkv][H*d][ldv]  V transposed — element (b,h,j,t) at Vt + b*sV + (h*d+j)*ldv + t
  *   O : [B][Tq][H*d] with sO, ldo
- * nsrc ∈ {1,2}: for query batch b the key/value batches are kvmap[b*nsrc + s] (identity if
- * kvmap == NULL); with nsrc == 2 the two softmax-normalised outputs are SUMMED — exactly
- * blocks.py:213-217 (left + right neighbour; the doubled out-bias is the caller's business).
+ * nsrc key/value sources per query batch: for query batch b they are the batches kvmap[b*nsrc + s] (identity if kvmap == NULL).
+ *   joint == 0, nsrc ∈ {1,2}: every source has its own softmax and the normalised outputs are SUMMED — neighboring_attn_type "add",
+ *     blocks.py:112-121, 213-217 (left + right neighbour; the doubled out-bias is the caller's business);
+ *   joint == 1, nsrc ∈ {1..8}: ONE softmax over the concatenation of the sources' keys — "concat" (the two neighbours, blocks.py:122-134)
+ *     and "self" (all cameras of the scene, blocks.py:135-138).
  * d % 8 == 0, d <= 160; ldq,ldk,ldv,sQ,sK,sV % 8 == 0; ldo % 4 == 0.
  */
 typedef struct MdxAttnDesc {
@@ -145,7 +147,7 @@ typedef struct MdxAttnDesc {
     int64_t B, H, Tq, Tk, d, nsrc;
     int64_t ldq, sQ, ldk, sK, ldv, sV, ldo, sO;
     double scale;
-    int64_t reserved0;
+    int64_t joint;
 } MdxAttnDesc;
 int mdx_attention_bf16(const MdxAttnDesc* d, void* stream);
 

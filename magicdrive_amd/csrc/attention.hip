@@ -33,6 +33,7 @@ struct AttnParams {
     const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
     const int* kvmap;
     int B, H, Tq, Tk, d, nsrc;
+    int joint;         // 1: one softmax over the concatenated sources; 0: per-source softmax, outputs summed
     long ldq, sQ, ldk, sK, ldv, sV, ldo, sO;
     float scale_log2;  // scale * log2(e)
     int qblocks;       // query blocks per (batch, head); >0 selects the XCD-aware 1-D grid
@@ -102,12 +103,13 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
             for (int r = 0; r < 16; ++r) osum[i][r] = 0.f;
     }
 
+    float m_run = -INFINITY;
+    float l_run = 0.f;
     for (int s = 0; s < p.nsrc; ++s) {
         const int bkv = p.kvmap ? p.kvmap[b * p.nsrc + s] : b;
         const bf16_t* kbase = p.K + (long)bkv * p.sK + (long)h * d;
         const bf16_t* vbase = p.Vt + (long)bkv * p.sV + (long)h * d * p.ldv;
-        float m_run = -INFINITY;
-        float l_run = 0.f;
+        if (!p.joint || s == 0) { m_run = -INFINITY; l_run = 0.f; }      // joint: the sources are ONE kv sequence (one softmax)
 
         for (int j0 = 0; j0 < p.Tk; j0 += KVT) {
             if constexpr (UNR) {
@@ -255,7 +257,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
             }
             __syncthreads();
         }
-        // ---- finish this source ----
+        // ---- finish this source (joint: only after the last one) ----
+        if (p.joint && s + 1 < p.nsrc) continue;
         float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         float inv = 1.0f / l_tot;
         if (TWO) {
@@ -304,12 +307,13 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
         q.qblocks = qblocks;
         grid = dim3((unsigned)(((long)p.B * p.H + 7) / 8 * 8 * qblocks), 1, 1);
     }
-    if (p.nsrc == 2)
+    const bool two = p.nsrc == 2 && !p.joint;
+    if (two)
         hipLaunchKernelGGL((attn_kernel<D16, NW, true>), grid, dim3(NW * 64), 0, st, q);
     else
         hipLaunchKernelGGL((attn_kernel<D16, NW, false>), grid, dim3(NW * 64), 0, st, q);
     char tag[64];
-    snprintf(tag, sizeof tag, "attn_kernel<%d,%d,%s>", D16, NW, p.nsrc == 2 ? "xview" : "self");
+    snprintf(tag, sizeof tag, "attn_kernel<%d,%d,%s>", D16, NW, two ? "xview" : (p.nsrc > 1 ? "joint" : "self"));
     return check_launch(tag);
 }
 
@@ -342,7 +346,9 @@ using namespace mdx;
 extern "C" int mdx_attention_bf16(const MdxAttnDesc* a, void* stream) {
     if (!a || !a->Q || !a->K || !a->Vt || !a->O) return set_error(MDX_EINVAL, "mdx_attention_bf16: null operand");
     if (a->d % 8 || a->d <= 0 || a->d > 160) return set_error(MDX_EINVAL, "head dim %ld unsupported (d %% 8 == 0, d <= 160)", (long)a->d);
-    if (a->nsrc != 1 && a->nsrc != 2) return set_error(MDX_EINVAL, "nsrc must be 1 or 2");
+    if (a->joint != 0 && a->joint != 1) return set_error(MDX_EINVAL, "joint must be 0 or 1");
+    if (a->nsrc < 1 || a->nsrc > (a->joint ? 8 : 2)) return set_error(MDX_EINVAL, "nsrc must be 1 or 2 (joint: 1..8)");
+    if (a->nsrc > 1 && !a->kvmap) return set_error(MDX_EINVAL, "nsrc > 1 needs a kvmap");
     if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->sQ % 8) || (a->sK % 8) || (a->sV % 8) || (a->ldo % 4) || (a->sO % 4))
         return set_error(MDX_EINVAL, "attention strides must be multiples of 8 (Q,K,Vt) / 4 (O)");
     if (((uintptr_t)a->Q & 15) || ((uintptr_t)a->K & 15) || ((uintptr_t)a->Vt & 15) || ((uintptr_t)a->O & 7))
@@ -352,14 +358,14 @@ extern "C" int mdx_attention_bf16(const MdxAttnDesc* a, void* stream) {
     AttnParams p;
     p.Q = (const bf16_t*)a->Q; p.K = (const bf16_t*)a->K; p.Vt = (const bf16_t*)a->Vt; p.O = (bf16_t*)a->O;
     p.kvmap = a->kvmap;
-    p.B = (int)a->B; p.H = (int)a->H; p.Tq = (int)a->Tq; p.Tk = (int)a->Tk; p.d = (int)a->d; p.nsrc = (int)a->nsrc;
+    p.B = (int)a->B; p.H = (int)a->H; p.Tq = (int)a->Tq; p.Tk = (int)a->Tk; p.d = (int)a->d; p.nsrc = (int)a->nsrc; p.joint = (int)a->joint;
     p.ldq = a->ldq; p.sQ = a->sQ; p.ldk = a->ldk; p.sK = a->sK; p.ldv = a->ldv; p.sV = a->sV; p.ldo = a->ldo; p.sO = a->sO;
     p.scale_log2 = (float)(a->scale * 1.4426950408889634);
     hipStream_t st = (hipStream_t)stream;
     {
         Attn2Params p2;
         p2.Q = p.Q; p2.K = p.K; p2.Vt = p.Vt; p2.O = p.O; p2.kvmap = p.kvmap;
-        p2.B = p.B; p2.H = p.H; p2.Tq = p.Tq; p2.Tk = p.Tk; p2.d = p.d; p2.nsrc = p.nsrc;
+        p2.B = p.B; p2.H = p.H; p2.Tq = p.Tq; p2.Tk = p.Tk; p2.d = p.d; p2.nsrc = p.nsrc; p2.joint = p.joint;
         p2.ldq = p.ldq; p2.sQ = p.sQ; p2.ldk = p.ldk; p2.sK = p.sK; p2.ldv = p.ldv; p2.sV = p.sV; p2.ldo = p.ldo; p2.sO = p.sO;
         p2.scale_log2 = p.scale_log2; p2.qblocks = 0;
         if (attn2_supported(p2)) return launch_attn2(p2, st);

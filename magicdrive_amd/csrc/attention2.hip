@@ -379,7 +379,8 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
         if (QT == 2 && nact == 2) A2_SOURCE((QT == 2 ? 2 : 1))
         else if (nact >= 1) A2_SOURCE(1)
         else A2_SOURCE(0)
-        // ---- end of a source: normalise, accumulate (cross-view), reset ----
+        // ---- end of a source: normalise, accumulate (cross-view), reset.  joint: the sources are one kv sequence — only after the last ----
+        if (p.joint && src + 1 < p.nsrc) continue;
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             float inv0, inv1;
@@ -446,10 +447,11 @@ static int launch_attn2_d(const Attn2Params& p, hipStream_t st) {
     Attn2Params q = p;
     q.qblocks = (p.Tq + A2_NW * 32 * QT - 1) / (A2_NW * 32 * QT);
     const dim3 grid((unsigned)(((long)p.B * p.H + 7) / 8 * 8 * q.qblocks), 1, 1);
-    if (p.nsrc == 2) hipLaunchKernelGGL((attn2_kernel<D8, true, QT>), grid, dim3(A2_NT), 0, st, q);
+    const bool two = p.nsrc == 2 && !p.joint;                   // TWO = the summed two-neighbour form; everything else is one softmax over nsrc sources
+    if (two) hipLaunchKernelGGL((attn2_kernel<D8, true, QT>), grid, dim3(A2_NT), 0, st, q);
     else hipLaunchKernelGGL((attn2_kernel<D8, false, QT>), grid, dim3(A2_NT), 0, st, q);
     char tag[64];
-    snprintf(tag, sizeof tag, "attn2_kernel<%d,%s,q%d>", D8 * 8, p.nsrc == 2 ? "xview" : "self", 32 * QT);
+    snprintf(tag, sizeof tag, "attn2_kernel<%d,%s,q%d>", D8 * 8, two ? "xview" : (p.nsrc > 1 ? "joint" : "self"), 32 * QT);
     return check_launch(tag);
 }
 

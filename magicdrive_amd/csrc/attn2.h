@@ -6,6 +6,7 @@ struct Attn2Params {
     const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
     const int* kvmap;
     int B, H, Tq, Tk, d, nsrc;
+    int joint;         // 1: one softmax over the concatenation of the nsrc sources; 0: per-source softmax, outputs summed (nsrc <= 2)
     long ldq, sQ, ldk, sK, ldv, sV, ldo, sO;
     float scale_log2;  // scale * log2(e)
     int qblocks;       // query blocks per (batch, head), filled in by launch_attn2

@@ -160,13 +160,25 @@ class Builder:
         self.eps = cfg["norm_eps"]
         pair = cfg["neighboring_view_pair"]
         pair = {int(k): [int(x) for x in v] for k, v in pair.items()}
-        assert cfg.get("neighboring_attn_type", "add") == "add", "only the default 'add' neighbour mode is built"
+        # cross-view attention form (BasicMultiviewTransformerBlock._construct_attn_input, blocks.py:106-142):
+        #   add    (default): one attention per (view, neighbour), outputs summed -> 2 sources, separate softmax, to_out bias twice
+        #   concat : the neighbours' tokens concatenated into one kv sequence     -> 2 sources, ONE softmax, bias once
+        #   self   : all cameras of the scene as one sequence (queries of every view see every view) -> n_cam sources, ONE softmax, bias once
+        self.nattn = cfg.get("neighboring_attn_type", "add")
+        if self.nattn not in ("add", "concat", "self"):
+            raise NotImplementedError(f"Unknown type: {self.nattn}")          # the reference's error (blocks.py:139-141)
         kv = []
         for i in range(n_views):
             base = (i // n_cam) * n_cam
-            for nb in pair[i % n_cam]:
+            srcs = list(range(n_cam)) if self.nattn == "self" else pair[i % n_cam]
+            for nb in srcs:
                 kv.append(base + nb)
-        assert all(len(v) == 2 for v in pair.values()), "cross-view kernel handles exactly 2 neighbours per view"
+        if self.nattn == "add":
+            assert all(len(v) == 2 for v in pair.values()), "the summed cross-view form handles exactly 2 neighbours per view"
+        else:
+            assert len({len(v) for v in pair.values()}) == 1 and (self.nattn == "self" or len(pair[0]) <= 8), "concat / self: equal source counts, <= 8"
+        self.xv_nsrc = n_cam if self.nattn == "self" else len(pair[0])
+        assert self.xv_nsrc <= 8, "joint cross-view attention handles <= 8 sources"
         self.kvmap = torch.tensor(kv, dtype=torch.int32, device=device)
 
     # ---- small helpers ---------------------------------------------------------------
@@ -238,7 +250,8 @@ class Builder:
         ao = self.pool.get((B * T, C))
         qk3 = qk.view(B, T, 2 * C)
         self.emit(O.Attn(qk3[:, :, :C], qk3[:, :, C:], vt, ao.view(B, T, C), heads=heads, Tk=T, scale=(C // heads) ** -0.5,
-                         kvmap=self.kvmap if cross_view else None, nsrc=2 if cross_view else 1, name=name + ".attn"))
+                         kvmap=self.kvmap if cross_view else None, nsrc=self.xv_nsrc if cross_view else 1,
+                         joint=cross_view and self.nattn != "add", name=name + ".attn"))
         self.pool.put(qk)
         self.pool.put(vt)
         return ao
@@ -268,7 +281,8 @@ class Builder:
             self.pool.put(n4)
             # connector(to_out(o_l + o_r) + 2 b_o) is one affine map: fold it at pack time,
             #   W = W_c W_o ,  b = W_c (2 b_o) + b_c     (one GEMM instead of two per block; fp32 fold, bf16 weights)
-            wf, bf_ = net.folded_affine(pre + "connector.weight", pre + "connector.bias", pre + "attn4.to_out.0.weight", pre + "attn4.to_out.0.bias", 2.0)
+            wf, bf_ = net.folded_affine(pre + "connector.weight", pre + "connector.bias", pre + "attn4.to_out.0.weight", pre + "attn4.to_out.0.bias",
+                                        2.0 if self.nattn == "add" else 1.0)      # concat / self: ONE attention per view, its out-bias once
             h3 = self.gemm(ao4, wf, C, bias=bf_, R=h2, name=name + ".attn4.out+connector")
             self.pool.put(ao4); self.pool.put(h2)
         else:

@@ -201,6 +201,7 @@ class Attn:
     kvmap: Optional[torch.Tensor] = None     # int32 [B*nsrc]
     nsrc: int = 1
     name: str = ""
+    joint: bool = False                      # one softmax over the concatenated sources (neighboring_attn_type concat / self) instead of a sum of per-source attentions
     opcode = L.OP_ATTN
 
     def lower(self):
@@ -222,6 +223,8 @@ class Attn:
         d.ldv, d.sV = Vt.stride(1), Vt.stride(0)
         d.ldo, d.sO = O.stride(1), O.stride(0)
         d.scale = float(self.scale)
+        d.joint = int(self.joint)
+        _chk(self.nsrc >= 1 and (self.nsrc <= 8 if self.joint else self.nsrc <= 2), f"attn {self.name}: nsrc={self.nsrc} (joint={self.joint})")
         return self.opcode, d
 
 

@@ -15,7 +15,7 @@ def build_reference(cfg, unet_sd, cn_sd, img_size=(224, 400)):
         cross_attention_dim=cfg["cross_attention_dim"], attention_head_dim=cfg["attention_head_dim"],
         norm_num_groups=cfg["norm_num_groups"])
     unet = ns.unet_mv.UNet2DConditionModelMultiview.from_unet_2d_condition(
-        base, neighboring_view_pair=cfg["neighboring_view_pair"], neighboring_attn_type="add",
+        base, neighboring_view_pair=cfg["neighboring_view_pair"], neighboring_attn_type=cfg.get("neighboring_attn_type", "add"),
         zero_module_type="zero_linear", img_size=list(img_size))
     cn = cfg["controlnet"]; bb = cn["bbox"]
     extra = {}

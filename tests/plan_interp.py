@@ -76,10 +76,14 @@ def run_attn(op: O.Attn):
     out = torch.zeros(B, Tq, Cc)
     kvmap = op.kvmap.tolist() if op.kvmap is not None else list(range(B))
     qh = Q.view(B, Tq, H, d).transpose(1, 2)
+    khs, vhs = [], []
     for s in range(op.nsrc):
         idx = torch.tensor([kvmap[b * op.nsrc + s] for b in range(B)])
-        kh = K[idx].view(B, op.Tk, H, d).transpose(1, 2)
-        vh = Vt[idx].transpose(1, 2).reshape(B, op.Tk, H, d).transpose(1, 2)
+        khs.append(K[idx].view(B, op.Tk, H, d).transpose(1, 2))
+        vhs.append(Vt[idx].transpose(1, 2).reshape(B, op.Tk, H, d).transpose(1, 2))
+    if getattr(op, "joint", False):            # one softmax over the concatenated sources
+        khs, vhs = [torch.cat(khs, 2)], [torch.cat(vhs, 2)]
+    for kh, vh in zip(khs, vhs):
         att = torch.softmax(qh @ kh.transpose(-1, -2) * op.scale, -1)
         out += (att @ vh).transpose(1, 2).reshape(B, Tq, Cc)
     op.O.copy_(out.to(op.O.dtype))

@@ -286,6 +286,31 @@ def test_module_api_forward_hires_plus_map_encoder(dev):
     assert e < 4e-2
 
 
+@pytest.mark.parametrize("mode", ["concat", "self"])
+def test_module_api_forward_neighboring_attn_modes(dev, mode):
+    """neighboring_attn_type concat / self on the GPU (joint-softmax attention over 2 / 6 kv sources), through the reference module
+    signatures, vs outputs of the REAL reference UNet (tests/golden/tiny_forward_nattn.pt)."""
+    import os
+    from magicdrive_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiview
+    from magicdrive_amd.networks.unet_addon_rawbox import BEVControlNetModel
+    G = torch.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_forward_nattn.pt"))
+    cfg = dict(spec.TINY_CONFIG); cfg["neighboring_attn_type"] = mode
+    unet = UNet2DConditionModelMultiview.from_config(cfg, 0).to(dev); cn = BEVControlNetModel.from_config(cfg, 1).to(dev)
+    sc = scene(cfg, 1, 3)
+    lat = torch.randn(1, 6, 4, 28, 50, generator=torch.Generator().manual_seed(G["lat_seed"]))
+    t = G["timesteps"]
+    down, mid, ctx = cn(lat.to(dev), t.to(dev), sc["camera_param"].to(dev), {k: v.to(dev) for k, v in sc["bboxes_3d_data"].items()},
+                        sc["prompt_embeds"].to(dev), sc["bev_map"].to(dev), return_dict=False)
+    eps = unet(lat.reshape(-1, 4, 28, 50).to(dev), t.repeat_interleave(6).to(dev), encoder_hidden_states=ctx,
+               down_block_additional_residuals=down, mid_block_additional_residual=mid).sample
+    torch.cuda.synchronize()
+    e = max(rel_l2(eps[i], G["eps_" + mode][i].float()) for i in range(6))
+    other = "self" if mode == "concat" else "concat"
+    eo = min(rel_l2(eps[i], G["eps_" + other][i].float()) for i in range(6))
+    print(f"[neighboring_attn_type={mode} vs reference golden] eps per-view max rel {e:.4f} (vs the other mode's golden: {eo:.4f})")
+    assert e < 4e-2 and eo > 2 * e
+
+
 def test_real_size_ddim_loop_sd15(dev):
     """SD-1.5-size sampler loop (the bench workload: text-only, camera_param=None => CFG off) through the drop-in
     pipeline vs the CPU oracle on the same bf16-rounded weights.  6 DDIM steps by default (CPU oracle ~5 s/step);

@@ -587,6 +587,35 @@ def test_attention_short_crossview_many_heads(dev):
     close(o, ref, rtol=2e-2, atol_rel=2e-2, name="attn short cross-view")
 
 
+@pytest.mark.parametrize("b,heads,T,d,nsrc,expect", [
+    (2, 8, 1400, 40, 2, "attn2_kernel<40,joint,q64>"),      # concat: two neighbours, one softmax (level 0)
+    (1, 8, 1400, 40, 6, "attn2_kernel<40,joint,q64>"),      # self: all six cameras of a scene
+    (2, 8, 350, 80, 2, "attn_kernel<5,4,joint>"),           # attention.hip
+    (2, 8, 91, 160, 6, "attn_kernel<10,2,joint>"),
+])
+def test_attention_joint_sources(dev, b, heads, T, d, nsrc, expect):
+    """MdxAttnDesc.joint: ONE softmax over the concatenation of the nsrc kv sources (neighboring_attn_type concat / self, blocks.py:122-138)
+    — not the sum of per-source attentions."""
+    ncam = 6
+    pair = {0: [5, 1], 1: [0, 2], 2: [1, 3], 3: [2, 4], 4: [3, 5], 5: [4, 0]}
+    Cc = heads * d; B = b * ncam
+    q = rnd(B, T, Cc, seed=1); k = rnd(B, T, Cc, seed=2); v = rnd(B, T, Cc, seed=3)
+    vt = torch.full((B, Cc, PK.round_up(T, 8)), float("nan"), dtype=BF, device=dev); vt[:, :, :T] = v.transpose(1, 2)
+    srcs = lambda i: [(i // ncam) * ncam + c for c in (range(ncam) if nsrc == ncam else pair[i % ncam])]
+    kvmap = torch.tensor([j for i in range(B) for j in srcs(i)], dtype=torch.int32, device=dev)
+    o = torch.zeros(B, T, Cc, dtype=BF, device=dev)
+    O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=T, scale=d ** -0.5, kvmap=kvmap, nsrc=nsrc, joint=True)])
+    kern = (L.lib().mdx_last_kernel() or b"").decode()
+    torch.cuda.synchronize()
+    assert kern == expect, kern
+    qc, kc, vc = q.float().cpu(), k.float().cpu(), v.float().cpu()
+    ref = torch.zeros(B, T, Cc)
+    for i in range(B):
+        js = srcs(i)
+        ref[i] = ref_attention(qc[i:i + 1], torch.cat([kc[j] for j in js])[None], torch.cat([vc[j] for j in js])[None], heads, d ** -0.5)[0]
+    close(o, ref, rtol=2e-2, atol_rel=2e-2, name=f"attn joint {nsrc} sources")
+
+
 # ---- attention2.hip (head dim 40, >= 128 workgroups; 80 behind MDX_ATTN2_D80): routes asserted, the rare branches forced ---------
 def attn2_route(d, Tq, xview=False):
     """Kernel mdx_attention_bf16 must pick for (d, Tq) under this process's switches (the library reads them once per process;

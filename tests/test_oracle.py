@@ -233,6 +233,25 @@ def test_golden_forward_hires_plus_map_encoder(tiny):
     assert rel_l2(e, G["eps"].float()) < 2e-3          # golden eps stored as fp16
 
 
+@pytest.mark.parametrize("mode", ["concat", "self"])
+def test_golden_forward_neighboring_attn_modes(tiny, mode):
+    """neighboring_attn_type concat / self (blocks.py:106-142, 206-217): the oracle vs the real reference UNet (tools/make_golden.py nattn);
+    the modes differ from each other and from the default by far more than the comparison tolerance."""
+    cfg0, usd, csd = tiny
+    G = torch.load(os.path.join(GOLD, "tiny_forward_nattn.pt"))
+    cfg = dict(cfg0); cfg["neighboring_attn_type"] = mode
+    sc = scene(cfg, 1, 3)
+    lat = torch.randn(1, 6, 4, 28, 50, generator=torch.Generator().manual_seed(G["lat_seed"]))
+    t = G["timesteps"]
+    with torch.no_grad():
+        d, m, ctx = D.controlnet_forward(csd, cfg, lat, t, sc["camera_param"], sc["bboxes_3d_data"], sc["prompt_embeds"], sc["bev_map"])
+        e = D.unet_forward(usd, cfg, lat.reshape(-1, 4, 28, 50), t.repeat_interleave(6), ctx, d, m)
+        e_add = D.unet_forward(usd, cfg0, lat.reshape(-1, 4, 28, 50), t.repeat_interleave(6), ctx, d, m)
+    assert rel_l2(e, G["eps_" + mode].float()) < 2e-3          # golden eps stored as fp16
+    other = "self" if mode == "concat" else "concat"
+    assert rel_l2(e, G["eps_" + other].float()) > 1e-2 and rel_l2(e, e_add) > 1e-2
+
+
 # ---------------------------------------------------------------- live reference (authoring container only)
 needs_ref = pytest.mark.skipif(not refshim.available(), reason="/root/reference not present")
 

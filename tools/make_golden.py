@@ -24,7 +24,8 @@ Fixtures
   tiny_vae_decode.pt  diffusers AutoencoderKL.decode (the reference's `vae`, pipeline_bev_controlnet.py:100-112) of a tiny decoder config
                     (spec.VAE_TINY_CONFIG, seeded weights) on 2 latents of 7x13.
 
-`python tools/make_golden.py unipc` / `... hires` / `... given` / `... vae` regenerate only that fixture.
+`python tools/make_golden.py unipc` / `... hires` / `... given` / `... vae` / `... nattn` regenerate only that fixture.
+  tiny_forward_nattn.pt  the reference UNet forward with neighboring_attn_type = concat and = self (same tiny weights and inputs).
 """
 import os
 import sys
@@ -116,6 +117,25 @@ def hires_fixture(out_dir, cfg0, usd, csd, meta, hw=(54, 96)):
     print("tiny_forward_hires: eps std", e.std().item(), "down0 |x|", d[0].abs().mean().item())
 
 
+def nattn_fixture(out_dir, cfg0, usd, csd, meta, hw=(28, 50)):
+    """neighboring_attn_type "concat" and "self" (blocks.py:106-142, 206-217): the UNet forward of the REAL reference on the same tiny
+    weights (the ControlNet has no cross-view attention: its residuals come from the default-mode golden's inputs)."""
+    out = {"meta": meta, "lat_seed": 13, "timesteps": torch.tensor([500])}
+    for mode in ("concat", "self"):
+        cfg = dict(cfg0); cfg["neighboring_attn_type"] = mode
+        ns, unet, cnet = ref_models.build_reference(cfg, usd, csd)
+        sc = scene(cfg, 1, 3, hw)
+        lat = torch.randn(1, 6, 4, *hw, generator=torch.Generator().manual_seed(13))
+        t = out["timesteps"]
+        with torch.no_grad():
+            d, m, ctx = cnet(lat, t, sc["camera_param"], sc["bboxes_3d_data"], sc["prompt_embeds"], sc["bev_map"], return_dict=False)
+            e = unet(lat.reshape(-1, 4, *hw), t.repeat_interleave(6), encoder_hidden_states=ctx,
+                     down_block_additional_residuals=d, mid_block_additional_residual=m).sample
+        out["eps_" + mode] = e.half()
+        print("tiny_forward_nattn", mode, "eps std", e.std().item())
+    torch.save(out, os.path.join(out_dir, "tiny_forward_nattn.pt"))
+
+
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
@@ -130,6 +150,8 @@ def main():
         return given_view_fixture(out_dir, cfg, usd, csd, meta)
     if sys.argv[1:] == ["vae"]:
         return vae_fixture(out_dir)
+    if sys.argv[1:] == ["nattn"]:
+        return nattn_fixture(out_dir, cfg, usd, csd, meta)
 
     # ---- module-level forwards
     ns, unet, cnet = ref_models.build_reference(cfg, usd, csd)
