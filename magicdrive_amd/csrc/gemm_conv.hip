@@ -393,10 +393,10 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
         p.splitk = keep;
         if (ok) return launch_gemm_xl(q, conv, bn_f, st);
     }
-    // K = 320 GEGLU with many rows: the 256 x 256 XL tile beats the weight-stationary kernel (384 views: 1757 vs 1994 us — the GELU
-    // epilogue weighs as much as the MFMAs there, and the XL tile has half the epilogue instructions per MFMA); the other K = 320
-    // projections stay on gemm_ws.hip (out-proj 318 vs 379 us).  MDX_XL_GEGLU320=0 restores the old route.
-    static const int xl_geglu320 = [] { const char* e = getenv("MDX_XL_GEGLU320"); return e ? atoi(e) : 1; }();
+    // K = 320 GEGLU with many rows: gemm_ws.hip (384 views: 1642 us) vs the 256 x 256 XL tile (1694-1757 us).  Before the ring of
+    // gemm_ws.hip really ran ahead (its DMA builtin drained the VM counter every slab: 1994 us) the XL tile was the faster one;
+    // MDX_XL_GEGLU320=1 selects it again.
+    static const int xl_geglu320 = [] { const char* e = getenv("MDX_XL_GEGLU320"); return e ? atoi(e) : 0; }();
     const bool geglu_xl = xl_geglu320 && xl_mode == 1 && impl == 0 && !conv && geglu && p.K == 320 && p.splitk <= 1 && ws_mode < 2 &&
                           xl_supported(p, false, 256) && (long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 1024;
     if (geglu_xl) return launch_gemm_xl(p, false, 256, st);

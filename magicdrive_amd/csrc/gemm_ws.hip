@@ -27,6 +27,31 @@ constexpr unsigned WS_RECORDS = 0x80000000u;   // 2 GiB window over A
 
 template <int N>
 __device__ __forceinline__ void ws_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// One LDS-DMA piece by inline asm (same statement as xl_glds in gemm_xl.hip).  The builtin (`__builtin_amdgcn_raw_ptr_buffer_load_lds`)
+// is modelled by hipcc as an LDS store of unknown extent: it put `s_waitcnt vmcnt(0)` in front of every slab's fragment reads, i.e.
+// every slab waited for the refills issued just before it — the three-stage ring never ran ahead (seen in the .s; round 2).
+typedef __attribute__((ext_vector_type(4))) unsigned ws_rsrc_t;
+__device__ __forceinline__ void ws_glds(const ws_rsrc_t rs, unsigned lds_addr, unsigned voff) {
+    unsigned keep;
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_addr), "v"(voff), "s"(rs)
+        : "memory");
+}
+// Workgroup barrier for the epilogue's LDS staging: waits for this wave's LDS traffic only.  `__syncthreads()` also drains the VM
+// counter whenever the compiler has loads / stores of its own outstanding (the residual fetch, the C stores) — and with them the
+// activation slabs the DMA ring has in flight for the NEXT tile.
+__device__ __forceinline__ void ws_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 // ST-stage LDS ring filled by LDS-DMA (buffer_load_dwordx4 ... lds): ST-1 slabs of the activation stream are in flight while
 // one is multiplied — a K = 320 slab is only 16 MFMAs per wave, far shorter than a memory round trip, and with register staging
@@ -91,7 +116,20 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
     }
 
     // ---- activation stream: DMA cursor (runs ST-1 slabs ahead of the multiply) ----
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, WS_RECORDS, 0x00020000);
+    ws_rsrc_t rsA;
+    {
+        const unsigned long long a_ = (unsigned long long)p.A;
+        rsA.x = __builtin_amdgcn_readfirstlane((unsigned)a_);
+        rsA.y = __builtin_amdgcn_readfirstlane((unsigned)(a_ >> 32) & 0xffffu);
+        rsA.z = WS_RECORDS; rsA.w = 0x00020000u;
+    }
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+    // The compiler cannot see the hand-counted DMA traffic on the VM counter: settle its bookkeeping for the registers loaded above
+    // (weights, bias) HERE, or it guards their first use inside the tile loop with `s_waitcnt vmcnt(0)` on every iteration.
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wf[ks].u.x), "+v"(wf[ks].u.y), "+v"(wf[ks].u.z), "+v"(wf[ks].u.w));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bA[g].x), "+v"(bA[g].y), "+v"(bA[g].z), "+v"(bA[g].w));
     const int crow = lane >> 3, cphys = lane & 7;
     unsigned r_row[PPW], r_coff[PPW];                            // row inside the tile; byte offset of the (swizzled) source chunk
 #pragma unroll
@@ -109,8 +147,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
     {                                                                                                                           \
         const unsigned m = (unsigned)(f_tile * BM) + r_row[j];                                                                  \
         const unsigned off = (f_cnt < total && m < (unsigned)p.M) ? m * ldab + (unsigned)(f_slab * BK * 2) + r_coff[j] : WS_OOB; \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                               \
-            rsA, (__attribute__((address_space(3))) void*)(smem + (f_cnt % ST) * STAGE + (wave * PPW + (j)) * 1024), 16, off, 0, 0, 0); \
+        ws_glds(rsA, lds0 + (unsigned)((f_cnt % ST) * STAGE + (wave * PPW + (j)) * 1024), off);                                 \
     }
 #define WS_ADVANCE()                                                                                                            \
     {                                                                                                                           \
@@ -174,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
         if (p.dbg & 2) continue;                                 // debug: main loop only
 #pragma unroll
         for (int pass = 0; pass < BM / ROWS_PASS; ++pass) {
-            if (pass > 0) __syncthreads();                       // previous pass's row walk is done with Cs
+            if (pass > 0) ws_lds_barrier();                       // previous pass's row walk is done with Cs
             if constexpr (VT) {
                 // V tile: lane = channel 32 wave + frow, accumulator register r = token (r&3) + 8 (r>>2) + 4 half of m-tile i
 #pragma unroll
@@ -192,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
                 }
-                __syncthreads();
+                ws_lds_barrier();
                 const int mp = m0 + pass * ROWS_PASS;
                 constexpr int CPRT = ROWS_PASS / 8;                                    // 16-byte token chunks per channel row
 #pragma unroll
@@ -237,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
             }
-            __syncthreads();
+            ws_lds_barrier();
             const int mp = m0 + pass * ROWS_PASS;
             if (p.wide) {
                 constexpr int CPR = BNO / 8, IT = ROWS_PASS * CPR / 256;     // 16-byte chunks per row; per thread: 4
@@ -249,8 +286,15 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
                     const int idx = tid + u * 256;
                     const int row = idx / CPR, c8 = (idx - row * CPR) * 8;
                     ok[u] = mp + row < p.M && n0o + c8 < Nout;
-                    rv[u] = make_uint4(0, 0, 0, 0);
-                    if (Rg && ok[u]) rv[u] = *(const uint4*)(Rg + (long)(mp + row) * p.ldr + n0o + c8);
+                }
+                if (Rg) {                                        // one batch of unconditional loads from clamped addresses (a guarded load
+#pragma unroll                                                   // becomes its own branch + full wait: four serial round trips per pass)
+                    for (int u = 0; u < IT; ++u) {
+                        const int idx = tid + u * 256;
+                        const int row = idx / CPR, c8 = (idx - row * CPR) * 8;
+                        const int rr = min(mp + row, p.M - 1), cc = min(n0o + c8, Nout - 8);
+                        rv[u] = *(const uint4*)(Rg + (long)rr * p.ldr + cc);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < IT; ++u) {

@@ -1,5 +1,5 @@
 """Worker of tests/test_routes_gpu.py::test_forced_routes: the library reads its routing switches (MDX_GEMM_XL, MDX_XL_BN, ...) from the
-environment ONCE per process, so every forced route runs in its own interpreter.  Usage: python tests/route_worker.py xl320|xl256|xl160|noxl|attn_q32|attn_d80|attn_old
+environment ONCE per process, so every forced route runs in its own interpreter.  Usage: python tests/route_worker.py xl320|xl256|xl160|noxl|geglu320xl|attn_q32|attn_d80|attn_old
 Prints ROUTE_WORKER_OK on success; any failure raises."""
 import os
 import sys
@@ -83,6 +83,11 @@ elif mode == "noxl":
     conv_case(22, 28, 28, 640, 640, expect="conv3x3_kernel")                                  # 28-px rows straddling 128-row tiles
     gemm_case(537600, 320, 320, res=True, expect="gemm_ws_kernel<plain>")                     # bench row count
     geglu_case(26400, 1280, 320, expect="gemm_ws_kernel<geglu>")                              # K = 320 GEGLU on the weight-stationary kernel
+elif mode == "geglu320xl":
+    assert os.environ.get("MDX_XL_GEGLU320") == "1"
+    from route_worker_helpers import geglu_check
+    k = geglu_check(26400, 1280, 320)
+    assert k == "gemm_xl_kernel<256x256,gemm>", k
 elif mode in ("attn_q32", "attn_d80", "attn_old"):
     # attention2.hip's other instantiations (32-query waves; head dim 80) and attention.hip at the same shapes, through the tests
     # of tests/test_kernels_gpu.py (their route assertion follows this process's switches)

@@ -143,11 +143,12 @@ def test_xl_conv(dev, B, H, W, Cin, Cout, stride, res, temb, expect):
     close(y, conv_ref(x, w, b, stride, (1, 1), tb, R), name=f"xl conv {B}x{H}x{W} {Cin}->{Cout}")
 
 
-def test_k320_geglu_large_goes_to_xl(dev):
-    """The level-0 GEGLU shape class (K = 320, >= 1024 tiles of 256 x 256): routed to the XL tile by default (gemm_conv.hip: geglu_xl)."""
+def test_k320_geglu_large_route(dev):
+    """The level-0 GEGLU shape class (K = 320, >= 1024 tiles of 256 x 256): the weight-stationary kernel by default; the XL tile with
+    MDX_XL_GEGLU320=1 runs in test_forced_routes[geglu320xl]."""
     from route_worker_helpers import geglu_check
     k = geglu_check(26400, 1280, 320)
-    assert k == "gemm_xl_kernel<256x256,gemm>", k
+    assert k == "gemm_ws_kernel<geglu>", k
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -176,6 +177,7 @@ def test_flattened_batched_vt(dev, Bt, T, Cc):
     ("xl256", {"MDX_GEMM_XL": "2", "MDX_XL_BN": "256"}),
     ("xl160", {"MDX_GEMM_XL": "2", "MDX_XL_BN": "160"}),
     ("noxl", {"MDX_GEMM_XL": "0"}),
+    ("geglu320xl", {"MDX_XL_GEGLU320": "1"}),
     ("attn_q32", {"MDX_ATTN2_QT": "1"}),
     ("attn_d80", {"MDX_ATTN2_D80": "1"}),
     ("attn_old", {"MDX_ATTN2": "0"}),
