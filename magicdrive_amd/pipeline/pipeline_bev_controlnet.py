@@ -192,6 +192,12 @@ class StableDiffusionBEVControlNetPipeline:
         return out
 
     # ---- the sampler ----
+    def _plan_config(self) -> Dict[str, Any]:
+        """Architecture config of the sampler plan: the UNet's, with the conditioning encoders' geometry taken from the ControlNet."""
+        cfg = dict(self.unet.cfg)
+        cfg["controlnet"] = self.controlnet.cfg["controlnet"]
+        return cfg
+
     @torch.no_grad()
     def __call__(self, prompt: Union[str, List[str], None], image: torch.Tensor, camera_param: Optional[torch.Tensor],
                  height: int, width: int, num_inference_steps: int = 50, guidance_scale: float = 7.5,
@@ -281,7 +287,7 @@ class StableDiffusionBEVControlNetPipeline:
                 # the UNet's config.json knows nothing about the conditioning encoders: their geometry (box MLP widths, map embedder
                 # class / size, camera frequencies) is the ControlNet checkpoint's (a tiny or a 272x736 `...Plus` checkpoint loaded with
                 # from_pretrained would otherwise be planned with the SD-1.5 defaults)
-                plan_cfg = dict(self.unet.cfg); plan_cfg["controlnet"] = self.controlnet.cfg["controlnet"]
+                plan_cfg = self._plan_config()
                 plan = SamplerPlan(plan_cfg, self.unet.packed(), self.controlnet.packed(), device, b, do_cfg, L_box, (h, w),
                                    num_steps=n_steps, guidance_scale=guidance_scale,
                                    conditioning_scale=float(controlnet_conditioning_scale), n_text=text.shape[1], scheduler_kind=sched_kind,

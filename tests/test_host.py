@@ -242,6 +242,27 @@ def test_build_pipe_call_sequence_replayed(tmp_path):
     assert torch.allclose(p2.scheduler.alphas_cumprod, schedulers.DDIMScheduler().alphas_cumprod)
 
 
+def test_plan_config_takes_conditioning_geometry_from_the_controlnet_checkpoint(tmp_path):
+    """A UNet loaded from its own config.json knows nothing about the box MLP widths / map embedder of the ControlNet checkpoint: the
+    sampler plan must be built with the ControlNet's (tiny checkpoint: proj_dims (64, 48, 48, 64), not SD-1.5's 768-wide defaults), and
+    such a plan must construct (CPU device: buffers + op list only)."""
+    from magicdrive_amd import denoiser as DN
+    tcfg = spec.with_plus_map_embedder(spec.TINY_CONFIG, (34, 46))
+    ckpt = tmp_path / "ckpt"
+    UNet2DConditionModelMultiview.from_config(tcfg, seed=0).save_pretrained(str(ckpt / "unet"))
+    BEVControlNetModel.from_config(tcfg, seed=1).save_pretrained(str(ckpt / "controlnet"))
+    unet = UNet2DConditionModelMultiview.from_pretrained(str(ckpt / "unet"))
+    cn = BEVControlNetModel.from_pretrained(str(ckpt / "controlnet"))
+    pipe = StableDiffusionBEVControlNetPipeline(unet=unet, controlnet=cn)
+    cfg = pipe._plan_config()
+    assert tuple(cfg["controlnet"]["bbox"]["proj_dims"]) == (64, 48, 48, 64) and cfg["controlnet"].get("map_embedder_cls")
+    assert tuple(unet.cfg["controlnet"]["bbox"]["proj_dims"]) != (64, 48, 48, 64), "the UNet's own config falls back to the SD-1.5 defaults"
+    from magicdrive_amd.engine import PackedNet
+    cpu = torch.device("cpu")
+    plan = DN.SamplerPlan(cfg, PackedNet(unet.state_dict(), cpu), PackedNet(cn.state_dict(), cpu), cpu, 1, True, 3, (34, 46), 2, guidance_scale=2.0)
+    assert len(plan.step_ops) > 100
+
+
 def test_prepare_latents_list_of_generators():
     """`fix_seed_within_batch` (misc/test_utils.py:224-237) passes one generator per scene; randn_tensor draws (1, ...) from each
     (third_party/diffusers/src/diffusers/utils/torch_utils.py:64-71)."""
