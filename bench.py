@@ -179,6 +179,8 @@ def main():
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if world > 1:                                               # N ranks generate 1.3 G random weights each on the host: share the cores
+        torch.set_num_threads(max(4, (os.cpu_count() or 8) // world))
     cfg = spec.SD15_CONFIG
     pipe, unet, cn = build_pipeline(cfg, dev, args.scheduler)
     pipe.use_graph = not args.no_graph
