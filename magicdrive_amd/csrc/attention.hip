@@ -120,18 +120,22 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
                     const int c = tid + i * NT;
                     const int row = c / (DP / 8);
                     const int cc = c - row * (DP / 8);
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (c < KTOT && j0 + row < p.Tk && cc * 8 < d) v = *(const uint4*)(kbase + (long)(j0 + row) * p.ldk + cc * 8);
-                    kreg[i] = v;
+                    // unconditional loads from clamped addresses, masked afterwards: a guarded load (`if (ok) v = load`) compiles to its own
+                    // branch with a full `s_waitcnt vmcnt(0)` inside — the tile's staging loads then ran one memory round trip after the other
+                    const bool ok = c < KTOT && j0 + row < p.Tk && cc * 8 < d;
+                    const int rr = min(j0 + row, p.Tk - 1), cq = min(cc * 8, d - 8);
+                    const uint4 v = *(const uint4*)(kbase + (long)rr * p.ldk + cq);
+                    kreg[i] = ok ? v : make_uint4(0, 0, 0, 0);
                 }
 #pragma unroll
                 for (int i = 0; i < VCH; ++i) {
                     const int c = tid + i * NT;
                     const int row = c >> 3;
                     const int kv0 = j0 + (c & 7) * 8;
+                    const bool ok = c < VTOT && row < d && kv0 < p.Tk;
                     Frag8 v;
-                    v.u = make_uint4(0, 0, 0, 0);
-                    if (c < VTOT && row < d && kv0 < p.Tk) v.u = *(const uint4*)(vbase + (long)row * p.ldv + kv0);
+                    v.u = *(const uint4*)(vbase + (long)min(row, d - 1) * p.ldv + (kv0 < p.Tk ? kv0 : 0));
+                    if (!ok) v.u = make_uint4(0, 0, 0, 0);
                     vreg[i] = v;
                 }
 #pragma unroll
