@@ -11,7 +11,7 @@ One bench "step" = one complete `pipe(...)` call: conditioning prologue + 50 den
 outside the built hot path).  Weak scaling: every rank samples its own scenes; the only
 collective is the final all_gather of the result latents (RCCL), inside the timed region.
 
-Launch: `python bench.py` (1 GPU) or
+Launch: `python bench.py` (1 GPU), `python bench.py --gpus N` (re-executes itself under torch.distributed.run with N ranks), or
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -144,6 +144,12 @@ def cpu_baseline(cfg, n_steps_timed=3):
             "cfg1_single_view_20step": cfg1}
 
 
+def launcher_command(gpus, argv, port):
+    """`python bench.py --gpus N` without a launcher becomes this command: one rank per GPU under torch.distributed.run, same flags."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,13 +178,26 @@ def main():
                          "adds per scene (config.vae_decode_ms_per_scene, config.scenes_per_s_incl_vae_decode); 0 skips it")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU over RCCL), same flags.  What the reference
+        # does with `accelerate launch` (perception/data_prepare/val_set_gen.py:71-87).
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(launcher_command(args.gpus, sys.argv[1:], port), env=env))
+
     from magicdrive_amd import distributed as DD
     from magicdrive_amd import synthetic, flops as FL
     from magicdrive_amd.networks import spec
     rank, world, local = DD.init_from_env()
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}: a line measured on fewer GPUs than it claims is worthless"
+    assert torch.cuda.device_count() > local, f"rank {rank}: local rank {local} but only {torch.cuda.device_count()} GPUs visible"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    n_devices = DD.assert_distinct_devices(dev, rank, world)    # N ranks on N different GPUs (uuid / PCI bus id gathered over the process group)
     if world > 1:                                               # N ranks generate 1.3 G random weights each on the host: share the cores
         torch.set_num_threads(max(4, (os.cpu_count() or 8) // world))
     cfg = spec.SD15_CONFIG
@@ -294,7 +313,7 @@ def main():
     f_scene = (args.ddim_steps * f_step["total"] + f_pro["total"]) / b          # per scene, incl. CFG duplication if any
     out = {
         "metric": "6-view scenes/sec at 224x400, 50-step DDIM" if (args.scheduler, args.ddim_steps) == ("ddim", 50) else f"6-view scenes/sec at 224x400, {args.ddim_steps}-step {args.scheduler}", "value": scenes_per_s, "unit": "scenes/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "n_gpus": n_devices, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": ("configs[2]: 6-view 224x400, camera+32 boxes+BEV map, CFG 2.0" if args.full_cond else
                                 f"configs[1]: 6-view 224x400, text-only conditioning (camera_param=None -> CFG off), {args.ddim_steps}-step {args.scheduler.upper() if args.scheduler == 'ddim' else 'UniPC'}, bf16"),

@@ -56,6 +56,28 @@ def gather_scene_results(local: torch.Tensor, n_scenes: int, rank: int, world: i
     return out
 
 
+def device_identity(device) -> str:
+    """A string that differs between physical GPUs of the node (uuid when the runtime reports one, else PCI ids + index)."""
+    pr = torch.cuda.get_device_properties(device)
+    parts = [str(getattr(pr, "uuid", "")), str(getattr(pr, "pci_bus_id", "")), str(getattr(pr, "pci_device_id", "")), str(getattr(pr, "pci_domain_id", ""))]
+    ident = "/".join(parts)
+    if ident.strip("/") == "":
+        ident = f"index{torch.device(device).index}"
+    return ident + f"#{torch.device(device).index}"
+
+
+def assert_distinct_devices(device, rank: int, world: int) -> int:
+    """Every rank must drive its own GPU: gathers device_identity() over the group and returns the number of distinct devices
+    (== world, asserted).  A launcher that put two ranks on one GPU would otherwise print a whole-job number for hardware it did not use."""
+    if world == 1:
+        return 1
+    ids: List[str] = [None] * world           # type: ignore[list-item]
+    dist.all_gather_object(ids, device_identity(device))
+    n = len(set(ids))
+    assert n == world, f"{world} ranks on {n} distinct GPUs: {ids}"
+    return n
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

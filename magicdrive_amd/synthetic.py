@@ -62,14 +62,14 @@ def boxes(g: torch.Generator, n_cam: int = 6, max_len: int = 32, n_classes: int 
 
 
 def make_scene_batch(batch: int, seed: int = 1234, ctx_dim: int = 768, max_len: Optional[int] = 32, latent_hw=(28, 50),
-                     n_cam: int = 6, with_camera: bool = True, zero_map: bool = False) -> Dict[str, object]:
+                     n_cam: int = 6, with_camera: bool = True, zero_map: bool = False, map_size: int = 200) -> Dict[str, object]:
     """Inputs for `batch` scenes; scene i uses seed + i so shards of a batch reproduce the same scenes."""
     pe, ne, maps, cams, bb, cl, mk, lat = [], [], [], [], [], [], [], []
     for i in range(batch):
         g = _gen(seed + i)
         pe.append(torch.randn(77, ctx_dim, generator=g))
         ne.append(torch.randn(77, ctx_dim, generator=g))
-        maps.append(torch.zeros(8, 200, 200) if zero_map else bev_map(g))
+        maps.append(torch.zeros(8, map_size, map_size) if zero_map else bev_map(g, size=map_size))
         cams.append(camera_param(g, n_cam))
         if max_len:
             b = boxes(g, n_cam, max_len)

@@ -42,3 +42,57 @@ def test_gather_two_ranks_gloo():
     for rank, vals, t in res:
         assert vals == [float(i) for i in range(n_scenes)], (rank, vals)
         assert t == 2.0
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus 8` (no WORLD_SIZE) must re-execute itself as 8 ranks, not measure one GPU and call it eight."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sp = importlib.util.spec_from_file_location("mdx_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(sp); sp.loader.exec_module(bench)
+    cmd = bench.launcher_command(8, ["--gpus", "8", "--steps", "3"], 12345)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--master-addr" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    src = open(os.path.join(root, "bench.py")).read()
+    assert "assert world == args.gpus," in src, "a WORLD_SIZE / --gpus mismatch must abort"
+
+
+def _nccl_worker(rank, world, port, n_scenes, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r, w, local = DD.init_from_env(backend="nccl")
+    dev = torch.device("cuda", local)
+    n_dev = DD.assert_distinct_devices(dev, r, w)
+    mine = DD.shard_scenes(n_scenes, r, w)
+    g = torch.Generator().manual_seed(5)
+    full = torch.randn(n_scenes, 6, 4, 7, 13, generator=g)                 # what ONE rank would have produced for all scenes
+    out = DD.gather_scene_results(full[mine].to(dev), n_scenes, r, w)
+    t = DD.max_over_ranks(float(rank + 1), dev)
+    DD.barrier(); torch.cuda.synchronize()
+    q.put((rank, bool(torch.equal(out.cpu(), full)), t, n_dev))
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_gather_two_ranks_nccl():
+    """The RCCL path itself (the only collective of the N > 1 bench): 2 ranks on 2 GPUs, result order and bit-equality with the
+    1-rank result.  Skipped on a 1-GPU box."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, t, n_dev in res:
+        assert same and t == 2.0 and n_dev == 2, (rank, same, t, n_dev)

@@ -25,8 +25,21 @@ Fixtures
                     (spec.VAE_TINY_CONFIG, seeded weights) on 2 latents of 7x13.
 
 `python tools/make_golden.py unipc` / `... hires` / `... given` / `... vae` / `... nattn` regenerate only that fixture.
+
+SD-1.5-SIZE fixtures (round 3; the REAL reference at spec.SD15_CONFIG, fp32 arithmetic on the bf16-rounded seeded weights — the
+weights the HIP model holds — so that the fixture measures arithmetic, not weight rounding; 8 host threads, minutes each):
+  sd15_loop50.pt    `... sd15`      BASELINE configs[1]: reference pipeline __call__ (pipeline_bev_controlnet.py:349-451), 1 scene,
+                    text-only (camera_param=None, zero map, no boxes), 50 DDIM steps; final latents + the latents after every 10th step (fp16).
+  sd15_loop_cfg.pt  `... sd15cfg`   BASELINE configs[2]: camera + 32 padded boxes per view + BEV map, guidance 2.0, 10 DDIM steps,
+                    latents after every 2nd step (fp16).
+  sd15_forward_hires.pt `... sd15hires`  BASELINE configs[3] shape at REAL width: 54x96 latents, ...Plus map encoder, one
+                    BEVControlNetModel.forward + UNet forward of 1 scene x 6 views, 3 boxes per view (eps fp16).
+  tiny_forward_272x736.pt `... res272`   configs/exp/272x736.yaml:15-22: 34x92 latents, ...Plus [34, 92] (tiny width).
+  tiny_forward_424x800.pt `... res424`   configs/exp/424x800abox0.1_nockpt.yaml:15-17: 53x100 latents, map_size [8, 400, 400] through the
+                    plain BEVControlNetConditioningEmbedding (tiny width).
   tiny_forward_nattn.pt  the reference UNet forward with neighboring_attn_type = concat and = self (same tiny weights and inputs).
 """
+import copy
 import os
 import sys
 
@@ -136,9 +149,103 @@ def nattn_fixture(out_dir, cfg0, usd, csd, meta, hw=(28, 50)):
     torch.save(out, os.path.join(out_dir, "tiny_forward_nattn.pt"))
 
 
+def _trace_cb(store, every):
+    def cb(i, t, latents):
+        if (i + 1) % every == 0:
+            store[i + 1] = latents.detach().half().clone()
+    return cb
+
+
+def sd15_loop_fixture(out_dir, full_cond):
+    """The headline configuration against the REAL reference."""
+    import time
+    from helpers import bf16_round
+    torch.set_num_threads(8)
+    cfg = spec.SD15_CONFIG
+    usd, csd = state_dicts(cfg)
+    usd, csd = bf16_round(usd), bf16_round(csd)
+    meta = {"unet_checksum": checksum(usd), "cn_checksum": checksum(csd), "torch": str(torch.__version__),
+            "weights": "spec.random_state_dict seeds (0, 1), bf16-rounded; reference arithmetic fp32"}
+    ns, pipe = ref_models.build_reference_pipeline(cfg, usd, csd)
+    trace = {}
+    t0 = time.time()
+    with torch.no_grad():
+        if not full_cond:
+            steps, every, name = 50, 10, "sd15_loop50.pt"
+            sc = scene(cfg, 1, None, (28, 50), zero_map=True)
+            out = pipe(prompt=None, image=sc["bev_map"], camera_param=None, height=224, width=400, num_inference_steps=steps, guidance_scale=2.0,
+                       latents=sc["latents"].clone(), prompt_embeds=sc["prompt_embeds"], negative_prompt_embeds=sc["negative_prompt_embeds"],
+                       output_type="latent", callback=_trace_cb(trace, every), callback_steps=1,
+                       bev_controlnet_kwargs={"bboxes_3d_data": None}).images
+        else:
+            steps, every, name = 10, 2, "sd15_loop_cfg.pt"
+            sc = scene(cfg, 1, 32, (28, 50))
+            out = pipe(prompt=None, image=sc["bev_map"], camera_param=sc["camera_param"], height=224, width=400, num_inference_steps=steps,
+                       guidance_scale=2.0, latents=sc["latents"].clone(), prompt_embeds=sc["prompt_embeds"],
+                       negative_prompt_embeds=sc["negative_prompt_embeds"], output_type="latent", callback=_trace_cb(trace, every), callback_steps=1,
+                       bev_controlnet_kwargs={"bboxes_3d_data": sc["bboxes_3d_data"]}).images
+    dt = time.time() - t0
+    meta["reference_seconds"] = dt; meta["reference_threads"] = torch.get_num_threads()
+    torch.save({"meta": meta, "steps": steps, "guidance": 2.0, "latents": out.half().clone(), "trace": trace,
+                "absmean": out.abs().mean().item()}, os.path.join(out_dir, name))
+    print(name, "|x|", out.abs().mean().item(), f"reference: {dt:.1f} s for {steps} steps = {dt / steps:.2f} s/step on {torch.get_num_threads()} threads",
+          os.path.getsize(os.path.join(out_dir, name)) // 1024, "KiB")
+
+
+def sd15_hires_fixture(out_dir, hw=(54, 96)):
+    from helpers import bf16_round
+    torch.set_num_threads(8)
+    cfg = spec.with_plus_map_embedder(spec.SD15_CONFIG, hw)
+    usd, csd = state_dicts(cfg)
+    usd, csd = bf16_round(usd), bf16_round(csd)
+    meta = {"unet_checksum": checksum(usd), "cn_checksum": checksum(csd), "torch": str(torch.__version__),
+            "weights": "spec.random_state_dict seeds (0, 1), bf16-rounded; reference arithmetic fp32"}
+    ns, unet, cnet = ref_models.build_reference(cfg, usd, csd, img_size=(hw[0] * 8, hw[1] * 8))
+    sc = scene(cfg, 1, 3, hw)
+    lat = torch.randn(1, 6, 4, *hw, generator=torch.Generator().manual_seed(11))
+    t = torch.tensor([741])
+    with torch.no_grad():
+        d, m, ctx = cnet(lat, t, sc["camera_param"], sc["bboxes_3d_data"], sc["prompt_embeds"], sc["bev_map"], return_dict=False)
+        e = unet(lat.reshape(-1, 4, *hw), t.repeat_interleave(6), encoder_hidden_states=ctx,
+                 down_block_additional_residuals=d, mid_block_additional_residual=m).sample
+    torch.save({"meta": meta, "lat_seed": 11, "timesteps": t, "hw": hw, "mid": m.half().clone(), "eps": e.half(),
+                "down_absmean": torch.tensor([x.abs().mean() for x in d])}, os.path.join(out_dir, "sd15_forward_hires.pt"))
+    print("sd15_forward_hires: eps std", e.std().item(), "mid |x|", m.abs().mean().item())
+
+
+def resolution_fixture(out_dir, cfg0, usd, meta, which):
+    """The reference's two other shipped resolutions at tiny width (module forwards of the REAL reference)."""
+    if which == "272x736":
+        hw = (34, 92)
+        cfg = spec.with_plus_map_embedder(cfg0, hw)                # configs/exp/272x736.yaml:15-22
+    else:
+        hw = (53, 100)
+        cfg = copy.deepcopy(cfg0); cfg["controlnet"]["map_size"] = (8, 400, 400)   # configs/exp/424x800abox0.1_nockpt.yaml:15-17
+    csd = spec.random_state_dict(spec.controlnet_param_shapes(cfg), 1)
+    meta = dict(meta); meta["cn_checksum"] = checksum(csd)
+    ns, unet, cnet = ref_models.build_reference(cfg, usd, csd, img_size=(hw[0] * 8, hw[1] * 8))
+    sc = scene(cfg, 1, 3, hw, map_size=cfg["controlnet"]["map_size"][1])
+    lat = torch.randn(1, 6, 4, *hw, generator=torch.Generator().manual_seed(17))
+    t = torch.tensor([333])
+    with torch.no_grad():
+        d, m, ctx = cnet(lat, t, sc["camera_param"], sc["bboxes_3d_data"], sc["prompt_embeds"], sc["bev_map"], return_dict=False)
+        e = unet(lat.reshape(-1, 4, *hw), t.repeat_interleave(6), encoder_hidden_states=ctx,
+                 down_block_additional_residuals=d, mid_block_additional_residual=m).sample
+    name = f"tiny_forward_{which}.pt"
+    torch.save({"meta": meta, "lat_seed": 17, "timesteps": t, "hw": hw, "mid": m.clone(), "eps": e.half(),
+                "down_absmean": torch.tensor([x.abs().mean() for x in d])}, os.path.join(out_dir, name))
+    print(name, "eps std", e.std().item(), "down0 |x|", d[0].abs().mean().item(), "map", tuple(sc["bev_map"].shape))
+
+
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    if sys.argv[1:] == ["sd15"]:
+        return sd15_loop_fixture(out_dir, False)
+    if sys.argv[1:] == ["sd15cfg"]:
+        return sd15_loop_fixture(out_dir, True)
+    if sys.argv[1:] == ["sd15hires"]:
+        return sd15_hires_fixture(out_dir)
     cfg = spec.TINY_CONFIG
     usd, csd = state_dicts(cfg)
     meta = {"unet_checksum": checksum(usd), "cn_checksum": checksum(csd), "torch": str(torch.__version__)}
@@ -152,6 +259,8 @@ def main():
         return vae_fixture(out_dir)
     if sys.argv[1:] == ["nattn"]:
         return nattn_fixture(out_dir, cfg, usd, csd, meta)
+    if sys.argv[1:] in (["res272"], ["res424"]):
+        return resolution_fixture(out_dir, cfg, usd, meta, "272x736" if sys.argv[1] == "res272" else "424x800")
 
     # ---- module-level forwards
     ns, unet, cnet = ref_models.build_reference(cfg, usd, csd)
