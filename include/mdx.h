@@ -42,7 +42,7 @@ extern "C" {
 #define MDX_ELAUNCH (-2)     /* hip launch / runtime error */
 #define MDX_EUNSUPPORTED (-3)
 
-#define MDX_ABI_VERSION 4
+#define MDX_ABI_VERSION 5
 
 /* ---- epilogue flags shared by GEMM / conv ------------------------------- */
 #define MDX_EPI_NONE 0
@@ -330,6 +330,15 @@ const char* mdx_last_error(void);
  * descriptor is routed to is decided inside the library by shape).  Measurement aid: bench.py groups its per-launch HIP-event
  * timings by this name so they can be compared with rocprofv3's kernel statistics. */
 const char* mdx_last_kernel(void);
+/* Tuning / routing switches (magicdrive_amd/csrc/options.h lists every key with its default and meaning, e.g. "GEMM_XL", "XL_BN",
+ * "ATTN2"): process-wide named integers that the launchers read on every call.  mdx_set_option returns MDX_EINVAL for an unknown
+ * key.  The reference has no counterpart (its kernel choice lives inside xformers' dispatch, ops/fmha/dispatch.py, and cuDNN's
+ * heuristics); they exist so that parity tests can force every main loop in-process and a profile can A/B a route.  mdx_option_name(i)
+ * enumerates the keys (NULL past the end).  Captured graphs keep the route they were captured with. */
+int mdx_set_option(const char* key, int64_t value);
+int mdx_get_option(const char* key, int64_t* value_out);
+const char* mdx_option_name(int64_t index);
+
 /* Device facts for bench/roofline bookkeeping: out[0]=CU count, out[1]=clock kHz, out[2]=HBM bytes. */
 int mdx_device_info(int64_t* out3);
 

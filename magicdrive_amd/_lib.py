@@ -13,7 +13,7 @@ from typing import Dict, List, Tuple
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDX_LIB_PATH") or os.path.join(_HERE, "libmdx.so")      # MDX_LIB_PATH: A/B a second build (tools only)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # opcodes (mdx.h)
 OP_GEMM, OP_CONV, OP_CONV_DIRECT, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM = 1, 2, 3, 4, 5, 6
@@ -67,7 +67,7 @@ ENTRY_OF_OP = {
 # every symbol include/mdx.h declares
 EXPORTS = sorted(set(ENTRY_OF_OP.values()) | {
     "mdx_program_run", "mdx_graph_create", "mdx_graph_launch", "mdx_graph_destroy",
-    "mdx_abi_version", "mdx_last_error", "mdx_last_kernel", "mdx_device_info"})
+    "mdx_abi_version", "mdx_last_error", "mdx_last_kernel", "mdx_device_info", "mdx_set_option", "mdx_get_option", "mdx_option_name"})
 
 
 class MdxOp(C.Structure):
@@ -116,6 +116,12 @@ def lib() -> C.CDLL:
     l.mdx_last_kernel.restype = C.c_char_p
     l.mdx_device_info.restype = C.c_int
     l.mdx_device_info.argtypes = [C.POINTER(C.c_int64)]
+    l.mdx_set_option.restype = C.c_int
+    l.mdx_set_option.argtypes = [C.c_char_p, C.c_int64]
+    l.mdx_get_option.restype = C.c_int
+    l.mdx_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_int64)]
+    l.mdx_option_name.restype = C.c_char_p
+    l.mdx_option_name.argtypes = [C.c_int64]
     if l.mdx_abi_version() != ABI_VERSION:
         raise MdxError(f"libmdx.so ABI {l.mdx_abi_version()} != expected {ABI_VERSION}")
     _LIB = l
@@ -168,6 +174,45 @@ class Program:
             self.destroy()
         except Exception:
             pass
+
+
+def set_option(key: str, value: int) -> None:
+    """Set a routing / tuning switch of the library (csrc/options.h) for this process; unknown keys raise MdxError."""
+    check(lib().mdx_set_option(key.encode(), int(value)), f"mdx_set_option({key})")
+
+
+def get_option(key: str) -> int:
+    v = C.c_int64(0)
+    check(lib().mdx_get_option(key.encode(), C.byref(v)), f"mdx_get_option({key})")
+    return int(v.value)
+
+
+def option_names() -> List[str]:
+    out, i = [], 0
+    while True:
+        n = lib().mdx_option_name(i)
+        if not n:
+            return out
+        out.append(n.decode()); i += 1
+
+
+class options:
+    """`with _lib.options(GEMM_XL=2, XL_BN=160): ...` — set switches for a block, restore the previous values after it."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+        self.prev: Dict[str, int] = {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.prev[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            set_option(k, v)
+        return False
 
 
 def device_info() -> Dict[str, int]:

@@ -10,6 +10,9 @@
 #include <set>
 #include <utility>
 #include "launch.h"
+#include "options.h"
+#include <atomic>
+#include <cstdlib>
 
 namespace mdx {
 char* error_buffer() {
@@ -34,9 +37,53 @@ int ensure_dyn_smem(const void* kernel, size_t bytes, const char* what) {
     done.insert(key);
     return MDX_OK;
 }
+// ---- options (options.h) ----------------------------------------------------------------------------------------------
+namespace {
+struct OptRow { const char* key; int64_t dflt; const char* doc; };
+const OptRow kOptRows[OPT_COUNT] = {
+#define MDX_OPT_ROW(key, dflt, doc) {#key, (int64_t)(dflt), doc},
+    MDX_OPTIONS(MDX_OPT_ROW)
+#undef MDX_OPT_ROW
+};
+std::atomic<int64_t> g_opt[OPT_COUNT];
+// defaults, then the MDX_<KEY> environment presets — once, when the library is loaded (before any launch can read a value)
+struct OptInit {
+    OptInit() {
+        for (int i = 0; i < OPT_COUNT; ++i) {
+            int64_t v = kOptRows[i].dflt;
+            char name[64];
+            snprintf(name, sizeof name, "MDX_%s", kOptRows[i].key);
+            if (const char* e = getenv(name)) v = strtoll(e, nullptr, 0);
+            g_opt[i].store(v, std::memory_order_relaxed);
+        }
+    }
+} g_opt_init;
+int find_opt(const char* key) {
+    if (!key) return -1;
+    if (!strncmp(key, "MDX_", 4)) key += 4;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcmp(key, kOptRows[i].key)) return i;
+    return -1;
+}
+}  // namespace
+int64_t opt(int id) { return g_opt[id].load(std::memory_order_relaxed); }
 }  // namespace mdx
 
 using namespace mdx;
+
+extern "C" int mdx_set_option(const char* key, int64_t value) {
+    const int i = find_opt(key);
+    if (i < 0) return set_error(MDX_EINVAL, "mdx_set_option: unknown key '%s' (see magicdrive_amd/csrc/options.h)", key ? key : "(null)");
+    g_opt[i].store(value, std::memory_order_relaxed);
+    return MDX_OK;
+}
+extern "C" int mdx_get_option(const char* key, int64_t* value_out) {
+    const int i = find_opt(key);
+    if (i < 0 || !value_out) return set_error(MDX_EINVAL, "mdx_get_option: unknown key '%s'", key ? key : "(null)");
+    *value_out = opt(i);
+    return MDX_OK;
+}
+extern "C" const char* mdx_option_name(int64_t index) { return (index >= 0 && index < OPT_COUNT) ? kOptRows[index].key : nullptr; }
 
 static int run_op(const MdxOp* op, hipStream_t st) {
     const void* d = op->desc;

@@ -24,8 +24,8 @@
 //     the two normalised outputs are summed in registers (blocks.py:213-217).
 #include "common.h"
 #include "launch.h"
+#include "options.h"
 #include "attn2.h"
-#include <cstdlib>
 
 namespace mdx {
 
@@ -304,7 +304,7 @@ template <int D16, int NW>
 static int launch_attn(const AttnParams& p, hipStream_t st) {
     AttnParams q = p;
     const int qblocks = (p.Tq + NW * 32 - 1) / (NW * 32);
-    static const int swz = [] { const char* e = getenv("MDX_ATTN_SWZ"); return e ? atoi(e) : 1; }();
+    const int swz = (int)opt(OPT_ATTN_SWZ);
     dim3 grid(qblocks, p.H, p.B);
     q.qblocks = 0;
     if (swz && qblocks > 1) {
@@ -328,10 +328,10 @@ static int launch_attn_nw(const AttnParams& p, hipStream_t st) {
     // T = 91, d = 160: 4 waves 103 us, 2 waves 152 us, 1 wave 448 us; T = 28: 39 / 44 / 71 us; cross-view at T = 28: 2 waves 73 vs 108 us).
     // With few (batch, head) pairs the sequence is split finer so that short sequences still spread over the chip.
     long blocks4 = (long)((p.Tq + 127) / 128) * p.H * p.B;
-    static const long thr4 = [] { const char* e = getenv("MDX_ATTN_NW4_BLOCKS"); return e ? atol(e) : 256L; }();
-    static const long thr8 = [] { const char* e = getenv("MDX_ATTN_NW8_BLOCKS"); return e ? atol(e) : (1L << 40); }();
+    const long thr4 = (long)opt(OPT_ATTN_NW4_BLOCKS);
+    const long thr8 = (long)opt(OPT_ATTN_NW8_BLOCKS);
     long blocks8 = (long)((p.Tq + 255) / 256) * p.H * p.B;
-    static const int force = [] { const char* e = getenv("MDX_ATTN_NW"); return e ? atoi(e) : 0; }();     // experiments: force 1 / 2 / 4 / 8 waves
+    const int force = (int)opt(OPT_ATTN_NW);     // experiments: force 1 / 2 / 4 / 8 waves
     if (force == 8) return launch_attn<D16, 8>(p, st);
     if (force == 4) return launch_attn<D16, 4>(p, st);
     if (force == 2) return launch_attn<D16, 2>(p, st);

@@ -23,9 +23,9 @@
 // MagicDrive's cross-view attention (magicdrive/networks/blocks.py:106-222); same C entry point (mdx_attention_bf16, include/mdx.h).
 #include "common.h"
 #include "launch.h"
+#include "options.h"
 #include "xl_layout.h"
 #include "attn2.h"
-#include <cstdlib>
 
 namespace mdx {
 
@@ -458,8 +458,8 @@ static int launch_attn2_d(const Attn2Params& p, hipStream_t st) {
 // Shapes the lean kernel takes (everything else stays on attention.hip): head dim 40 or 80, enough query blocks to fill the chip,
 // 16-byte aligned K rows / V^T rows, matrices within the 2 GiB DMA window.
 bool attn2_supported(const Attn2Params& p) {
-    static const int on = [] { const char* e = getenv("MDX_ATTN2"); return e ? atoi(e) : 1; }();
-    static const int d80 = [] { const char* e = getenv("MDX_ATTN2_D80"); return e ? atoi(e) : 0; }();   // d = 80: slower than attention.hip so far
+    const int on = (int)opt(OPT_ATTN2);
+    const int d80 = (int)opt(OPT_ATTN2_D80);   // d = 80: slower than attention.hip so far
     if (!on || (p.d != 40 && !(p.d == 80 && d80))) return false;
     if (p.Tq < 256 || (long)((p.Tq + 127) / 128) * p.H * p.B < 128) return false;
     if ((p.ldk % 8) || (p.ldv % 8) || (p.sK % 8) || (p.sV % 8) || (p.ldv < ((p.Tk + 7) / 8) * 8)) return false;
@@ -469,7 +469,7 @@ bool attn2_supported(const Attn2Params& p) {
 
 int launch_attn2(const Attn2Params& p, hipStream_t st) {
     // 64 queries per wave (see attn2_kernel) when there are enough queries per head; MDX_ATTN2_QT=1 forces 32
-    static const int qt = [] { const char* e = getenv("MDX_ATTN2_QT"); return e ? atoi(e) : 2; }();
+    const int qt = (int)opt(OPT_ATTN2_QT);
     const bool two = qt == 2 && p.Tq >= 512 && p.d == 40;
     if (p.d == 40) return two ? launch_attn2_d<5, 2>(p, st) : launch_attn2_d<5, 1>(p, st);
     return launch_attn2_d<10, 1>(p, st);

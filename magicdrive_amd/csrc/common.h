@@ -26,9 +26,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// erf GELU (attention.py:259-280 uses F.gelu's default, exact form).  erf by Abramowitz-Stegun 7.1.26
-// (|error| <= 1.5e-7, far below the bf16 output rounding of 4e-3 relative): 1 rcp + 1 exp + 6 fma instead of the
-// ~50-instruction libm erff — the GEGLU epilogue evaluates 8192 of these per 128x128 tile.
+// erf GELU (attention.py:259-280 uses F.gelu's default, exact form): gelu(x) = 0.5 x (1 + erf(x / sqrt 2)).
+// erf(z) = z P(z^2) on |z| <= 3 (clamped beyond: erf(3) = 1 - 2.2e-5), P = the degree-8 minimax polynomial of erf(z) / z in z^2 (linear
+// programme on 3000 points, tools/fit_erf.py): |error| <= 2.7e-5 in fp32 Horner arithmetic — 150x below the bf16 rounding of the
+// product it feeds (2^-9 relative).  14 full-rate VALU operations and NO transcendental: the GEGLU epilogue of the level-0 feed-forward
+// evaluates 1.4 G of these per launch and was VALU-bound on the round-2 form (Abramowitz-Stegun 7.1.26: 13 operations + v_rcp_f32 +
+// v_exp_f32 at quarter rate = 21 issue slots; profiles/README.md round 3).  -DMDX_GELU_AS selects the old form (A/B side builds).
+#ifdef MDX_GELU_AS
 __device__ __forceinline__ float erf_as_f(float x) {
     const float ax = fabsf(x);
     const float t = __frcp_rn(1.0f + 0.3275911f * ax);
@@ -41,6 +45,26 @@ __device__ __forceinline__ float erf_as_f(float x) {
     return copysignf(y, x);
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f)); }
+#else
+__device__ __forceinline__ float erf_poly_f(float z) {
+    const float zc = __builtin_amdgcn_fmed3f(z, -3.0f, 3.0f);
+    const float u = zc * zc;
+    float p = 4.074397617e-08f;
+    p = __builtin_fmaf(p, u, -1.944883433e-06f);
+    p = __builtin_fmaf(p, u, 4.106127751e-05f);
+    p = __builtin_fmaf(p, u, -5.110412727e-04f);
+    p = __builtin_fmaf(p, u, 4.235439367e-03f);
+    p = __builtin_fmaf(p, u, -2.510287440e-02f);
+    p = __builtin_fmaf(p, u, 1.110793533e-01f);
+    p = __builtin_fmaf(p, u, -3.753149504e-01f);
+    p = __builtin_fmaf(p, u, 1.128268531e+00f);
+    return zc * p;
+}
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    const float hx = 0.5f * x;
+    return __builtin_fmaf(hx, erf_poly_f(x * 0.70710678118654752440f), hx);
+}
+#endif
 
 union Frag8 {
     uint4 u;

@@ -16,8 +16,8 @@
 // (channel block, ky, kx): a permutation of the reduction, same fp32 accumulation.
 #include "common.h"
 #include "launch.h"
+#include "options.h"
 #include "gemm_params.h"
-#include <cstdlib>
 
 namespace mdx {
 
@@ -192,9 +192,9 @@ int launch_conv3x3(const GCParams& p, hipStream_t st) {
     if (int rc = ensure_dyn_smem((const void*)conv3x3_kernel, smem, "conv3x3")) return rc;
     GCParams q = p;
     q.mt = (p.M + BM - 1) / BM; q.nt = (p.N + BN - 1) / BN;
-    static const int swz = [] { const char* e = getenv("MDX_GEMM_SWZ"); return e ? atoi(e) : 1; }();
+    const int swz = (int)opt(OPT_GEMM_SWZ);
     q.swz = swz && q.nt > 1 && q.mt >= 128;
-    static const int dbg = [] { const char* e = getenv("MDX_C3_DBG"); return e ? atoi(e) : 0; }();
+    const int dbg = (int)opt(OPT_C3_DBG);
     q.dbg = dbg;
     const unsigned nblk = q.swz ? (unsigned)((q.mt + 7) / 8 * 8 * q.nt) : (unsigned)(q.mt * q.nt);
     hipLaunchKernelGGL(conv3x3_kernel, dim3(nblk), dim3(256), smem, st, q);

@@ -21,21 +21,16 @@
 // Reference semantics replaced: ATen conv2d/addmm call sites listed in include/mdx.h.
 #include "common.h"
 #include "launch.h"
+#include "options.h"
 #include "gemm_params.h"
-#include <cstdlib>
 
 namespace mdx {
 
 
-int launch_gemm_dma(const GCParams& p, bool conv, int tile, hipStream_t st);
-void dma_tile_dims(int tile, int* bm, int* bn);
-int launch_gemm_pp(const GCParams& p, bool conv, int cfg, hipStream_t st);      // gemm_pp.hip: 256-row ping-pong tiles
-bool pp_supported(const GCParams& p, int cfg);
 int launch_conv3x3(const GCParams& p, hipStream_t st);                          // conv3x3.hip: 3x3/s1/p1 conv, A slab shared by 3 taps
 bool conv3x3_supported(const GCParams& p);
 int launch_gemm_ws(const GCParams& p, hipStream_t st);                          // gemm_ws.hip: weight-stationary K = 320 GEMM
 bool ws_supported(const GCParams& p);
-void pp_tile_dims(int cfg, int* bm, int* bn);
 int launch_gemm_xl(const GCParams& p, bool conv, int bn, hipStream_t st);       // gemm_xl.hip: 256 x {256,160} LDS-DMA quadrant-phase tiles
 bool xl_supported(const GCParams& p, bool conv, int bn);
 
@@ -317,7 +312,7 @@ static int launch_one_(const GCParams& p, hipStream_t st) {
     if (int rc = ensure_dyn_smem((const void*)kern, smem, "gemm_conv")) return rc;
     GCParams q = p;
     q.mt = (p.M + BM - 1) / BM; q.nt = (p.N + BN - 1) / BN;
-    static const int swz = [] { const char* e = getenv("MDX_GEMM_SWZ"); return e ? atoi(e) : 1; }();
+    const int swz = (int)opt(OPT_GEMM_SWZ);
     q.swz = swz && q.nt > 1 && q.mt >= 128;   // pays when A (activations) dwarfs W; mid-size M prefers W-tile reuse (measured)
     const unsigned nblk = q.swz ? (unsigned)((q.mt + 7) / 8 * 8 * q.nt) : (unsigned)(q.mt * q.nt);
     dim3 grid(nblk, 1, p.batch > 1 ? p.batch : p.splitk);
@@ -330,44 +325,47 @@ static int launch_one_(const GCParams& p, hipStream_t st) {
 // MDX_GEMM_PIPE (default 1): software-pipelined fragment reads for the 128x128x64 GEMM tile (the one with registers to spare).
 template <int BM, int BN, int BK, int WM, int WN, bool CONV>
 static int launch_one(const GCParams& p, hipStream_t st) {
-    static const int pipe = [] { const char* e = getenv("MDX_GEMM_PIPE"); return e ? atoi(e) : 1; }();
+    const int pipe = (int)opt(OPT_GEMM_PIPE);
     if constexpr (BM == 128 && BN == 128 && BK == 64 && WM == 2 && WN == 2) {
         if (pipe) return launch_one_<BM, BN, BK, WM, WN, CONV, true>(p, st);
     }
     return launch_one_<BM, BN, BK, WM, WN, CONV, false>(p, st);
 }
 
-// Tile / split-K choice.  The chip has 256 CUs.
-//   MDX_GEMM_IMPL=0 : register-staged main loop (gemm_conv_kernel), 128/64 tiles (default; the specialised kernels —
-//                     gemm_ws.hip, gemm_pp.hip, conv3x3.hip — are tried first, each behind its own switch)
-//   MDX_GEMM_IMPL=1 : LDS-DMA ring main loop (gemm_dma_kernel), tile picked per shape (kept for comparison: slower, profiles/README.md)
-//   MDX_GEMM_IMPL=10+t : LDS-DMA with tile id t forced (benchmarking)
+// Routing (four main loops; options.h lists the switches, all settable in-process through mdx_set_option):
+//   gemm_ws.hip   K = 320 projections / GEGLU with M >= 8192 (level 0 of the UNet): weights in registers, activations streamed
+//   gemm_xl.hip   every conv with Cin % 64 == 0 and every GEMM with K % 64 == 0 that yields >= xl_min_tiles 256-row tiles
+//                 (>= ~8 scenes per GPU at level 0, >= ~32 at the 7x13 level): 256 x {160, 256, 320} LDS-DMA tiles
+//   conv3x3.hip   3x3 / s1 / p1 convs with M >= 4096 that XL declined (1-7 scenes per GPU: too few 256-row tiles to fill 256 CUs)
+//   this file     everything else: 128 / 64-row register-staged tiles, split-K for the 7x13 / 4x7 levels at small batches
+// (round 3 removed gemm_dma.hip — an LDS-DMA ring that never beat register staging — and gemm_pp.hip, whose 256 x 256 ping-pong tile
+// was superseded by gemm_xl.hip at every batch where it used to be chosen.)
 int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MDX_OK;
     const bool geglu = p.epi == 1;
     {   // 16-byte epilogue accesses need 16-byte aligned rows of C and R and whole 8-column chunks
         const long nout = geglu ? p.N / 2 : p.N;
-        static const int wide_on = [] { const char* e = getenv("MDX_EPI_WIDE"); return e ? atoi(e) : 1; }();
+        const int wide_on = (int)opt(OPT_EPI_WIDE);
         p.wide = wide_on && !p.c_f32 && (nout % 8) == 0 && (p.ldc % 8) == 0 && (p.sC % 8) == 0 && (((uintptr_t)p.C) & 15) == 0 &&
                  (!p.R || ((p.ldr % 8) == 0 && (p.sR % 8) == 0 && (((uintptr_t)p.R) & 15) == 0));
     }
     if (geglu && (p.N % 64) != 0) return set_error(MDX_EINVAL, "GEGLU needs packed N %% 64 == 0 (N=%d)", p.N);
-    static const int impl = [] { const char* e = getenv("MDX_GEMM_IMPL"); return e ? atoi(e) : 0; }();
+    constexpr int impl = 0;
     // K = 320 projections with many rows: weights in registers, activations streamed (gemm_ws.hip).  MDX_GEMM_WS: 0 off, 1 when
     // M >= 8192 (default), 2 whenever supported.
-    static const int ws_mode = [] { const char* e = getenv("MDX_GEMM_WS"); return e ? atoi(e) : 1; }();
+    const int ws_mode = (int)opt(OPT_GEMM_WS);
     // Large shapes: the LDS-DMA quadrant-phase kernel (gemm_xl.hip).  MDX_GEMM_XL: 0 off, 1 cost model (default), 2 whenever supported.
     // Tile width: 256 columns, or 160 when that wastes fewer padded columns (N = 320 / 640 / 960 / 1920); a launch must give most of
     // the 256 CUs a tile (one workgroup per CU).  MDX_XL_K320 = 1 lets it take the K = 320 projections from gemm_ws.hip as well.
-    static const int xl_mode = [] { const char* e = getenv("MDX_GEMM_XL"); return e ? atoi(e) : 1; }();
-    static const int xl_k320 = [] { const char* e = getenv("MDX_XL_K320"); return e ? atoi(e) : 0; }();
-    static const int xl_min_tiles = [] { const char* e = getenv("MDX_XL_MIN_TILES"); return e ? atoi(e) : 160; }();
+    const int xl_mode = (int)opt(OPT_GEMM_XL);
+    const int xl_k320 = (int)opt(OPT_XL_K320);
+    const int xl_min_tiles = (int)opt(OPT_XL_MIN_TILES);
     // Width choice: time model fitted on MI355X at 384 views (profiles/README.md, round 2): a tile costs a(bn) + b(bn) * K/64
     // microseconds — b falls with the tile width (operand bytes per MAC through the global -> LDS path), a (prologue + the
     // HBM-bound epilogue burst; the 320-wide tile stages C in two halves) rises — times the rounds of tiles over the 256 CUs.
     auto try_xl = [&](int& bn_out) -> bool {
         if (impl != 0 || xl_mode <= 0 || p.splitk > 1) return false;
-        static const int xl_bn = [] { const char* e = getenv("MDX_XL_BN"); return e ? atoi(e) : 0; }();   // benchmarking: force a width
+        const int xl_bn = (int)opt(OPT_XL_BN);   // benchmarking: force a width
         double best = 1e300;
         bn_out = 0;
         const double nslab = p.K / 64.0;
@@ -396,35 +394,20 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
     // K = 320 GEGLU with many rows: gemm_ws.hip (384 views: 1642 us) vs the 256 x 256 XL tile (1694-1757 us).  Before the ring of
     // gemm_ws.hip really ran ahead (its DMA builtin drained the VM counter every slab: 1994 us) the XL tile was the faster one;
     // MDX_XL_GEGLU320=1 selects it again.
-    static const int xl_geglu320 = [] { const char* e = getenv("MDX_XL_GEGLU320"); return e ? atoi(e) : 0; }();
+    const int xl_geglu320 = (int)opt(OPT_XL_GEGLU320);
     const bool geglu_xl = xl_geglu320 && xl_mode == 1 && impl == 0 && !conv && geglu && p.K == 320 && p.splitk <= 1 && ws_mode < 2 &&
                           xl_supported(p, false, 256) && (long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 1024;
     if (geglu_xl) return launch_gemm_xl(p, false, 256, st);
     const bool ws_first = !conv && ws_mode > 0 && p.splitk <= 1 && ws_supported(p) && (ws_mode >= 2 || p.M >= 8192);
     if (impl == 0 && ws_first && !(xl_k320 && xl_mode > 0))
         return launch_gemm_ws(p, st);
-    int BM, BN, tile = -1;
-    if (impl == 0) {
+    int BM, BN;
+    {
         BN = 128;
         if (!geglu && (p.N <= 64 || (p.N % 128 != 0 && p.N <= 192))) BN = 64;
         BM = p.M >= 2048 ? 128 : 64;
-        static const int big = [] { const char* e = getenv("MDX_GEMM_BM256"); return e ? atoi(e) : 0; }();
+        const int big = (int)opt(OPT_GEMM_BM256);
         if (big && BN == 128 && p.M >= big) BM = 256;
-    } else {
-        if (impl >= 10) {
-            tile = impl - 10;
-        } else {
-            const long nb = p.batch > 1 ? p.batch : 1;
-            auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * nb; };
-            // biggest tile that still gives every CU a block; N tails waste MFMA work, so prefer BN that divides N
-            if (p.N >= 256 && p.N % 256 == 0 && blocks(256, 256) >= 200) tile = 2;
-            else if (p.N >= 96 && blocks(256, 128) >= 200) tile = 1;
-            else if (p.N >= 96 && blocks(128, 128) >= 128) tile = 0;
-            else if (p.N >= 96) tile = p.M > 64 ? 0 : 3;
-            else tile = p.M >= 2048 ? 4 : 5;
-        }
-        if (geglu && (tile == 4 || tile == 5)) tile = 3;
-        dma_tile_dims(tile, &BM, &BN);
     }
     long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.batch > 1 ? p.batch : 1);
     int splitk = 1;
@@ -448,47 +431,21 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
     if (splitk > 1 && !p.ws) return set_error(MDX_EINVAL, "split-K needs a workspace");
     p.splitk = splitk;
     p.kchunk = kchunk;
-    static const int timing = [] { const char* e = getenv("MDX_GEMM_TIMING"); return e ? atoi(e) : 0; }();
+    const int timing = (int)opt(OPT_GEMM_TIMING);
     p.timing = (timing && p.ws && splitk == 1) ? (unsigned long long*)p.ws : nullptr;
-    // Large shapes: the 256-row ping-pong kernel (gemm_pp.hip).  MDX_GEMM_PP: 0 off, 1 cost model (default), 2 whenever supported.
-    // Cost model: rounds of tiles over the 256 CUs x tile area / relative per-tile efficiency.  Measured (tools/kbench.py, 96 views):
-    // the 256 x 256 tile is 1.16-1.25x the 128 x 128 kernel per FLOP when N % 256 == 0 and K >= 1024 (N = 1280 convs 763 -> 888,
-    // end to end at 64 scenes/GPU: +3.2 % with gain 1.18, +3.8 % with 1.5 — the default);
-    // 612 -> 764 TFLOP/s); the 256 x 320 tile (N = 320 / 640) spills and loses, so it is opt-in (MDX_PP_CFG1=1).
     if (splitk == 1) {
         int bn_xl;
         if (try_xl(bn_xl)) return launch_gemm_xl(p, conv, bn_xl, st);
     }
     if (impl == 0 && ws_first) return launch_gemm_ws(p, st);       // MDX_XL_K320 was set but the XL kernel declined the shape
-    static const int pp_mode = [] { const char* e = getenv("MDX_GEMM_PP"); return e ? atoi(e) : 1; }();
-    static const double pp_gain = [] { const char* e = getenv("MDX_PP_GAIN"); return e ? atof(e) : 1.5; }();
-    static const int pp_cfg1 = [] { const char* e = getenv("MDX_PP_CFG1"); return e ? atoi(e) : 0; }();
-    if (impl == 0 && pp_mode > 0 && splitk == 1) {
-        const double cost_old = (double)((tiles + 511) / 512) * 2.0 * BM * BN;   // two co-resident workgroups share a CU
-        int best = -1;
-        double best_cost = pp_mode >= 2 ? 1e300 : cost_old;
-        for (int cfg = 0; cfg < 2; ++cfg) {
-            if (!pp_supported(p, cfg)) continue;
-            if (pp_mode < 2 && (p.K < 1024 || p.M < 4096 || (cfg == 0 && p.N % 256) || (cfg == 1 && !pp_cfg1))) continue;
-            int bm, bn;
-            pp_tile_dims(cfg, &bm, &bn);
-            const long t = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-            const double c = (double)((t + 255) / 256) * bm * bn / pp_gain;
-            if (c < best_cost) { best_cost = c; best = cfg; }
-        }
-        if (best >= 0) return launch_gemm_pp(p, conv, best, st);
-    }
     // 3x3 / stride 1 / pad 1 convs with enough rows for 128-row tiles: conv3x3.hip.  MDX_CONV3: 0 off, 1 when M >= 4096 (default).
-    // Runs after the ping-pong cost model: N % 256 == 0 convs with K >= 1024 stay on gemm_pp.hip (927 vs 851 TFLOP/s measured).
-    static const int c3_mode = [] { const char* e = getenv("MDX_CONV3"); return e ? atoi(e) : 1; }();
+    const int c3_mode = (int)opt(OPT_CONV3);
     if (impl == 0 && conv && c3_mode > 0 && splitk == 1 && conv3x3_supported(p) && p.M >= 4096 && (p.N % 4) == 0) {
         return launch_conv3x3(p, st);                                              // (small grids were given split-K above)
     }
     int rc;
-    if (impl != 0) {
-        rc = launch_gemm_dma(p, conv, tile, st);
-    } else {
-        static const int bk = [] { const char* e = getenv("MDX_GEMM_BK"); return e ? atoi(e) : 64; }();
+    {
+        const int bk = (int)opt(OPT_GEMM_BK);
 #define MDX_GC2(BM_, BN_, BK_, WM_, WN_) (conv ? launch_one<BM_, BN_, BK_, WM_, WN_, true>(p, st) : launch_one<BM_, BN_, BK_, WM_, WN_, false>(p, st))
 #define MDX_GC(BM_, BN_) (bk == 32 ? MDX_GC2(BM_, BN_, 32, 2, 2) : MDX_GC2(BM_, BN_, 64, 2, 2))
         if (BM == 256 && BN == 128) rc = (bk == 32) ? MDX_GC2(256, 128, 32, 4, 2) : MDX_GC2(256, 128, 64, 4, 2);
@@ -526,7 +483,7 @@ static int check_common(int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int64_
 // One XL launch for a batch-flattened GEMM (see mdx_gemm_bf16); MDX_EUNSUPPORTED when the XL kernel does not take the shape.
 static int launch_gemm_flat(const mdx::GCParams& q, hipStream_t st) {
     using namespace mdx;
-    static const int xl_mode = [] { const char* e = getenv("MDX_GEMM_XL"); return e ? atoi(e) : 1; }();
+    const int xl_mode = (int)opt(OPT_GEMM_XL);
     if (xl_mode <= 0) return MDX_EUNSUPPORTED;
     double best = 1e300; int bn_best = 0;
     for (int bn : {320, 256, 160}) {
@@ -573,7 +530,7 @@ extern "C" int mdx_gemm_bf16(const MdxGemmDesc* d, void* stream) {
     // Batched GEMM with a shared A and W batches that are rows of ONE matrix (the per-view V^T projections at levels 1 and 2: 384
     // products of 640 x 350 x 640): run it as a single GEMM over all batches' columns on the XL main loop, the epilogue scattering
     // each column to its batch (GCParams.col_split).  MDX_GEMM_FLATTEN=0 keeps the per-batch launches.
-    static const int flatten = [] { const char* e = getenv("MDX_GEMM_FLATTEN"); return e ? atoi(e) : 1; }();
+    const int flatten = (int)opt(OPT_GEMM_FLATTEN);
     if (flatten && p.batch > 1 && p.sA == 0 && p.sW == (long)p.N * p.ldw && !p.bias && !p.temb && !p.R && !p.epi && !p.c_f32 && p.splitk <= 1 &&
         (long)p.batch * p.N < 0x7fffff00L && ((long)p.batch * p.N) % 4 == 0) {
         GCParams q = p;
@@ -603,7 +560,7 @@ extern "C" int mdx_conv2d_bf16(const MdxConvDesc* d, void* stream) {
     p.epi = (int)d->epilogue; p.splitk = (int)d->splitk; p.c_f32 = 0; p.ws_bytes = d->ws_bytes;
     p.Hi = (int)d->Hi; p.Wi = (int)d->Wi; p.Cin = (int)d->Cin; p.Ho = (int)d->Ho; p.Wo = (int)d->Wo;
     p.kh = (int)d->kh; p.kw = (int)d->kw; p.sh = (int)d->sh; p.sw = (int)d->sw; p.ph = (int)d->ph; p.pw = (int)d->pw;
-    static const int cim = [] { const char* e = getenv("MDX_CONV_CIMAJOR"); return e ? atoi(e) : 1; }();
+    const int cim = (int)opt(OPT_CONV_CIMAJOR);
     p.cimajor = (cim && d->kh * d->kw > 1 && d->Cin % 64 == 0) ? 1 : 0;
     return launch_gemm_conv(p, true, (hipStream_t)stream);
 }

@@ -15,7 +15,8 @@ struct GCParams {
     int rows_per_b;
     int epi, splitk, kchunk, c_f32, batch;
     long ws_bytes;
-    int mt, nt, swz;              // tile counts along M / N; swz: XCD-aware tile order (1-D grid)
+    int mt, nt, swz;              // tile counts along M / N; swz: XCD-aware tile order (1-D grid); gemm_xl.hip: 2 = XCD-blocked panels
+    int gm, gn;                   // swz == 2: an XCD walks panels of gm M-tiles x gn N-tiles (xl_tile_coords in gemm_xl.hip)
     unsigned long long* timing;   // debug: per-block s_memtime stamps (MDX_GEMM_TIMING=1), else null
     // conv geometry (CONV only); lda doubles as the pixel stride of X
     int Hi, Wi, Cin, Ho, Wo, kh, kw, sh, sw, ph, pw;

@@ -17,8 +17,8 @@
 // residual added from 16-byte loads.  Same arithmetic per output element as gemm_conv.hip (k ascending, fp32 accumulation).
 #include "common.h"
 #include "launch.h"
+#include "options.h"
 #include "gemm_params.h"
-#include <cstdlib>
 
 namespace mdx {
 
@@ -353,13 +353,13 @@ static int launch_ws_one(const GCParams& p, hipStream_t st) {
     GCParams q = p;
     q.mt = (p.M + 127) / 128; q.nt = (p.N + 127) / 128;
     // walkers per N-tile: fill the 512 workgroup slots (2 per CU), multiple of 8 (one XCD per walker), at most one per M-tile
-    static const int slots = [] { const char* e = getenv("MDX_WS_SLOTS"); return e ? atoi(e) : 512; }();
+    const int slots = (int)opt(OPT_WS_SLOTS);
     int nwalk = slots / q.nt / 8 * 8;
     if (nwalk < 8) nwalk = 8;
     const int mt8 = (q.mt + 7) / 8 * 8;
     if (nwalk > mt8) nwalk = mt8;
     q.swz = nwalk;
-    static const int dbg = [] { const char* e = getenv("MDX_WS_DBG"); return e ? atoi(e) : 0; }();
+    const int dbg = (int)opt(OPT_WS_DBG);
     q.dbg = dbg;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nwalk * q.nt)), dim3(256), smem, st, q);
     return check_launch(GEGLU ? "gemm_ws_kernel<geglu>" : (VT ? "gemm_ws_kernel<vT>" : "gemm_ws_kernel<plain>"));

@@ -26,9 +26,9 @@
 // attention_processor.py:141-157) at shapes with >= ~200 tiles.
 #include "common.h"
 #include "launch.h"
+#include "options.h"
 #include "gemm_params.h"
 #include "xl_layout.h"
-#include <cstdlib>
 
 namespace mdx {
 
@@ -77,6 +77,16 @@ __device__ __forceinline__ void xl_glds(const xl_rsrc_t rs, unsigned lds_addr, u
         : "memory");
 }
 
+// Tile order.  swz == 2 ("XCD-blocked panels", round 3; index math in xl_layout.h: raster_tile): the 32 workgroups an XCD runs side
+// by side are ONE panel of gm M-tiles x gn N-tiles, so the operand bytes that XCD's L2 takes in per round of tiles are gm A-panels +
+// gn W-panels instead of ~32 / nt A-panels + nt W-panels: at N = 5120 (20 N-tiles) the round-2 order streamed the whole 6.5 MB weight
+// matrix through every 4 MiB L2 once per 1.6 M-tiles (13x read over-fetch, 60 % L2 hits: profiles/r02_pmc_summary.json); contiguous
+// M-tiles also share their 3x3 halo rows inside one L2 (conv).
+__device__ __forceinline__ bool xl_tile_coords(const GCParams& p, int& tm, int& tn) {
+    if (p.swz != 2) return tile_coords(p, tm, tn);
+    return raster_tile((int)blockIdx.x, p.mt, p.nt, p.gm, p.gn, &tm, &tn);
+}
+
 template <int BN, bool CONV, int SCHED>
 __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
     using G = Geo<BN>;
@@ -92,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
     const int grp = wave >> 2;                                  // waves w and w + 4 share a SIMD
     const int wm = wave % G::WM, wn = wave / G::WM;
     int tile_m, tile_n;
-    if (!tile_coords(p, tile_m, tile_n)) return;
+    if (!xl_tile_coords(p, tile_m, tile_n)) return;
     // MDX_XL_TIMING=1 (tools/xl_timing.py): s_memtime stamps of wave 0 at 0 entry, 1 bookkeeping done (first DMA issue), 2 first slab
     // landed, 3 main loop done, 4 C tile staged (last half), 5 stores issued — (6 after the epilogue's first barrier, 7 accumulators staged, before the second barrier) — 8 x 8 bytes per workgroup into the caller's workspace
     unsigned long long ts_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
         }
         return T * 128;
     };
-    // Debug ablations (MDX_XL_DBG: 1 skip the MFMAs, 2 skip the DMA) exist only in builds with -DMDX_XL_ABLATE: a runtime test inside
+    // Debug ablations (XL_DBG: 1 skip the MFMAs, 2 skip the DMA, 4 return after the main loop, 8 stage C but store nothing) exist only in builds with -DMDX_XL_ABLATE: a runtime test inside
     // the MFMA clusters splits their scheduling regions.
 #ifdef MDX_XL_ABLATE
     const bool do_mma = !(p.dbg & 1), do_dma = !(p.dbg & 2);
@@ -547,6 +557,9 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
 #undef XL_MMA_END
 
     XL_STAMP(3)
+#ifdef MDX_XL_ABLATE
+    if (p.dbg & 4) return;                                       // ablation: prologue + main loop only (no epilogue at all)
+#endif
     // ---- epilogue ----
     constexpr int NH = (BN == 320) ? 2 : 1;                       // the 320-wide bf16 tile goes through LDS in two 128-row halves
     constexpr int HROWS = BM / NH;
@@ -665,6 +678,9 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         XL_STAMP(4)
+#ifdef MDX_XL_ABLATE
+        if (p.dbg & 8) continue;                                 // ablation: accumulators staged, nothing stored
+#endif
         const int mh = m0 + hh * HROWS;
         if (p.col_split) {
             // batch-flattened output: a tile's columns are tokens of consecutive images; column n -> image n / cs, token n % cs.
@@ -806,14 +822,22 @@ static int launch_xl(const GCParams& p, hipStream_t st) {
     if (int rc = ensure_dyn_smem((const void*)kern, smem, "xl")) return rc;
     GCParams q = p;
     q.mt = (p.M + 255) / 256; q.nt = (p.N + BN - 1) / BN;
-    static const int swz = [] { const char* e = getenv("MDX_GEMM_SWZ"); return e ? atoi(e) : 1; }();
-    static const int dbg = [] { const char* e = getenv("MDX_XL_DBG"); return e ? atoi(e) : 0; }();
+    const int swz = (int)opt(OPT_GEMM_SWZ);
+    const int dbg = (int)opt(OPT_XL_DBG);
     q.dbg = dbg;
     q.swz = swz && q.nt > 1 && q.mt >= 64;
-    static const int timing = [] { const char* e = getenv("MDX_XL_TIMING"); return e ? atoi(e) : 0; }();
-    const unsigned nblk_t = q.swz ? (unsigned)((q.mt + 7) / 8 * 8 * q.nt) : (unsigned)(q.mt * q.nt);
+    unsigned nblk_raster = 0;
+    const int raster = (int)opt(OPT_XL_RASTER);
+    if (raster == 0) q.swz = 0;
+    if (raster == 2 && q.mt >= 64) {
+        raster_shape(q.mt, q.nt, &q.gm, &q.gn);
+        const long nb = raster_blocks(q.mt, q.nt, q.gm, q.gn);
+        if (nb < 0x7fffffffL) { q.swz = 2; nblk_raster = (unsigned)nb; }
+    }
+    const int timing = (int)opt(OPT_XL_TIMING);
+    const unsigned nblk_t = q.swz == 2 ? nblk_raster : q.swz ? (unsigned)((q.mt + 7) / 8 * 8 * q.nt) : (unsigned)(q.mt * q.nt);
     q.timing = (timing && p.ws && (long)nblk_t * 64 <= p.ws_bytes) ? (unsigned long long*)p.ws : nullptr;
-    const unsigned nblk = q.swz ? (unsigned)((q.mt + 7) / 8 * 8 * q.nt) : (unsigned)(q.mt * q.nt);
+    const unsigned nblk = nblk_t;
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), smem, st, q);
     char tag[96];
     snprintf(tag, sizeof tag, "gemm_xl_kernel<256x%d,%s>", BN, CONV ? "conv" : "gemm");   // (the schedule is a tuning knob, not part of the name)
@@ -845,7 +869,7 @@ bool xl_supported(const GCParams& p, bool conv, int bn) {
 // issued between the MFMAs (measured 10 % slower: the DMA issue lengthens the MFMA segments, which are the serial resource);
 // 2 / 3 = quadrant variants (see the kernel).
 int launch_gemm_xl(const GCParams& p, bool conv, int bn, hipStream_t st) {
-    static const int sched = [] { const char* e = getenv("MDX_XL_SCHED"); return e ? atoi(e) : 0; }();
+    const int sched = (int)opt(OPT_XL_SCHED);
 #define XL_GO(BN_, S_) (conv ? launch_xl<BN_, true, S_>(p, st) : launch_xl<BN_, false, S_>(p, st))
     if (bn == 320) return XL_GO(320, 0);
     if (bn == 256) return sched == 1 ? XL_GO(256, 1) : sched == 2 ? XL_GO(256, 2) : sched == 3 ? XL_GO(256, 3) : XL_GO(256, 0);

@@ -9,7 +9,7 @@
 //   row, 16-byte loads, shuffle reductions.
 #include "common.h"
 #include "launch.h"
-#include <cstdlib>
+#include "options.h"
 
 namespace mdx {
 
@@ -395,7 +395,7 @@ extern "C" int mdx_groupnorm_bf16(const MdxGroupNormDesc* d, void* stream) {
     const int cpg = p.C / p.G;
     hipStream_t st = (hipStream_t)stream;
     // big maps: two-stage streaming path (needs 16-byte rows, G <= 240 = the smallest workgroup, a partials workspace)
-    static const int two_stage = [] { const char* e = getenv("MDX_GN_TWO_STAGE"); return e ? atoi(e) : 1; }();
+    const int two_stage = (int)opt(OPT_GN_TWO_STAGE);
     const long elems = (long)p.HW * p.C;
     if (two_stage && d->ws && elems >= 32768 && p.C % 8 == 0 && p.C <= GN2_MAXC && p.G <= 240 && p.ldx % 8 == 0 && p.ldy % 8 == 0 &&
         ((uintptr_t)p.X & 15) == 0 && ((uintptr_t)p.Y & 15) == 0) {

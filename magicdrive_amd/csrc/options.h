@@ -1,0 +1,53 @@
+// options.h — the tuning / routing switches of libmdx, in ONE table.
+//
+// Every switch is a named 64-bit integer with a default.  Product code reads them through opt(OPT_x) on every launch (an array
+// load); mdx_set_option(key, value) / mdx_get_option(key, &value) (include/mdx.h) change and query them in-process — tests force a
+// route without spawning an interpreter, an embedding application never has to touch the environment.  For the measurement scripts
+// under tools/ each switch can still be PRE-SET through the environment variable MDX_<KEY>, read once when the library is loaded.
+#pragma once
+#include <cstdint>
+
+namespace mdx {
+
+#define MDX_OPTIONS(X) \
+    X(ATTN_SWZ, 1, "XCD-aware block order of attention.hip") \
+    X(ATTN_NW4_BLOCKS, 256L, "attention.hip: 4-wave workgroups from this many blocks") \
+    X(ATTN_NW8_BLOCKS, (1L << 40), "attention.hip: 8-wave workgroups from this many blocks") \
+    X(ATTN_NW, 0, "force the waves per workgroup of attention.hip (0 = heuristic)") \
+    X(ATTN2, 1, "attention2.hip for head dim 40") \
+    X(ATTN2_D80, 0, "attention2.hip also for head dim 80") \
+    X(ATTN2_QT, 2, "32-query tiles per wave in attention2.hip (2 or 1)") \
+    X(GEMM_SWZ, 1, "XCD-aware tile order of the generic / conv3x3 kernels") \
+    X(C3_DBG, 0, "conv3x3 ablation bits (wrong results)") \
+    X(GEMM_PIPE, 1, "software-pipelined fragment reads in the generic 128x128x64 tile") \
+    X(EPI_WIDE, 1, "16-byte epilogue accesses when alignment allows") \
+    X(GEMM_WS, 1, "gemm_ws.hip: 0 off, 1 when M >= 8192, 2 whenever supported") \
+    X(GEMM_XL, 1, "gemm_xl.hip: 0 off, 1 cost model, 2 whenever supported") \
+    X(XL_K320, 0, "let XL take the K = 320 projections from gemm_ws.hip") \
+    X(XL_MIN_TILES, 160, "fewest 256-row tiles an XL launch must have") \
+    X(XL_BN, 0, "force an XL tile width (160 / 256 / 320; 0 = cost model)") \
+    X(XL_GEGLU320, 0, "K = 320 GEGLU on the 256-wide XL tile instead of gemm_ws.hip") \
+    X(GEMM_BM256, 0, "generic 256x128 8-wave tile from M >= value (0 = never)") \
+    X(GEMM_TIMING, 0, "s_memtime stamps of the generic kernel into the op workspace") \
+    X(CONV3, 1, "conv3x3.hip for 3x3/s1/p1 convs with M >= 4096 that XL declined") \
+    X(GEMM_BK, 64, "generic tile slab depth (64 or 32)") \
+    X(GEMM_FLATTEN, 1, "batched shared-A GEMM as ONE col_split XL launch") \
+    X(CONV_CIMAJOR, 1, "channel-block-major K order of implicit-GEMM convs") \
+    X(WS_SLOTS, 512, "workgroup slots the gemm_ws M walkers are sized for") \
+    X(WS_DBG, 0, "gemm_ws ablation bits (wrong results)") \
+    X(XL_DBG, 0, "ablation bits, only in -DMDX_XL_ABLATE builds") \
+    X(XL_TIMING, 0, "per-workgroup s_memtime stamps into the op workspace") \
+    X(XL_SCHED, 0, "XL main-loop schedule variant 0..3 (0 = four quadrant phases)") \
+    X(GN_TWO_STAGE, 1, "streaming two-stage GroupNorm for maps >= 32768 elements") \
+    X(XL_RASTER, 2, "XL tile order: 0 row-major, 1 XCD-strided M-tiles, 2 XCD-blocked (M-group x N-group panels per XCD)")
+
+enum Opt : int {
+#define MDX_OPT_ENUM(key, dflt, doc) OPT_##key,
+    MDX_OPTIONS(MDX_OPT_ENUM)
+#undef MDX_OPT_ENUM
+    OPT_COUNT
+};
+
+int64_t opt(int id);                 // current value (api.hip)
+
+}  // namespace mdx

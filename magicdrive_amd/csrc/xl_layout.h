@@ -85,4 +85,31 @@ XL_HD int frag_off(int row0, int lane, int kk) {
     return row * 128 + ((chunk ^ swz(row)) << 4);
 }
 
+// ---- tile order: XCD-blocked panels (GCParams.swz == 2; gemm_xl.hip: xl_tile_coords) ----
+// Workgroup b runs on XCD b % 8 (dispatch rule, used for speed only); the ~32 workgroups an XCD runs side by side are ONE panel of
+// gm consecutive M-tiles x gn consecutive N-tiles.  An XCD walks the N-groups of one M-group back to back (its A panels stay in that
+// L2), then takes its next M-group (M-group g belongs to XCD g % 8).  Blocks whose tile falls outside the ragged edge exit.
+XL_HD void raster_shape(int mt, int nt, int* gm, int* gn) {
+    int n = nt <= 5 ? nt : 4;                                  // all N-tiles of a narrow problem; groups of 4 otherwise
+    int m = 32 / n;
+    if (m > mt / 16) m = mt / 16;                              // at least two M-groups per XCD: short problems must still spread over all 8
+    if (m < 1) m = 1;
+    *gm = m; *gn = n;
+}
+XL_HD long raster_blocks(int mt, int nt, int gm, int gn) {
+    const int ngm = (mt + gm - 1) / gm, ngn = (nt + gn - 1) / gn;
+    return (long)((ngm + 7) / 8) * 8 * ngn * gm * gn;
+}
+XL_HD bool raster_tile(int bid, int mt, int nt, int gm, int gn, int* tm, int* tn) {
+    const int xcd = bid & 7, local = bid >> 3;
+    const int per = gm * gn;
+    const int panel = local / per, within = local - panel * per;
+    const int ngn = (nt + gn - 1) / gn;
+    const int mg_local = panel / ngn, ng = panel - mg_local * ngn;
+    const int tn_in = within / gm, tm_in = within - tn_in * gm;
+    *tm = (mg_local * 8 + xcd) * gm + tm_in;
+    *tn = ng * gn + tn_in;
+    return *tm < mt && *tn < nt;
+}
+
 }  // namespace mdx_xl

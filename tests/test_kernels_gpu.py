@@ -608,13 +608,12 @@ def test_attention_joint_sources(dev, b, heads, T, d, nsrc, expect):
 
 # ---- attention2.hip (head dim 40, >= 128 workgroups; 80 behind MDX_ATTN2_D80): routes asserted, the rare branches forced ---------
 def attn2_route(d, Tq, xview=False):
-    """Kernel mdx_attention_bf16 must pick for (d, Tq) under this process's switches (the library reads them once per process;
-    tests/test_routes_gpu.py::test_forced_routes re-runs these tests with MDX_ATTN2_QT=1 and MDX_ATTN2_D80=1 in worker processes)."""
-    import os
+    """Kernel mdx_attention_bf16 must pick for (d, Tq) under the library's current switches (csrc/options.h;
+    tests/test_routes_gpu.py::test_forced_attention_routes re-runs these tests with ATTN2_QT=1, ATTN2_D80=1 and ATTN2=0)."""
     mode = "xview" if xview else "self"
-    if os.environ.get("MDX_ATTN2", "1") == "0" or (d == 80 and os.environ.get("MDX_ATTN2_D80", "0") == "0"):
+    if L.get_option("ATTN2") == 0 or (d == 80 and L.get_option("ATTN2_D80") == 0):
         return "attn_kernel<"                                       # attention.hip (prefix)
-    q = 64 if (d == 40 and Tq >= 512 and os.environ.get("MDX_ATTN2_QT", "2") == "2") else 32
+    q = 64 if (d == 40 and Tq >= 512 and L.get_option("ATTN2_QT") == 2) else 32
     return f"attn2_kernel<{d},{mode},q{q}>"
 
 

@@ -134,12 +134,22 @@ def test_xl_conv(dev, B, H, W, Cin, Cout, stride, res, temb, expect):
     close(y, conv_ref(x, w, b, stride, (1, 1), tb, R), name=f"xl conv {B}x{H}x{W} {Cin}->{Cout}")
 
 
+def geglu_case(M, F_, K, expect=None):
+    dev = torch.device("cuda")
+    A = rnd(M, K, seed=1); W = rnd(2 * F_, K, scale=K ** -0.5, seed=2, dtype=torch.float32); b = rnd(2 * F_, seed=3, dtype=torch.float32)
+    Wp, bp = PK.pack_geglu(W.cpu(), b.cpu())
+    C = torch.zeros(M, F_, dtype=BF, device=dev)
+    k = run_one(O.Gemm(A, Wp.to(dev), C, bias=bp.to(dev), epilogue=L.EPI_GEGLU, ws=ws_buf()))
+    h, g = (A.float() @ W.to(BF).float().T + b).chunk(2, dim=-1)
+    close(C, h * F.gelu(g), name=f"geglu {M}x{F_}x{K} ({k})")
+    assert expect is None or k.startswith(expect), (k, expect)
+    return k
+
+
 def test_k320_geglu_large_route(dev):
     """The level-0 GEGLU shape class (K = 320, >= 1024 tiles of 256 x 256): the weight-stationary kernel by default; the XL tile with
-    MDX_XL_GEGLU320=1 runs in test_forced_routes[geglu320xl]."""
-    from route_worker_helpers import geglu_check
-    k = geglu_check(26400, 1280, 320)
-    assert k == "gemm_ws_kernel<geglu>", k
+    XL_GEGLU320=1 runs in test_forced_routes[geglu320xl]."""
+    assert geglu_case(26400, 1280, 320) == "gemm_ws_kernel<geglu>"
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -160,24 +170,93 @@ def test_flattened_batched_vt(dev, Bt, T, Cc):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-# Forced routes.  The library reads its routing switches from the environment once per process, so each forced configuration runs
-# tests/route_worker.py in its own interpreter: every XL tile width on small ragged shapes (MDX_GEMM_XL=2: whenever supported), and
-# the round-1 main loops (gemm_pp, conv3x3, gemm_ws) with the XL kernel switched off, at the shapes the round-1 review listed.
-@pytest.mark.parametrize("mode,env", [
-    ("xl320", {"MDX_GEMM_XL": "2", "MDX_XL_BN": "320"}),
-    ("xl256", {"MDX_GEMM_XL": "2", "MDX_XL_BN": "256"}),
-    ("xl160", {"MDX_GEMM_XL": "2", "MDX_XL_BN": "160"}),
-    ("noxl", {"MDX_GEMM_XL": "0"}),
-    ("geglu320xl", {"MDX_XL_GEGLU320": "1"}),
-    ("attn_q32", {"MDX_ATTN2_QT": "1"}),
-    ("attn_d80", {"MDX_ATTN2_D80": "1"}),
-    ("attn_old", {"MDX_ATTN2": "0"}),
-])
-def test_forced_routes(dev, mode, env):
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    e = dict(os.environ); e.update(env)
-    r = subprocess.run([sys.executable, os.path.join(here, "route_worker.py"), mode], env=e, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "ROUTE_WORKER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+# Forced routes, in-process: the routing switches are library options (csrc/options.h, mdx_set_option): every XL tile width on small
+# ragged shapes (GEMM_XL=2: whenever supported), the other main loops (generic tile, conv3x3, gemm_ws) with the XL kernel switched
+# off at the shapes the round-1 review listed, and the attention kernels' other instantiations.
+def gemm_case(M, N, K, bias=True, res=False, epi=0, expect=None):
+    dev = torch.device("cuda")
+    A = rnd(M, K, seed=1); W = rnd(N, K, scale=K ** -0.5, seed=2)
+    b = rnd(N, seed=3, dtype=torch.float32) if bias else None
+    R = rnd(M, N, seed=4) if res else None
+    C = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+    k = run_one(O.Gemm(A, W, C, bias=b, R=R, epilogue=epi, ws=ws_buf()))
+    ref = A.float() @ W.float().T
+    if bias: ref += b
+    if epi == 2: ref = F.silu(ref)
+    if res: ref += R.float()
+    close(C, ref, name=f"gemm {M}x{N}x{K} ({k})")
+    assert expect is None or k.startswith(expect), (k, expect)
+    return k
+
+
+def conv_case(B, H, W, Cin, Cout, stride=(1, 1), res=True, temb=True, expect=None):
+    dev = torch.device("cuda")
+    x = rnd(B, H, W, Cin, seed=1)
+    w = rnd(Cout, Cin, 3, 3, scale=(Cin * 9) ** -0.5, seed=2, dtype=torch.float32); b = rnd(Cout, seed=3, dtype=torch.float32)
+    Ho = (H - 1) // stride[0] + 1; Wo = (W - 1) // stride[1] + 1
+    y = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=BF, device=dev)
+    R = rnd(B, Ho, Wo, Cout, seed=4) if res else None
+    tb = rnd(B, Cout, seed=5, dtype=torch.float32) if temb else None
+    k = run_one(O.Conv(x, PK.pack_conv_weight(w.cpu()).to(dev), y, bias=b, R=R, temb=tb, temb_b_stride=Cout if temb else 0, stride=stride, pad=(1, 1), ws=ws_buf()))
+    close(y, conv_ref(x, w, b, stride, (1, 1), tb, R), name=f"conv {B}x{H}x{W} {Cin}->{Cout} ({k})")
+    assert expect is None or k.startswith(expect), (k, expect)
+    return k
+
+
+@pytest.mark.parametrize("bn", [320, 256, 160])
+@pytest.mark.parametrize("raster", [0, 1, 2])
+def test_forced_xl_widths(dev, bn, raster):
+    with L.options(GEMM_XL=2, XL_BN=bn, XL_RASTER=raster):
+        g, c = f"gemm_xl_kernel<256x{bn},gemm>", f"gemm_xl_kernel<256x{bn},conv>"
+        gemm_case(2000, 640, 640, res=True, expect=g)                 # ragged M (7.8 tiles), N = 2-4 tiles
+        gemm_case(777, 324, 128, bias=False, expect=g)                # N % 8 != 0: narrow stores; ragged everything; two slabs
+        gemm_case(5000, 320, 64, epi=2, expect=g)                     # one slab, SiLU
+        gemm_case(3000, 1280, 960, res=True, expect=g)                # 15 slabs (K < 1024: no automatic split-K)
+        gemm_case(30000, 1600, 128, res=True, expect=g)               # 118 M-tiles x 5-10 N-tiles: several XCD panels, ragged last N-group
+        conv_case(6, 28, 50, 320, 320, expect=c)                      # level-0 resnet conv
+        conv_case(12, 14, 25, 128, 640, res=False, expect=c)          # 350-px images, 2 channel blocks
+        conv_case(40, 7, 13, 64, 320, temb=True, expect=c)            # 91-px images: temb slots
+        conv_case(100, 4, 7, 128, 160, expect=c)                      # 28-px images: 10 images per tile
+        conv_case(6, 28, 50, 64, 320, stride=(2, 2), res=False, temb=False, expect=c)
+        if bn == 256:
+            geglu_case(3000, 640, 320, expect=g)
+
+
+def test_forced_no_xl(dev):
+    """The main loops that serve small batches (XL declines below XL_MIN_TILES tiles), forced at larger shapes."""
+    with L.options(GEMM_XL=0):
+        gemm_case(8736, 1280, 1280, res=True, expect="gemm_conv_kernel<128,128,64")
+        geglu_case(8736, 5120, 1280, expect="gemm_conv_kernel<128,128,64")
+        gemm_case(4500, 2560, 1280, res=True, expect="gemm_conv_kernel<128,128,64")          # ragged M
+        conv_case(96, 7, 13, 1280, 1280, expect="conv3x3_kernel")                             # 8736 rows, tiles span 3-4 images
+        conv_case(24, 14, 25, 1920, 1280, res=False, expect="conv3x3_kernel")
+        conv_case(16, 28, 50, 320, 320, expect="conv3x3_kernel")
+        conv_case(600, 4, 7, 320, 320, expect="conv3x3_kernel")                               # 4x7 images
+        conv_case(22, 28, 28, 640, 640, expect="conv3x3_kernel")                              # 28-px rows straddling 128-row tiles
+        gemm_case(537600, 320, 320, res=True, expect="gemm_ws_kernel<plain>")                 # bench row count
+        geglu_case(26400, 1280, 320, expect="gemm_ws_kernel<geglu>")                          # K = 320 GEGLU on the weight-stationary kernel
+        with L.options(CONV3=0):
+            conv_case(16, 28, 50, 320, 320, expect="gemm_conv_kernel<128,128,64")             # the generic implicit-GEMM conv
+
+
+def test_forced_geglu320_on_xl(dev):
+    with L.options(XL_GEGLU320=1):
+        assert geglu_case(26400, 1280, 320) == "gemm_xl_kernel<256x256,gemm>"
+
+
+@pytest.mark.parametrize("mode,opts", [("attn_q32", {"ATTN2_QT": 1}), ("attn_d80", {"ATTN2_D80": 1}), ("attn_old", {"ATTN2": 0})])
+def test_forced_attention_routes(dev, mode, opts):
+    """attention2.hip's other instantiations (32-query waves; head dim 80) and attention.hip at the same shapes, through the tests of
+    tests/test_kernels_gpu.py (their route assertions follow the current switches)."""
+    import test_kernels_gpu as T
+    with L.options(**opts):
+        for case in T.ATTN2_CASES:
+            T.test_attention2(dev, *case)
+        T.test_attention2_softmax_rescale_branch(dev)
+        for case in [(1, 8, 1400, 40), (3, 8, 350, 80), (2, 8, 700, 40)]:
+            T.test_attention2_crossview(dev, *case)
+
+
+def test_set_option_rejects_unknown_key():
+    with pytest.raises(L.MdxError):
+        L.set_option("NO_SUCH_SWITCH", 1)

@@ -102,7 +102,42 @@ static int check() {
     return errors;
 }
 
+// XCD-blocked tile order: every tile exactly once; the tiles an XCD holds side by side (32 consecutive local indices) span at most
+// gm M-tiles x gn N-tiles of ONE panel or the tail of one and the head of the next; M-tiles of a panel are contiguous.
+static int check_raster() {
+    int errors = 0;
+    const int shapes[][2] = {{64, 1}, {64, 2}, {65, 3}, {84, 5}, {273, 5}, {1050, 20}, {1050, 3}, {4200, 2}, {333, 7}, {100, 40}, {71, 4}, {4200, 1}};
+    for (auto& sh : shapes) {
+        const int mt = sh[0], nt = sh[1];
+        int gm, gn;
+        raster_shape(mt, nt, &gm, &gn);
+        const long nb = raster_blocks(mt, nt, gm, gn);
+        std::vector<int> seen((size_t)mt * nt, 0);
+        for (long b = 0; b < nb; ++b) {
+            int tm, tn;
+            if (!raster_tile((int)b, mt, nt, gm, gn, &tm, &tn)) continue;
+            if (tm < 0 || tn < 0 || tm >= mt || tn >= nt) { ++errors; continue; }
+            ++seen[(size_t)tm * nt + tn];
+        }
+        for (int v : seen) if (v != 1) ++errors;
+        // one panel per gm * gn consecutive locals of an XCD: distinct M-tiles <= gm, distinct N-tiles <= gn, M-tiles contiguous
+        for (int xcd = 0; xcd < 8; ++xcd)
+            for (long l0 = 0; l0 * 8 + xcd < nb; l0 += gm * gn) {
+                int mlo = 1 << 30, mhi = -1, nlo = 1 << 30, nhi = -1;
+                for (int k = 0; k < gm * gn; ++k) {
+                    int tm, tn;
+                    const long b = (l0 + k) * 8 + xcd;
+                    if (b >= nb || !raster_tile((int)b, mt, nt, gm, gn, &tm, &tn)) continue;
+                    mlo = tm < mlo ? tm : mlo; mhi = tm > mhi ? tm : mhi; nlo = tn < nlo ? tn : nlo; nhi = tn > nhi ? tn : nhi;
+                }
+                if (mhi >= 0 && (mhi - mlo + 1 > gm || nhi - nlo + 1 > gn)) ++errors;
+            }
+        std::printf("raster mt=%d nt=%d: panels %d x %d, %ld blocks for %d tiles: %s\n", mt, nt, gm, gn, nb, mt * nt, errors ? "FAIL" : "ok");
+    }
+    return errors;
+}
+
 int main() {
-    int e = check<256>() + check<160>() + check<320>();
+    int e = check<256>() + check<160>() + check<320>() + check_raster();
     return e ? 1 : 0;
 }

@@ -39,4 +39,13 @@ for name, op in cases:
     tot = ((t[:, 7] - t[:, 0]).mean() / 100.0).item()
     span = ((t[:, 7].max() - t[:, 0].min()) / 100.0).item()
     us = e0.elapsed_time(e1) * 1e3 / max(1.0, n / 256.0) / tot          # microseconds per printed unit, from the launch time and the rounds of tiles
+    # are the CUs synchronised, and do the burst-bound phases (first slab, store issue) shrink once rounds of tiles have drifted apart?
+    order = torch.argsort(t[:, 0])
+    ts_ = t[order]
+    nq = 4
+    for qi in range(nq):
+        seg = ts_[qi * n // nq:(qi + 1) * n // nq]
+        dd = (seg[:, 1:] - seg[:, :-1]).mean(0) / 100.0
+        print(f"    tiles by start time, quarter {qi}: first slab {dd[1]*us:5.2f}  main {dd[2]*us:6.2f}  stage {dd[4]*us:5.2f}  store {dd[6]*us:5.2f} us; "
+              f"start-time spread inside the quarter's first 256 tiles {(seg[:256, 0].max() - seg[:256, 0].min()).item() / 100.0 * us:7.1f} us")
     print(f"{name:36s} {kern:30s} {n:6d} tiles, launch {e0.elapsed_time(e1)*1e3:8.1f} us (stamps span {span:8.1f}) | per tile {tot*us:6.1f} us = setup {d[0]*us:4.1f} + first slab {d[1]*us:4.1f} + main loop {d[2]*us:6.1f} + barrier {d[3]*us:4.1f} + stage {d[4]*us:4.1f} + barrier {d[5]*us:4.1f} + residual/store {d[6]*us:4.1f}")

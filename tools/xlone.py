@@ -47,6 +47,9 @@ def main():
     gemm("g256_ffout_L1", B * 350, 640, 2560, res=True)
     gemm("g160_ffout_L0", B * 1400, 320, 1280, res=True)
     gemm("g256_qk_L1", B * 350, 1280, 640)
+    gemm("g256_cc_L1", B * 350, 640, 640, res=True)
+    gemm("g256_cc_L2", B * 91, 1280, 1280, res=True)
+    gemm("g256_geglu_L2", B * 91, 10240, 1280, epi=1)
     gemm("g_geglu_L0", B * 1400, 2560, 320, epi=1)
     gemm("g_out_L0", B * 1400, 320, 320, res=True)
     only = [s for s in a.only.split(",") if s]
