@@ -148,6 +148,9 @@ typedef struct MdxAttnDesc {
     int64_t ldq, sQ, ldk, sK, ldv, sV, ldo, sO;
     double scale;
     int64_t joint;
+    int64_t q_prescaled;   /* 1: Q already carries scale * log2(e) (folded into the to_q weights when they were packed): `scale` is ignored,
+                            * Q K^T is used as the base-2 exponent directly — lets the head-dim-40 kernel subtract the running maximum
+                            * inside the QK MFMA (attention2.hip: FOLD).  0: plain Q, softmax(scale * Q K^T) as in the reference. */
 } MdxAttnDesc;
 int mdx_attention_bf16(const MdxAttnDesc* d, void* stream);
 

@@ -41,7 +41,7 @@ MdxConvDesc = _struct("MdxConvDesc", _f(P, "X Wt Y R bias temb sel_ptr ws") + _f
 MdxConvDirectDesc = _struct("MdxConvDirectDesc", _f(P, "X Wt Y R bias temb sel_ptr reserved_p") + _f(I, "B Hi Wi Cin Ho Wo Cout kh kw sh sw ph pw "
                             "ldx ldy ldr temb_sel_stride temb_b_stride epilogue x_is_f32 y_is_f32 reserved0"))
 MdxAttnDesc = _struct("MdxAttnDesc", _f(P, "Q K Vt O kvmap reserved_p") + _f(I, "B H Tq Tk d nsrc ldq sQ ldk sK ldv sV ldo sO")
-                      + _f(D, "scale") + _f(I, "joint"))
+                      + _f(D, "scale") + _f(I, "joint q_prescaled"))
 MdxGroupNormDesc = _struct("MdxGroupNormDesc", _f(P, "X Y gamma beta") + _f(I, "B HW C G ldx ldy") + _f(D, "eps") + _f(I, "silu") + _f(P, "ws") + _f(I, "ws_bytes"))
 MdxLayerNormDesc = _struct("MdxLayerNormDesc", _f(P, "X Y gamma beta") + _f(I, "M C ldx ldy") + _f(D, "eps") + _f(I, "reserved0"))
 MdxEwDesc = _struct("MdxEwDesc", _f(P, "X Y ymap xmap") + _f(I, "kind M C ldx ldy B Hi Wi Ho Wo x_is_f32 y_is_f32") + _f(D, "alpha"))

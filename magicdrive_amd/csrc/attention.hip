@@ -364,14 +364,16 @@ extern "C" int mdx_attention_bf16(const MdxAttnDesc* a, void* stream) {
     p.kvmap = a->kvmap;
     p.B = (int)a->B; p.H = (int)a->H; p.Tq = (int)a->Tq; p.Tk = (int)a->Tk; p.d = (int)a->d; p.nsrc = (int)a->nsrc; p.joint = (int)a->joint;
     p.ldq = a->ldq; p.sQ = a->sQ; p.ldk = a->ldk; p.sK = a->sK; p.ldv = a->ldv; p.sV = a->sV; p.ldo = a->ldo; p.sO = a->sO;
-    p.scale_log2 = (float)(a->scale * 1.4426950408889634);
+    // q_prescaled: the caller folded scale * log2(e) into the query projection: scores are base-2 exponents already
+    if (a->q_prescaled != 0 && a->q_prescaled != 1) return set_error(MDX_EINVAL, "q_prescaled must be 0 or 1");
+    p.scale_log2 = a->q_prescaled ? 1.0f : (float)(a->scale * 1.4426950408889634);
     hipStream_t st = (hipStream_t)stream;
     {
         Attn2Params p2;
         p2.Q = p.Q; p2.K = p.K; p2.Vt = p.Vt; p2.O = p.O; p2.kvmap = p.kvmap;
         p2.B = p.B; p2.H = p.H; p2.Tq = p.Tq; p2.Tk = p.Tk; p2.d = p.d; p2.nsrc = p.nsrc; p2.joint = p.joint;
         p2.ldq = p.ldq; p2.sQ = p.sQ; p2.ldk = p.ldk; p2.sK = p.sK; p2.ldv = p.ldv; p2.sV = p.sV; p2.ldo = p.ldo; p2.sO = p.sO;
-        p2.scale_log2 = p.scale_log2; p2.qblocks = 0;
+        p2.scale_log2 = p.scale_log2; p2.qblocks = 0; p2.q_prescaled = (int)a->q_prescaled;
         if (attn2_supported(p2)) return launch_attn2(p2, st);
     }
     int d16 = (int)(a->d + 15) / 16;

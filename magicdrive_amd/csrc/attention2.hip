@@ -98,9 +98,16 @@ constexpr float A2_DEFER = 4.0f;   // log2 units: the running max is only raised
 // D8 = d / 8 (5 or 10); QT = 32-query tiles per wave; one workgroup = 4 waves = 128 QT queries of one (batch, head).
 // QT = 2 halves, per query, everything that is per (workgroup, kv tile): the DMA pieces, the K / V^T fragment reads, the barrier —
 // and the per-workgroup prologue / epilogue; it runs at 2 waves per SIMD (<= 256 VGPRs).
-template <int D8, bool TWO, int QT>
+// FOLD (round 3; needs a spare k slot, d % 16 != 0, and Q pre-scaled by scale * log2(e) — MdxAttnDesc.q_prescaled): the running maximum
+// is subtracted INSIDE the QK MFMA.  The padded k slot d of the Q fragment carries -m (bf16) and the same slot of the K fragment is
+// forced to 1, so the accumulator comes out as s - m in base-2 units and feeds v_exp_f32 directly: the 32 v_fma_f32 per (32 queries x
+// 64 kv) of `exp2(s * scale - m)` — a fifth of the kernel's VALU time, and the kernel is VALU-bound — disappear.  m is kept on the bf16
+// grid (any value works as the subtracted maximum as long as numerator and row sum use the same one); a tile that raises it (rare:
+// deferred maximum) re-bases its own scores with an explicit subtraction.
+template <int D8, bool TWO, int QT, bool FOLD>
 __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kernel(Attn2Params p) {
     constexpr int D = D8 * 8;
+    static_assert(!FOLD || (D % 16) == 8, "FOLD needs the 8 spare k slots of a head dim that is 8 mod 16");
     constexpr int D16 = (D + 15) / 16;             // QK k-steps of 16 and PV row tiles of 16
     constexpr int KROW = D * 2;                    // K tile row bytes (contiguous rows: the DMA image is lane-linear)
     constexpr int K_BYTES = A2_KV * KROW;          // d = 40: 5120
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
     float m_run[QT], l_run[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        m_run[qt] = -INFINITY; l_run[qt] = 0.f;
+        m_run[qt] = FOLD ? 0.f : -INFINITY; l_run[qt] = 0.f;      // FOLD: the subtracted maximum starts at 0 (the Q pad slot is zero); the first tile of a source always re-bases
 #pragma unroll
         for (int i = 0; i < D16; ++i)
 #pragma unroll
@@ -240,13 +247,14 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
                     oacc[qt][i][t][e] = 0.f;
                 }
     }
+    const unsigned one_slot = half ? 0x00003F80u : 0u;          // FOLD: K fragment of the pad k-step for the upper half lanes = (1, 0, ..., 0)
 
     // One kv tile for the first NQ_ query tiles of the wave: scores, online softmax, PV.  The K / V^T fragments are read once and used
     // by every query tile.  LAST adds the kv >= Tk mask (the V^T pad columns were scrubbed by the caller).
     // Online softmax with a deferred maximum: m_run is raised only when a tile exceeds it by more than A2_DEFER (wave-uniform
     // decision), so most tiles skip the O rescale and its two cross-lane fetches.  Until then probabilities are relative to the older
     // maximum (at most 2^A2_DEFER instead of 1) — the numerator and the row sum carry the same factor and it cancels in O = (P V) / l.
-#define A2_TILE(LAST, NQ_, slot_, j0_)                                                                                 \
+#define A2_TILE(LAST, NQ_, slot_, j0_, FIRST_)                                                                         \
     {                                                                                                                  \
         const unsigned char* sb_ = smem + (slot_) * BUF;                                                               \
         Frag8 kf_[2][D16], vf_[2][D16];                                                                                \
@@ -254,6 +262,12 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
             _Pragma("unroll") for (int ks = 0; ks < D16; ++ks) kf_[s][ks].u = *(const uint4*)(sb_ + k_rd[s] + ks * 32); \
         _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                  \
             _Pragma("unroll") for (int i = 0; i < D16; ++i) vf_[s][i].u = *(const uint4*)(sb_ + (s ? v_rd1 : v_rd0) + i * 2048); \
+        if (FOLD) {   /* upper-half lanes of the last k-step hold only pad dims (bytes of the NEXT K row in LDS): make them (1, 0 x 7) */ \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                            \
+                kf_[s][D16 - 1].u.x = half ? one_slot : kf_[s][D16 - 1].u.x; kf_[s][D16 - 1].u.y = half ? 0u : kf_[s][D16 - 1].u.y; \
+                kf_[s][D16 - 1].u.z = half ? 0u : kf_[s][D16 - 1].u.z; kf_[s][D16 - 1].u.w = half ? 0u : kf_[s][D16 - 1].u.w; \
+            }                                                                                                          \
+        }                                                                                                              \
         _Pragma("unroll") for (int qt = 0; qt < NQ_; ++qt) {                                                           \
             f32x16_t sacc[2];                                                                                          \
             _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                            \
@@ -274,9 +288,29 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
             {   /* max with the other half of this query (lane ^ 32): one v_permlane32_swap instead of a ds_bpermute */  \
                 const unsigned mu_ = __float_as_uint(mx);                                                              \
                 auto sw_ = __builtin_amdgcn_permlane32_swap(mu_, mu_, false, false);                                   \
-                mx = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1])) * p.scale_log2;                           \
+                mx = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                                          \
+                if (!FOLD) mx *= p.scale_log2;                                                                         \
             }                                                                                                          \
             float alpha = 1.0f;                                                                                        \
+            if (FOLD) {                                                                                                \
+                /* scores are already relative to m_run; raise it when a tile exceeds it by A2_DEFER — and always on a source's first tile */ \
+                if (((FIRST_) || __builtin_amdgcn_ballot_w64(mx > A2_DEFER) != 0) && !(A2_ABL & 4)) {                   \
+                    const float inc_ = (FIRST_) ? mx : fmaxf(mx, 0.f);                                                 \
+                    const float m_new = __uint_as_float(pack2bf(m_run[qt] + inc_, 0.f) << 16);       /* on the bf16 grid */ \
+                    const float delta_ = m_new - m_run[qt];                                                            \
+                    alpha = (FIRST_) ? 0.f : __builtin_amdgcn_exp2f(-delta_);      /* first tile: O is zero; exp2 of a large -delta would be inf */ \
+                    m_run[qt] = m_new;                                                                                 \
+                    if (half) qf[qt][D16 - 1].u.x = pack2bf(-m_new, 0.f);          /* -m into the pad k slot of this query */ \
+                    _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                      \
+                        _Pragma("unroll") for (int r = 0; r < 16; ++r) sacc[s][r] -= delta_;      /* this tile was multiplied with the old m */ \
+                    const float al0 = __shfl(alpha, lane & 15, 64), al1 = __shfl(alpha, 16 + (lane & 15), 64);          \
+                    _Pragma("unroll") for (int i = 0; i < D16; ++i)                                                    \
+                        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                \
+                            asm volatile("v_mul_f32 %0, %0, %1" : "+v"(oacc[qt][i][0][e]) : "v"(al0));                 \
+                            asm volatile("v_mul_f32 %0, %0, %1" : "+v"(oacc[qt][i][1][e]) : "v"(al1));                 \
+                        }                                                                                              \
+                }                                                                                                      \
+            } else                                                                                                     \
             if (__builtin_amdgcn_ballot_w64(mx > m_run[qt] + A2_DEFER) != 0 && !(A2_ABL & 4)) {                        \
                 const float m_new = fmaxf(m_run[qt], mx);                                                              \
                 alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);           /* first tile: exp2(-inf) = 0 on zeros */ \
@@ -295,8 +329,8 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
             _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                            \
                 Frag8 b0, b1;                                                                                          \
                 _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                        \
-                    float p0 = __builtin_fmaf(sacc[s][2 * u], p.scale_log2, mneg_);                                    \
-                    float p1 = __builtin_fmaf(sacc[s][2 * u + 1], p.scale_log2, mneg_);                                \
+                    float p0 = FOLD ? sacc[s][2 * u] : __builtin_fmaf(sacc[s][2 * u], p.scale_log2, mneg_);            \
+                    float p1 = FOLD ? sacc[s][2 * u + 1] : __builtin_fmaf(sacc[s][2 * u + 1], p.scale_log2, mneg_);    \
                     if (!(A2_ABL & 1)) { p0 = __builtin_amdgcn_exp2f(p0); p1 = __builtin_amdgcn_exp2f(p1); }           \
                     if (!ONES) psum += p0 + p1;                                                                        \
                     const unsigned pk_ = pack2bf(p0, p1);                                                              \
@@ -345,7 +379,8 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
             issue_next(s2);
         }
     };
-    auto tile_done = [&]() { ++g; if (++slot == A2_NBUF) slot = 0; };
+    int fresh = 1;                       // FOLD: the next tile is the first of a softmax (a source; all sources when joint): it always re-bases m
+    auto tile_done = [&]() { ++g; if (++slot == A2_NBUF) slot = 0; fresh = 0; };
     const int nfull = p.Tk / A2_KV;      // full tiles per source; a partial one follows when Tk % 64 != 0
 
     // The loop nest of one source, for the first NQ_ query tiles of the wave.  The full tiles run in a loop with ONE body (so the
@@ -355,7 +390,7 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
     {                                                                                                                  \
         for (int t = 0; t < nfull; ++t) {                                                                              \
             tile_sync();                                                                                               \
-            A2_TILE(false, NQ_, slot, t * A2_KV)                                                                       \
+            A2_TILE(false, NQ_, slot, t * A2_KV, fresh)                                                                \
             tile_done();                                                                                               \
         }                                                                                                              \
         if (nfull < ntile) {                                                                                           \
@@ -370,7 +405,7 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
                 }                                                                                                      \
                 __syncthreads();                                                                                       \
             }                                                                                                          \
-            A2_TILE(true, NQ_, slot, nfull * A2_KV)                                                                    \
+            A2_TILE(true, NQ_, slot, nfull * A2_KV, fresh)                                                          \
             tile_done();                                                                                               \
         }                                                                                                              \
     }
@@ -413,8 +448,10 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
                         }
                     }
                 }
-            m_run[qt] = -INFINITY; l_run[qt] = 0.f;
+            m_run[qt] = FOLD ? 0.f : -INFINITY; l_run[qt] = 0.f;
+            if (FOLD && half) qf[qt][D16 - 1].u.x = 0u;
         }
+        fresh = 1;
     }
 #undef A2_SOURCE
 #undef A2_TILE
@@ -442,16 +479,16 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
         }
 }
 
-template <int D8, int QT>
+template <int D8, int QT, bool FOLD>
 static int launch_attn2_d(const Attn2Params& p, hipStream_t st) {
     Attn2Params q = p;
     q.qblocks = (p.Tq + A2_NW * 32 * QT - 1) / (A2_NW * 32 * QT);
     const dim3 grid((unsigned)(((long)p.B * p.H + 7) / 8 * 8 * q.qblocks), 1, 1);
     const bool two = p.nsrc == 2 && !p.joint;                   // TWO = the summed two-neighbour form; everything else is one softmax over nsrc sources
-    if (two) hipLaunchKernelGGL((attn2_kernel<D8, true, QT>), grid, dim3(A2_NT), 0, st, q);
-    else hipLaunchKernelGGL((attn2_kernel<D8, false, QT>), grid, dim3(A2_NT), 0, st, q);
+    if (two) hipLaunchKernelGGL((attn2_kernel<D8, true, QT, FOLD>), grid, dim3(A2_NT), 0, st, q);
+    else hipLaunchKernelGGL((attn2_kernel<D8, false, QT, FOLD>), grid, dim3(A2_NT), 0, st, q);
     char tag[64];
-    snprintf(tag, sizeof tag, "attn2_kernel<%d,%s,q%d>", D8 * 8, two ? "xview" : (p.nsrc > 1 ? "joint" : "self"), 32 * QT);
+    snprintf(tag, sizeof tag, "attn2_kernel<%d,%s,q%d%s>", D8 * 8, two ? "xview" : (p.nsrc > 1 ? "joint" : "self"), 32 * QT, FOLD ? ",fold" : "");
     return check_launch(tag);
 }
 
@@ -471,8 +508,13 @@ int launch_attn2(const Attn2Params& p, hipStream_t st) {
     // 64 queries per wave (see attn2_kernel) when there are enough queries per head; MDX_ATTN2_QT=1 forces 32
     const int qt = (int)opt(OPT_ATTN2_QT);
     const bool two = qt == 2 && p.Tq >= 512 && p.d == 40;
-    if (p.d == 40) return two ? launch_attn2_d<5, 2>(p, st) : launch_attn2_d<5, 1>(p, st);
-    return launch_attn2_d<10, 1>(p, st);
+    // pre-scaled Q (scale * log2 e folded into to_q at pack time): scores are base-2 exponents as they come out of the MFMA
+    const bool fold = p.q_prescaled && opt(OPT_ATTN2_FOLD) != 0;
+    if (p.d == 40) {
+        if (fold) return two ? launch_attn2_d<5, 2, true>(p, st) : launch_attn2_d<5, 1, true>(p, st);
+        return two ? launch_attn2_d<5, 2, false>(p, st) : launch_attn2_d<5, 1, false>(p, st);
+    }
+    return launch_attn2_d<10, 1, false>(p, st);
 }
 
 }  // namespace mdx

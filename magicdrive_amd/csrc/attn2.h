@@ -8,7 +8,8 @@ struct Attn2Params {
     int B, H, Tq, Tk, d, nsrc;
     int joint;         // 1: one softmax over the concatenation of the nsrc sources; 0: per-source softmax, outputs summed (nsrc <= 2)
     long ldq, sQ, ldk, sK, ldv, sV, ldo, sO;
-    float scale_log2;  // scale * log2(e)
+    float scale_log2;  // scale * log2(e); 1 when q_prescaled
+    int q_prescaled;   // Q already carries scale * log2(e) (MdxAttnDesc.q_prescaled)
     int qblocks;       // query blocks per (batch, head), filled in by launch_attn2
 
 };

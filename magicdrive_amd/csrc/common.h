@@ -25,7 +25,8 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return *reinterpret_cast<bf16_t*>(&v);
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with v_rcp_f32 (1 ulp) instead of the IEEE division sequence (v_div_scale / v_div_fmas / v_div_fixup: ~12 instructions)
+__device__ __forceinline__ float silu_f(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
 // erf GELU (attention.py:259-280 uses F.gelu's default, exact form): gelu(x) = 0.5 x (1 + erf(x / sqrt 2)).
 // erf(z) = z P(z^2) on |z| <= 3 (clamped beyond: erf(3) = 1 - 2.2e-5), P = the degree-8 minimax polynomial of erf(z) / z in z^2 (linear
 // programme on 3000 points, tools/fit_erf.py): |error| <= 2.7e-5 in fp32 Horner arithmetic — 150x below the bf16 rounding of the

@@ -97,13 +97,14 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
     }
     Frag8 wf[KS];
     {
+        // all 20 loads issued back to back from a clamped row, masked afterwards: written as `ok ? load : 0` each load became its own
+        // branch + `s_waitcnt vmcnt(0)` (24 serial memory round trips at the start of every workgroup, seen in the .s; round 3)
         const bf16_t* wp = p.W + (long)min(wrow, p.N - 1) * p.ldw + half * 8;
-        const bool ok = wrow < p.N;
+        const unsigned keep = wrow < p.N ? 0xffffffffu : 0u;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const uint4 v = *(const uint4*)(wp + ks * 16);
-            wf[ks].u = ok ? v : make_uint4(0, 0, 0, 0);
-        }
+        for (int ks = 0; ks < KS; ++ks) wf[ks].u = *(const uint4*)(wp + ks * 16);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { wf[ks].u.x &= keep; wf[ks].u.y &= keep; wf[ks].u.z &= keep; wf[ks].u.w &= keep; }
     }
     // bias of this lane's output positions (fixed for the whole launch)
     float4 bA[4];                                                // GEGLU: {value g0, value g1, gate g0, gate g1}; else g = 0..3
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
         int col;
         if (GEGLU) col = n0 + (wave >> 1) * 64 + 16 * (wave & 1) + 8 * (g & 1) + 4 * half + 32 * (g >> 1);
         else col = n0 + ocol + 8 * g + 4 * half;
-        bA[g] = (p.bias && col < p.N) ? *(const float4*)(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 bv = p.bias ? *(const float4*)(p.bias + min(col, p.N - 4)) : make_float4(0.f, 0.f, 0.f, 0.f);   // unconditional, clamped (p.bias is wave-uniform)
+        bA[g] = col < p.N ? bv : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
     // ---- activation stream: DMA cursor (runs ST-1 slabs ahead of the multiply) ----
@@ -173,6 +175,14 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
     const bf16_t* Rg = p.R ? (const bf16_t*)p.R : nullptr;
     bf16_t* Cg = (bf16_t*)p.C;
     constexpr bool vtile = VT;
+    // Ablations (WS_DBG: 1 GEGLU without GELU, 2 main loop only, 4 no MFMAs) exist only in -DMDX_WS_ABLATE builds: as runtime tests they
+    // sat INSIDE the slab loop — one scalar branch per k-step, which cut the loop into 20 basic blocks of {4 fragment reads, wait, 4 MFMAs}
+    // per tile and kept the compiler from reading a slab's fragments ahead of its MFMAs (seen in the .s; round 3).
+#ifdef MDX_WS_ABLATE
+    const bool do_mma = !(p.dbg & 4), no_gelu = p.dbg & 1, no_epi = p.dbg & 2;
+#else
+    constexpr bool do_mma = true, no_gelu = false, no_epi = false;
+#endif
     const int n0o = GEGLU ? n0 / 2 : n0, Nout = GEGLU ? p.N / 2 : p.N;
     int q = 0;                                                   // slab counter (ring stage = q % ST)
     for (int t = 0; t < ntiles; ++t) {
@@ -181,34 +191,49 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
         for (int s = 0; s < NSLAB; ++s, ++q) {
             // slab q has landed once at most the ST-2 younger slabs are outstanding (an epilogue's younger loads / stores only
             // make this wait conservative); the barrier also frees stage (q-1) % ST for the refill below
+            // Nothing of the previous slab may sink below this barrier: its last fragment reads must have RETURNED (their MFMAs carry the
+            // lgkmcnt waits) before any wave refills that stage.
+            __builtin_amdgcn_sched_barrier(0);
             ws_wait_vmcnt<(ST - 2) * PPW>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < PPW; ++j) WS_ISSUE_PIECE(j)      // refill of the stage freed by this iteration's barrier
             WS_ADVANCE()
             const unsigned char* as = a_rd + (q % ST) * STAGE;
+            // fragment reads one k-step ahead of their MFMAs (two register sets): left to the compiler each k-step read two fragments,
+            // waited, multiplied — the LDS latency sat between every pair of MFMAs
+            Frag8 af[2][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[0][i].u = *(const uint4*)(as + i * 32 * 128 + (x0 << 4));
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int co = (x0 ^ (ks << 1)) << 4;
-                Frag8 af[4];
+                if (ks + 1 < 4) {
+                    const int co = (x0 ^ ((ks + 1) << 1)) << 4;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[i].u = *(const uint4*)(as + i * 32 * 128 + co);
-                if (!(p.dbg & 4)) {
+                    for (int i = 0; i < 4; ++i) af[(ks + 1) & 1][i].u = *(const uint4*)(as + i * 32 * 128 + co);
+                }
+                if (do_mma) {
                     if (vtile) {          // operands swapped: the accumulator comes out transposed (lane = channel, registers = tokens)
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i].v, wf[s * 4 + ks].v, acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i].v, wf[s * 4 + ks].v, acc[i], 0, 0, 0);
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s * 4 + ks].v, af[i].v, acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s * 4 + ks].v, af[ks & 1][i].v, acc[i], 0, 0, 0);
                     }
                 }
+                // pin the order {4 fragment reads of k-step ks + 1} {4 MFMAs of k-step ks}: the machine scheduler otherwise sinks the
+                // reads back next to their use to save registers
+                if (ks + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
         }
         // ---- epilogue of tile t: staging is separate from the ring, which keeps streaming ----
-        if (p.dbg & 2) continue;                                 // debug: main loop only
+        if (no_epi) continue;                                    // ablation: main loop only
 #pragma unroll
         for (int pass = 0; pass < BM / ROWS_PASS; ++pass) {
             if (pass > 0) ws_lds_barrier();                       // previous pass's row walk is done with Cs
@@ -257,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
                         for (int e = 0; e < 4; ++e) {
                             const float x = acc[i][4 * g + e] + bvv[e];
                             const float gt = acc[i][8 + 4 * g + e] + bgg[e];
-                            o[e] = (p.dbg & 1) ? x * gt : x * gelu_erf_f(gt);
+                            o[e] = no_gelu ? x * gt : x * gelu_erf_f(gt);
                         }
                         uint2 ov; ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]);
                         *(uint2*)(Cs + ml * CSTR + ocol + 8 * g + 4 * half) = ov;

@@ -29,6 +29,7 @@
 #include "options.h"
 #include "gemm_params.h"
 #include "xl_layout.h"
+#include <type_traits>
 
 namespace mdx {
 
@@ -623,54 +624,71 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
         asm volatile("" ::: "memory");
         XL_STAMP(6)
         {
+            // The epilogue kind (plain / GEGLU / SiLU) and "addend rows per image" are wave-uniform RUNTIME facts: tested per element
+            // (round 2) the compiler kept them as scalar branches inside the unrolled loops — ~300 branches and a full IEEE division per
+            // SiLU in a 128-accumulator staging pass that took 4.7 us of a 25 us K = 640 tile (s_memtime stamps, profiles/README.md
+            // round 3).  The body is instantiated per (kind, addend mode) and the choice is made ONCE per tile.
             const int fr = lane & 15, fq = lane >> 4;
-            // without temb rows the addends depend on the column only: read the wave's TJ (x2 for GEGLU gates) vectors once, not per row tile
-            constexpr bool HOIST = BN != 320;                     // the 320-wide kernel has no registers to spare
-            float4 a4h[HOIST ? TJ : 1], g4h[HOIST ? TJ : 1];
-            if (HOIST && !has_t) {
+            auto stage = [&](auto epi_c, auto hast_c) {
+                constexpr int EPI = decltype(epi_c)::value;
+                constexpr bool HAS_T = decltype(hast_c)::value;
+                constexpr bool HOIST = BN != 320 && !HAS_T;       // column-only addends: read the wave's vectors once (the 320-wide kernel has no registers to spare)
+                float4 a4h[HOIST ? TJ : 1], g4h[HOIST ? TJ : 1];
+                if constexpr (HOIST) {
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) {
-                    const int nl = wn * TJ * 16 + j * 16 + 4 * fq;
-                    a4h[HOIST ? j : 0] = *(const float4*)(addend + nl);
-                    g4h[HOIST ? j : 0] = geglu ? *(const float4*)(addend + ((nl + 32) < BN ? nl + 32 : nl)) : a4h[HOIST ? j : 0];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                const int mt_ = wm * TI * 16 + i * 16;            // first row of this MFMA tile inside the block tile
-                if (NH > 1 && mt_ / HROWS != hh) continue;        // wave-uniform
-                const int ml = mt_ + fr;
-                int slot = 0;
-                if (has_t) slot = min(min(m0 + ml, p.M - 1) / p.rows_per_b - b0, XL_SLOTS - 1);
-                const float* ad = addend + slot * BN;
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) {
-                    if (geglu && (j & 2)) continue;               // gate tiles (columns 32..63 of a 64 group) are consumed with their value tile
-                    const int nl = wn * TJ * 16 + j * 16 + 4 * fq;   // raw column inside the tile
-                    const float4 a4 = (has_t || !HOIST) ? *(const float4*)(ad + nl) : a4h[HOIST ? j : 0];
-                    const float bb[4] = {a4.x, a4.y, a4.z, a4.w};
-                    float o[4];
-                    if (geglu) {
-                        const float4 g4 = HOIST ? g4h[HOIST ? j : 0] : *(const float4*)(ad + nl + 32);
-                        const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float x = acc[i][j][e] + bb[e];
-                            const float gt = acc[i][(TJ == 4) ? (j | 2) : j][e] + gg[e];
-                            o[e] = x * gelu_erf_f(gt);
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float x = acc[i][j][e] + bb[e];
-                            if (p.epi == 2) x = silu_f(x);
-                            o[e] = x;
-                        }
+                    for (int j = 0; j < TJ; ++j) {
+                        const int nl = wn * TJ * 16 + j * 16 + 4 * fq;
+                        a4h[j] = *(const float4*)(addend + nl);
+                        if constexpr (EPI == 1) g4h[j] = *(const float4*)(addend + ((nl + 32) < BN ? nl + 32 : nl));
                     }
-                    const int cl = geglu ? ((nl >> 6) * 32 + (nl & 31)) : nl;
-                    uint2 ov; ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]);
-                    *(uint2*)(Cs + (ml - hh * HROWS) * CSTR + cl) = ov;
                 }
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    const int mt_ = wm * TI * 16 + i * 16;        // first row of this MFMA tile inside the block tile
+                    if (NH > 1 && mt_ / HROWS != hh) continue;    // wave-uniform
+                    const int ml = mt_ + fr;
+                    int slot = 0;
+                    if constexpr (HAS_T) slot = min(min(m0 + ml, p.M - 1) / p.rows_per_b - b0, XL_SLOTS - 1);
+                    const float* ad = addend + slot * BN;
+                    bf16_t* crow = Cs + (ml - hh * HROWS) * CSTR;
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) {
+                        if (EPI == 1 && (j & 2)) continue;        // gate tiles (columns 32..63 of a 64 group) are consumed with their value tile
+                        const int nl = wn * TJ * 16 + j * 16 + 4 * fq;   // raw column inside the tile
+                        float4 a4;
+                        if constexpr (HOIST) a4 = a4h[j]; else a4 = *(const float4*)(ad + nl);
+                        const float bb[4] = {a4.x, a4.y, a4.z, a4.w};
+                        float o[4];
+                        if constexpr (EPI == 1) {
+                            float4 g4;
+                            if constexpr (HOIST) g4 = g4h[j]; else g4 = *(const float4*)(ad + nl + 32);
+                            const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float x = acc[i][j][e] + bb[e];
+                                const float gt = acc[i][(TJ == 4) ? (j | 2) : j][e] + gg[e];
+                                o[e] = x * gelu_erf_f(gt);
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float x = acc[i][j][e] + bb[e];
+                                if constexpr (EPI == 2) x = silu_f(x);
+                                o[e] = x;
+                            }
+                        }
+                        const int cl = EPI == 1 ? ((nl >> 6) * 32 + (nl & 31)) : nl;
+                        uint2 ov; ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]);
+                        *(uint2*)(crow + cl) = ov;
+                    }
+                }
+            };
+            using std::integral_constant;
+            if (geglu) {
+                if constexpr (BN == 256) stage(integral_constant<int, 1>{}, integral_constant<bool, false>{});   // (xl_supported: GEGLU only on the 256-wide tile)
+            } else {                                              // (SiLU epilogues never reach this kernel: xl_supported)
+                if (has_t) stage(integral_constant<int, 0>{}, integral_constant<bool, true>{});
+                else stage(integral_constant<int, 0>{}, integral_constant<bool, false>{});
             }
         }
         XL_STAMP(7)
@@ -850,6 +868,9 @@ bool xl_supported(const GCParams& p, bool conv, int bn) {
     if (p.col_split && (conv || p.bias || p.temb || p.R || p.epi || (p.sC & 1) || (p.ldc & 1) || p.col_split < 16)) return false;
     if (bn != 256 && bn != 160 && bn != 320) return false;
     if (p.epi == 1 && (bn != 256 || (p.N % 64))) return false;
+    // SiLU epilogue: only the prologue's map-encoder convs and the time MLP use it (never >= 160 tiles); instantiating it here cost the
+    // 256-wide kernels 17 spilled VGPRs (the residual prefetch went through scratch behind a full vmcnt wait)
+    if (p.epi == 2) return false;
     if (conv) {
         if (p.kh != 3 || p.kw != 3 || p.ph != 1 || p.pw != 1 || (p.Cin % 64) || !p.cimajor) return false;   // pad 1: input pixel index monotonic in m
         // voffsets are relative to the tile's first receptive-field pixel: 256 output pixels span < 2^31 bytes for every real shape,

@@ -16,6 +16,7 @@ namespace mdx {
     X(ATTN_NW, 0, "force the waves per workgroup of attention.hip (0 = heuristic)") \
     X(ATTN2, 1, "attention2.hip for head dim 40") \
     X(ATTN2_D80, 0, "attention2.hip also for head dim 80") \
+    X(ATTN2_FOLD, 1, "attention2.hip: subtract the running maximum inside the QK MFMA when Q is pre-scaled (head dim 40)") \
     X(ATTN2_QT, 2, "32-query tiles per wave in attention2.hip (2 or 1)") \
     X(GEMM_SWZ, 1, "XCD-aware tile order of the generic / conv3x3 kernels") \
     X(C3_DBG, 0, "conv3x3 ablation bits (wrong results)") \

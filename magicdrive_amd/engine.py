@@ -29,6 +29,12 @@ from .networks.spec import heads_at
 BF16, F32 = torch.bfloat16, torch.float32
 
 
+def q_prescale(head_dim: int) -> float:
+    """softmax scale * log2(e) (attention_processor.py: scale = head_dim ** -0.5): folded into the to_q weights when they are packed, so
+    that Q K^T is the base-2 exponent and the attention kernel can subtract the running maximum inside the QK MFMA."""
+    return float(head_dim) ** -0.5 * 1.4426950408889634
+
+
 class PackedNet:
     """Device-resident, kernel-layout weights of one network, packed lazily from a reference state dict."""
 
@@ -65,8 +71,10 @@ class PackedNet:
     def vec_bf16(self, key):
         return self._get("vecbf", [key], lambda v: v.reshape(-1).contiguous().to(BF16))
 
-    def cat_lin(self, keys: Sequence[str]):            # rows concatenated
-        return self._get("catlin", keys, lambda *ws: torch.cat([w.reshape(w.shape[0], -1) for w in ws], 0).contiguous().to(BF16))
+    def cat_lin(self, keys: Sequence[str], scales: Sequence[float] = ()):            # rows concatenated (each part optionally scaled, in fp32)
+        sc = tuple(scales) if scales else (1.0,) * len(keys)
+        return self._get(("catlin",) + sc, keys,
+                         lambda *ws: torch.cat([w.reshape(w.shape[0], -1) * f for w, f in zip(ws, sc)], 0).contiguous().to(BF16))
 
     def cat_vec(self, keys: Sequence[str]):
         return self._get("catvec", keys, lambda *vs: torch.cat([v.reshape(-1) for v in vs]).contiguous().to(F32))
@@ -238,18 +246,19 @@ class Builder:
         two neighbour views (attn4).  n: normalised tokens [B*T, C]."""
         ldv = PK.round_up(T, 8)
         vt = self.pool.get((B, C, ldv))
+        qs = q_prescale(C // heads)         # softmax scale * log2(e), folded into to_q (MdxAttnDesc.q_prescaled)
         if C == 320 and T % 8 == 0 and B * T >= 8192:
             # level 0: ONE weight-stationary launch pair reads the tokens for q, k and v; the V columns are stored transposed
             # (gemm_ws.hip) — replaces the batched V^T GEMM (245 TFLOP/s, 2 % of the step)
             qk = self.pool.get((B * T, 2 * C))
-            self.emit(O.Gemm(n, net.cat_lin([pre + "to_q.weight", pre + "to_k.weight", pre + "to_v.weight"]), qk, Vt=vt, vt_from=2 * C, vt_T=T,
+            self.emit(O.Gemm(n, net.cat_lin([pre + "to_q.weight", pre + "to_k.weight", pre + "to_v.weight"], (qs, 1.0, 1.0)), qk, Vt=vt, vt_from=2 * C, vt_T=T,
                              ws=self.ws, name=name + ".qkv"))
         else:
-            qk = self.gemm(n, net.cat_lin([pre + "to_q.weight", pre + "to_k.weight"]), 2 * C, name=name + ".qk")
+            qk = self.gemm(n, net.cat_lin([pre + "to_q.weight", pre + "to_k.weight"], (qs, 1.0)), 2 * C, name=name + ".qk")
             self.emit(O.Gemm(net.lin(pre + "to_v.weight"), n.view(B, T, C), vt[:, :, :T], name=name + ".vT"))
         ao = self.pool.get((B * T, C))
         qk3 = qk.view(B, T, 2 * C)
-        self.emit(O.Attn(qk3[:, :, :C], qk3[:, :, C:], vt, ao.view(B, T, C), heads=heads, Tk=T, scale=(C // heads) ** -0.5,
+        self.emit(O.Attn(qk3[:, :, :C], qk3[:, :, C:], vt, ao.view(B, T, C), heads=heads, Tk=T, scale=(C // heads) ** -0.5, q_prescaled=True,
                          kvmap=self.kvmap if cross_view else None, nsrc=self.xv_nsrc if cross_view else 1,
                          joint=cross_view and self.nattn != "add", name=name + ".attn"))
         self.pool.put(qk)
@@ -266,11 +275,11 @@ class Builder:
         self.pool.put(ao); self.pool.put(h)
         # 2. context cross-attention with prologue-computed K / V^T
         n2 = self.layernorm(net, pre + "norm2.", h1, name + ".norm2")
-        q2 = self.gemm(n2, net.lin(pre + "attn2.to_q.weight"), C, name=name + ".attn2.q")
+        q2 = self.gemm(n2, net.lin(pre + "attn2.to_q.weight", q_prescale(C // heads)), C, name=name + ".attn2.q")
         self.pool.put(n2)
         Kc, Vtc, S = ctx_kv[pre + "attn2."]
         ao2 = self.pool.get((B * T, C))
-        self.emit(O.Attn(q2.view(B, T, C), Kc, Vtc, ao2.view(B, T, C), heads=heads, Tk=S, scale=(C // heads) ** -0.5, name=name + ".attn2"))
+        self.emit(O.Attn(q2.view(B, T, C), Kc, Vtc, ao2.view(B, T, C), heads=heads, Tk=S, scale=(C // heads) ** -0.5, q_prescaled=True, name=name + ".attn2"))
         self.pool.put(q2)
         h2 = self.gemm(ao2, net.lin(pre + "attn2.to_out.0.weight"), C, bias=net.vec(pre + "attn2.to_out.0.bias"), R=h1, name=name + ".attn2.out")
         self.pool.put(ao2); self.pool.put(h1)

@@ -202,6 +202,7 @@ class Attn:
     nsrc: int = 1
     name: str = ""
     joint: bool = False                      # one softmax over the concatenated sources (neighboring_attn_type concat / self) instead of a sum of per-source attentions
+    q_prescaled: bool = False                # Q already carries scale * log2(e) (folded into to_q at pack time): probabilities are exp2(Q K^T - max)
     opcode = L.OP_ATTN
 
     def lower(self):
@@ -224,6 +225,7 @@ class Attn:
         d.ldo, d.sO = O.stride(1), O.stride(0)
         d.scale = float(self.scale)
         d.joint = int(self.joint)
+        d.q_prescaled = int(self.q_prescaled)
         _chk(self.nsrc >= 1 and (self.nsrc <= 8 if self.joint else self.nsrc <= 2), f"attn {self.name}: nsrc={self.nsrc} (joint={self.joint})")
         return self.opcode, d
 

@@ -83,8 +83,10 @@ def run_attn(op: O.Attn):
         vhs.append(Vt[idx].transpose(1, 2).reshape(B, op.Tk, H, d).transpose(1, 2))
     if getattr(op, "joint", False):            # one softmax over the concatenated sources
         khs, vhs = [torch.cat(khs, 2)], [torch.cat(vhs, 2)]
+    # q_prescaled: the to_q weights carry scale * log2(e), scores are base-2 exponents: exp2(s) = exp(s ln 2)
+    sc = 0.6931471805599453 if getattr(op, "q_prescaled", False) else op.scale
     for kh, vh in zip(khs, vhs):
-        att = torch.softmax(qh @ kh.transpose(-1, -2) * op.scale, -1)
+        att = torch.softmax(qh @ kh.transpose(-1, -2) * sc, -1)
         out += (att @ vh).transpose(1, 2).reshape(B, Tq, Cc)
     op.O.copy_(out.to(op.O.dtype))
 

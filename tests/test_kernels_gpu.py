@@ -583,7 +583,8 @@ def test_attention_short_crossview_many_heads(dev):
     (2, 8, 350, 80, 2, "attn_kernel<5,4,joint>"),           # attention.hip
     (2, 8, 91, 160, 6, "attn_kernel<10,2,joint>"),
 ])
-def test_attention_joint_sources(dev, b, heads, T, d, nsrc, expect):
+@pytest.mark.parametrize("pre", [False, True])
+def test_attention_joint_sources(dev, b, heads, T, d, nsrc, expect, pre):
     """MdxAttnDesc.joint: ONE softmax over the concatenation of the nsrc kv sources (neighboring_attn_type concat / self, blocks.py:122-138)
     — not the sum of per-source attentions."""
     ncam = 6
@@ -594,27 +595,45 @@ def test_attention_joint_sources(dev, b, heads, T, d, nsrc, expect):
     srcs = lambda i: [(i // ncam) * ncam + c for c in (range(ncam) if nsrc == ncam else pair[i % ncam])]
     kvmap = torch.tensor([j for i in range(B) for j in srcs(i)], dtype=torch.int32, device=dev)
     o = torch.zeros(B, T, Cc, dtype=BF, device=dev)
-    O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=T, scale=d ** -0.5, kvmap=kvmap, nsrc=nsrc, joint=True)])
+    qpre = d ** -0.5 * 1.4426950408889634
+    qref = q
+    if pre:                                  # MdxAttnDesc.q_prescaled (every kernel takes it; head dim 40 folds the maximum into the MFMA)
+        q = (q.float() * qpre).to(BF); qref = q.float() / qpre
+        if d == 40: expect = expect.replace(">", ",fold>")
+    O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=T, scale=d ** -0.5, kvmap=kvmap, nsrc=nsrc, joint=True, q_prescaled=pre)])
     kern = (L.lib().mdx_last_kernel() or b"").decode()
     torch.cuda.synchronize()
     assert kern == expect, kern
-    qc, kc, vc = q.float().cpu(), k.float().cpu(), v.float().cpu()
+    qc, kc, vc = qref.float().cpu(), k.float().cpu(), v.float().cpu()
     ref = torch.zeros(B, T, Cc)
     for i in range(B):
         js = srcs(i)
         ref[i] = ref_attention(qc[i:i + 1], torch.cat([kc[j] for j in js])[None], torch.cat([vc[j] for j in js])[None], heads, d ** -0.5)[0]
-    close(o, ref, name=f"attn joint {nsrc} sources")
+    close(o, ref, name=f"attn joint {nsrc} sources{' prescaled' if pre else ''}")
 
 
 # ---- attention2.hip (head dim 40, >= 128 workgroups; 80 behind MDX_ATTN2_D80): routes asserted, the rare branches forced ---------
-def attn2_route(d, Tq, xview=False):
+QPRE = lambda d: d ** -0.5 * 1.4426950408889634     # what engine.q_prescale folds into to_q
+
+
+def prescale_q(q, d, pre):
+    """(Q for the kernel, Q for the reference): pre = the q_prescaled form — Q' = bf16(Q * scale * log2 e); the reference gets Q' / that
+    factor, i.e. the same rounded values."""
+    if not pre:
+        return q, q
+    qp = (q.float() * QPRE(d)).to(BF)
+    return qp, (qp.float() / QPRE(d))
+
+
+def attn2_route(d, Tq, xview=False, pre=False):
     """Kernel mdx_attention_bf16 must pick for (d, Tq) under the library's current switches (csrc/options.h;
     tests/test_routes_gpu.py::test_forced_attention_routes re-runs these tests with ATTN2_QT=1, ATTN2_D80=1 and ATTN2=0)."""
     mode = "xview" if xview else "self"
     if L.get_option("ATTN2") == 0 or (d == 80 and L.get_option("ATTN2_D80") == 0):
         return "attn_kernel<"                                       # attention.hip (prefix)
     q = 64 if (d == 40 and Tq >= 512 and L.get_option("ATTN2_QT") == 2) else 32
-    return f"attn2_kernel<{d},{mode},q{q}>"
+    fold = ",fold" if (pre and d == 40 and L.get_option("ATTN2_FOLD")) else ""
+    return f"attn2_kernel<{d},{mode},q{q}{fold}>"
 
 
 ATTN2_CASES = [
@@ -629,23 +648,28 @@ ATTN2_CASES = [
 ]
 
 
+@pytest.mark.parametrize("pre", [False, True])
 @pytest.mark.parametrize("B,heads,Tq,Tk,d", ATTN2_CASES)
-def test_attention2(dev, B, heads, Tq, Tk, d):
+def test_attention2(dev, B, heads, Tq, Tk, d, pre):
+    """pre: Q pre-scaled by scale * log2(e) (MdxAttnDesc.q_prescaled) — head dim 40 then runs the FOLD instances (running maximum
+    subtracted inside the QK MFMA), head dim 80 the plain ones with a unit scale."""
     Cc = heads * d
     q = rnd(B, Tq, Cc, seed=1); k = rnd(B, Tk, Cc, seed=2); v = rnd(B, Tk, Cc, seed=3)
+    q, qref = prescale_q(q, d, pre)
     ldv = PK.round_up(Tk, 8)
     vt = torch.full((B, Cc, ldv), float("nan"), dtype=BF, device=dev)   # garbage in the kv pad must not leak
     vt[:, :, :Tk] = v.transpose(1, 2)
     o = torch.full((B, Tq, Cc), float("nan"), dtype=BF, device=dev)
-    O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=Tk, scale=d ** -0.5)])
+    O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=Tk, scale=d ** -0.5, q_prescaled=pre)])
     kern = (L.lib().mdx_last_kernel() or b"").decode()
     torch.cuda.synchronize()
-    assert kern.startswith(attn2_route(d, Tq)), kern
-    ref = ref_attention(q.float().cpu(), k.float().cpu(), v.float().cpu(), heads, d ** -0.5)
-    close(o, ref, name=f"attn2 {B},{heads},{Tq},{Tk},{d}")
+    assert kern.startswith(attn2_route(d, Tq, pre=pre)), kern
+    ref = ref_attention(qref.float().cpu(), k.float().cpu(), v.float().cpu(), heads, d ** -0.5)
+    close(o, ref, name=f"attn2 {B},{heads},{Tq},{Tk},{d}{' prescaled' if pre else ''}")
 
 
-def test_attention2_softmax_rescale_branch(dev):
+@pytest.mark.parametrize("pre", [False, True])
+def test_attention2_softmax_rescale_branch(dev, pre):
     """cdna guide rule 26 on the new kernel: the running max jumps in a LATE kv tile for one query (and early for another) by far more
     than the deferral threshold, so the O accumulators (16x16 layout) must be rescaled with the alpha of the right query lane — while
     the other queries of the same wave, whose max did not move, are multiplied by exactly 1; fp64 reference."""
@@ -655,18 +679,22 @@ def test_attention2_softmax_rescale_branch(dev):
     for h in range(heads):
         k[0, 400, h * d:(h + 1) * d] = q[0, 5 + h, h * d:(h + 1) * d] * 6.0       # spike in the 7th tile for query 5 + h of head h
         k[1, 10, h * d:(h + 1) * d] = q[1, 200 + 17 * h, h * d:(h + 1) * d] * 6.0  # an early one that later tiles must not disturb
+        k[2, 30, h * d:(h + 1) * d] = q[2, 100 + h, h * d:(h + 1) * d] * -9.0      # a strongly NEGATIVE score in the first tile (FOLD: the first tile re-bases from m = 0)
+    q[3] = q[3] * 0.01                                                              # a view whose scores are all tiny: the maximum never exceeds the deferral threshold
     vt = torch.zeros(B, Cc, Tk, dtype=BF, device=dev); vt[:] = v.transpose(1, 2)
     o = torch.zeros(B, Tq, Cc, dtype=BF, device=dev)
-    O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=Tk, scale=d ** -0.5)])
+    q, qref = prescale_q(q, d, pre)
+    O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=Tk, scale=d ** -0.5, q_prescaled=pre)])
     kern = (L.lib().mdx_last_kernel() or b"").decode()
     torch.cuda.synchronize()
-    assert kern.startswith(attn2_route(40, Tq)), kern
-    ref = ref_attention(q.double().cpu(), k.double().cpu(), v.double().cpu(), heads, d ** -0.5)
-    close(o, ref, name="attn2 rescale")
+    assert kern.startswith(attn2_route(40, Tq, pre=pre)), kern
+    ref = ref_attention(qref.double().cpu(), k.double().cpu(), v.double().cpu(), heads, d ** -0.5)
+    close(o, ref, name=f"attn2 rescale{' prescaled' if pre else ''}")
 
 
+@pytest.mark.parametrize("pre", [False, True])
 @pytest.mark.parametrize("b,heads,T,d", [(1, 8, 1400, 40), (3, 8, 350, 80), (2, 8, 700, 40)])
-def test_attention2_crossview(dev, b, heads, T, d):
+def test_attention2_crossview(dev, b, heads, T, d, pre=False):
     ncam = 6
     pair = {0: [5, 1], 1: [0, 2], 2: [1, 3], 3: [2, 4], 4: [3, 5], 5: [4, 0]}
     Cc = heads * d; B = b * ncam
@@ -674,14 +702,15 @@ def test_attention2_crossview(dev, b, heads, T, d):
     vt = torch.full((B, Cc, PK.round_up(T, 8)), float("nan"), dtype=BF, device=dev); vt[:, :, :T] = v.transpose(1, 2)
     kvmap = torch.tensor([(i // ncam) * ncam + pair[i % ncam][s] for i in range(B) for s in range(2)], dtype=torch.int32, device=dev)
     o = torch.zeros(B, T, Cc, dtype=BF, device=dev)
-    O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=T, scale=d ** -0.5, kvmap=kvmap, nsrc=2)])
+    q, qref = prescale_q(q, d, pre)
+    O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=T, scale=d ** -0.5, kvmap=kvmap, nsrc=2, q_prescaled=pre)])
     kern = (L.lib().mdx_last_kernel() or b"").decode()
     torch.cuda.synchronize()
-    assert kern.startswith(attn2_route(d, T, xview=True)), kern
-    qc, kc, vc = q.float().cpu(), k.float().cpu(), v.float().cpu()
+    assert kern.startswith(attn2_route(d, T, xview=True, pre=pre)), kern
+    qc, kc, vc = qref.float().cpu(), k.float().cpu(), v.float().cpu()
     ref = torch.zeros(B, T, Cc)
     for i in range(B):
         for s in range(2):
             j = (i // ncam) * ncam + pair[i % ncam][s]
             ref[i] += ref_attention(qc[i:i + 1], kc[j:j + 1], vc[j:j + 1], heads, d ** -0.5)[0]
-    close(o, ref, name="attn2 cross-view")
+    close(o, ref, name=f"attn2 cross-view{' prescaled' if pre else ''}")

@@ -42,7 +42,7 @@ def run_one(op):
 # gemm_xl.hip — GEMM
 @pytest.mark.parametrize("M,N,K,bias,res,inplace,epi,expect", [
     (41037, 1280, 1280, True, True, False, 0, "gemm_xl_kernel<256x"),              # ragged M, residual
-    (41000, 640, 640, True, False, False, 2, "gemm_xl_kernel<256x"),                # SiLU epilogue
+    (41000, 640, 640, True, False, False, 2, "gemm_conv_kernel<128,128,64"),        # SiLU epilogue: declined by XL (xl_supported), generic tile
     (82000, 320, 1280, True, True, True, 0, "gemm_xl_kernel<256x"),        # ff.out at level 0: in-place residual (R == C)
     (82000, 160, 640, True, False, False, 0, "gemm_xl_kernel<256x"),       # one 160-wide N tile
     (41000, 644, 640, False, False, False, 0, "gemm_xl_kernel<256x"),               # N % 8 != 0: narrow stores, ragged last N tile
@@ -210,7 +210,8 @@ def test_forced_xl_widths(dev, bn, raster):
         g, c = f"gemm_xl_kernel<256x{bn},gemm>", f"gemm_xl_kernel<256x{bn},conv>"
         gemm_case(2000, 640, 640, res=True, expect=g)                 # ragged M (7.8 tiles), N = 2-4 tiles
         gemm_case(777, 324, 128, bias=False, expect=g)                # N % 8 != 0: narrow stores; ragged everything; two slabs
-        gemm_case(5000, 320, 64, epi=2, expect=g)                     # one slab, SiLU
+        gemm_case(5000, 320, 64, expect=g)                            # one slab
+        gemm_case(5000, 320, 64, epi=2, expect="gemm_conv_kernel<")   # SiLU epilogues stay off the XL kernel even when it is forced
         gemm_case(3000, 1280, 960, res=True, expect=g)                # 15 slabs (K < 1024: no automatic split-K)
         gemm_case(30000, 1600, 128, res=True, expect=g)               # 118 M-tiles x 5-10 N-tiles: several XCD panels, ragged last N-group
         conv_case(6, 28, 50, 320, 320, expect=c)                      # level-0 resnet conv
@@ -244,17 +245,18 @@ def test_forced_geglu320_on_xl(dev):
         assert geglu_case(26400, 1280, 320) == "gemm_xl_kernel<256x256,gemm>"
 
 
-@pytest.mark.parametrize("mode,opts", [("attn_q32", {"ATTN2_QT": 1}), ("attn_d80", {"ATTN2_D80": 1}), ("attn_old", {"ATTN2": 0})])
+@pytest.mark.parametrize("mode,opts", [("attn_q32", {"ATTN2_QT": 1}), ("attn_d80", {"ATTN2_D80": 1}), ("attn_old", {"ATTN2": 0}), ("attn_nofold", {"ATTN2_FOLD": 0})])
 def test_forced_attention_routes(dev, mode, opts):
     """attention2.hip's other instantiations (32-query waves; head dim 80) and attention.hip at the same shapes, through the tests of
     tests/test_kernels_gpu.py (their route assertions follow the current switches)."""
     import test_kernels_gpu as T
     with L.options(**opts):
-        for case in T.ATTN2_CASES:
-            T.test_attention2(dev, *case)
-        T.test_attention2_softmax_rescale_branch(dev)
-        for case in [(1, 8, 1400, 40), (3, 8, 350, 80), (2, 8, 700, 40)]:
-            T.test_attention2_crossview(dev, *case)
+        for pre in (False, True):
+            for case in T.ATTN2_CASES:
+                T.test_attention2(dev, *case, pre)
+            T.test_attention2_softmax_rescale_branch(dev, pre)
+            for case in [(1, 8, 1400, 40), (3, 8, 350, 80), (2, 8, 700, 40)]:
+                T.test_attention2_crossview(dev, *case, pre)
 
 
 def test_set_option_rejects_unknown_key():
