@@ -26,7 +26,7 @@ _lib = None
 class MdxAttnDesc(ctypes.Structure):               # mirrors include/mdx.h MdxAttnDesc field for field
     _fields_ = [(n, ctypes.c_void_p) for n in "Q K Vt O kvmap reserved_p".split()] + \
                [(n, ctypes.c_int64) for n in "B H Tq Tk d nsrc ldq sQ ldk sK ldv sV ldo sO".split()] + \
-               [("scale", ctypes.c_double), ("joint", ctypes.c_int64)]
+               [("scale", ctypes.c_double), ("joint", ctypes.c_int64), ("q_prescaled", ctypes.c_int64)]   # q_prescaled = 0: plain Q
 
 
 def _mdx():

@@ -46,3 +46,13 @@ def test_bad_descriptor_is_rejected_without_a_gpu():
     d = L.MdxGemmDesc()
     rc = L.lib().mdx_gemm_bf16(ctypes.byref(d), None)
     assert rc == -1 and b"null operand" in L.lib().mdx_last_error()
+
+
+def test_integration_binding_struct_matches_the_abi():
+    """The reference-side binding of INTEGRATION.md §2 declares MdxAttnDesc by hand: it must stay byte-compatible with include/mdx.h
+    (a stale copy passes garbage in the new trailing fields — caught on the GPU only as a run-time error otherwise)."""
+    import ctypes
+    from magicdrive_amd import _lib as L
+    from magicdrive_amd.integration import attn_processor as AP
+    assert ctypes.sizeof(AP.MdxAttnDesc) == ctypes.sizeof(L.MdxAttnDesc)
+    assert [f[0] for f in AP.MdxAttnDesc._fields_] == [f[0] for f in L.MdxAttnDesc._fields_]

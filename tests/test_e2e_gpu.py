@@ -12,7 +12,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from helpers import given_view_inputs, bf16_round, cfg_inputs, rel_l2, scene, state_dicts
+from helpers import check, given_view_inputs, bf16_round, cfg_inputs, rel_l2, scene, state_dicts
 from magicdrive_amd import denoiser as DN, schedulers
 from magicdrive_amd.engine import PackedNet
 from magicdrive_amd.networks import spec
@@ -43,16 +43,16 @@ def test_controlnet_and_unet_forward_tiny(dev, tiny):
     cp = DN.ControlNetPlan(cfg, cn, dev, nb, Lb, hw)
     down, mid, ctx_g = cp.run(lat, t, sc["camera_param"], sc["bboxes_3d_data"], sc["prompt_embeds"], sc["bev_map"])
     torch.cuda.synchronize()
-    assert rel_l2(ctx_g[:, 0], ctx[:, 0]) < 1e-2, "camera token"
-    assert rel_l2(ctx_g[:, 78:], ctx[:, 78:]) < 1e-2, "box tokens"
+    check("tiny forward: camera token", rel_l2(ctx_g[:, 0], ctx[:, 0]), 1e-2)
+    check("tiny forward: box tokens", rel_l2(ctx_g[:, 78:], ctx[:, 78:]), 1e-2)
     assert torch.equal(ctx_g[:, 1:78].float().cpu(), ctx[:, 1:78].to(torch.bfloat16).float()), "text tokens are a pure copy"
     for k, (a, b_) in enumerate(zip(down, d)):
-        assert per_view_max_rel(a, b_) < 3e-2, f"down residual {k}: {per_view_max_rel(a, b_)}"
-    assert per_view_max_rel(mid, m) < 3e-2
+        check(f"tiny forward: down residual {k}", per_view_max_rel(a, b_), 2.5e-2)
+    check("tiny forward: mid residual", per_view_max_rel(mid, m), 2.5e-2)
     up = DN.UNetPlan(cfg, un, dev, nb * 6, ctx.shape[1], hw)
     out = up.run(lat.reshape(-1, 4, *hw), t.repeat_interleave(6), ctx, d, m)
     torch.cuda.synchronize()
-    assert per_view_max_rel(out, e) < 3e-2, per_view_max_rel(out, e)
+    check("tiny forward: eps per view", per_view_max_rel(out, e), 2.5e-2)
 
 
 @pytest.mark.parametrize("do_cfg,Lb", [(True, 5), (False, 0)])
@@ -75,8 +75,7 @@ def test_sampler_loop_tiny(dev, tiny, do_cfg, Lb):
     eager = sp.run(use_graph=False).cpu()
     torch.cuda.synchronize()
     assert sp.step_ctr.item() == steps
-    assert rel_l2(eager, ref) < 5e-2, rel_l2(eager, ref)
-    assert max(rel_l2(eager[:, v], ref[:, v]) for v in range(6)) < 5e-2
+    check(f"tiny sampler loop cfg={do_cfg}", max(rel_l2(eager[:, v], ref[:, v]) for v in range(6)), 2.5e-2)
     # same plan replayed as a captured hipGraph must give bit-identical latents
     sp.load_inputs(lat6, cam, text, bev, boxes, ts, sch.coefficient_table())
     graph = sp.run(use_graph=True).cpu()
@@ -104,15 +103,15 @@ def test_real_size_one_pass_sd15(dev):
     cp = DN.ControlNetPlan(cfg, cn, dev, nb, Lb, hw)
     down, mid, ctx_g = cp.run(lat, t, sc["camera_param"], sc["bboxes_3d_data"], sc["prompt_embeds"], sc["bev_map"])
     torch.cuda.synchronize()
-    assert rel_l2(ctx_g, ctx) < 1e-2
+    check("sd15 one pass: ctx", rel_l2(ctx_g, ctx), 1e-2)
     errs = [per_view_max_rel(a, b_) for a, b_ in zip(down, d)] + [per_view_max_rel(mid, m)]
-    assert max(errs) < 3e-2, errs
+    check("sd15 one pass: controlnet residuals", max(errs), 2.5e-2)
     up = DN.UNetPlan(cfg, un, dev, nb * 6, ctx.shape[1], hw)
     out = up.run(lat.reshape(-1, 4, *hw), 501, ctx, d, m)
     torch.cuda.synchronize()
     err = per_view_max_rel(out, e)
     print(f"[sd15 one pass] controlnet residual max rel {max(errs):.4f}; eps per-view max rel {err:.4f}")
-    assert err < 3e-2, err
+    check("sd15 one pass: eps per view", err, 2.2e-2)
 
 
 def test_pipeline_call_matches_reference_goldens(dev):
@@ -136,7 +135,7 @@ def test_pipeline_call_matches_reference_goldens(dev):
     assert out.shape == (2, 6, 4, 28, 50)
     e1, e2 = rel_l2(out, G["latents_cfg"]), rel_l2(out2, G["latents_textonly"])
     print(f"[pipeline vs reference golden] cfg {e1:.4f} text-only {e2:.4f}")
-    assert e1 < 5e-2 and e2 < 5e-2
+    check("tiny pipeline vs reference golden: cfg", e1, 2.2e-2); check("tiny pipeline vs reference golden: text-only", e2, 1.2e-2)
 
 
 def test_pipeline_call_unipc_matches_reference_golden(dev):
@@ -160,7 +159,8 @@ def test_pipeline_call_unipc_matches_reference_golden(dev):
     torch.cuda.synchronize()
     e1 = rel_l2(out, G["latents_cfg"])
     print(f"[pipeline UniPC vs reference golden] {e1:.4f}")
-    assert e1 < 5e-2 and torch.equal(out, out_again)
+    check("tiny UniPC pipeline vs reference golden", e1, 2e-2)
+    assert torch.equal(out, out_again)
 
 
 def test_module_api_forward(dev):
@@ -176,11 +176,12 @@ def test_module_api_forward(dev):
     t = G["timesteps"]
     down, mid, ctx = cn(lat.to(dev), t.to(dev), sc["camera_param"].to(dev), {k: v.to(dev) for k, v in sc["bboxes_3d_data"].items()},
                         sc["prompt_embeds"].to(dev), sc["bev_map"].to(dev), return_dict=False)
-    assert len(down) == 12 and rel_l2(mid, G["mid"]) < 3e-2 and rel_l2(ctx, G["ctx"].float()) < 1e-2
+    assert len(down) == 12
+    check("module API vs reference golden: mid", rel_l2(mid, G["mid"]), 2.5e-2); check("module API vs reference golden: ctx", rel_l2(ctx, G["ctx"].float()), 1e-2)
     eps = unet(lat.reshape(-1, 4, 28, 50).to(dev), t.repeat_interleave(6).to(dev), encoder_hidden_states=ctx,
                down_block_additional_residuals=down, mid_block_additional_residual=mid).sample
     torch.cuda.synchronize()
-    assert max(rel_l2(eps[i], G["eps"][i]) for i in range(12)) < 4e-2
+    check("module API vs reference golden: eps per view", max(rel_l2(eps[i], G["eps"][i]) for i in range(12)), 3e-2)
 
 
 @pytest.mark.parametrize("every", [True, False])
@@ -202,7 +203,7 @@ def test_given_view_pipeline_matches_reference_golden(dev, every):
     torch.cuda.synchronize()
     e = rel_l2(out, G["latents_every" if every else "latents_once"])
     print(f"[given-view pipeline (every_input={every}) vs reference golden] {e:.4f}")
-    assert e < 5e-2
+    check("given-view pipeline vs reference golden", e, 2.2e-2)
 
 
 def test_vae_decode_matches_diffusers_golden(dev):
@@ -216,7 +217,8 @@ def test_vae_decode_matches_diffusers_golden(dev):
     torch.cuda.synchronize()
     e = rel_l2(img, G["image"].float())
     print(f"[VAE decode vs diffusers golden] rel L2 {e:.4f}")
-    assert img.shape == (2, 3, 56, 104) and e < 3e-2
+    assert img.shape == (2, 3, 56, 104)
+    check("VAE decode vs diffusers golden", e, 2.7e-2)
 
 
 def test_vae_decode_real_size_sd15(dev):
@@ -234,7 +236,7 @@ def test_vae_decode_real_size_sd15(dev):
     assert img.shape == (6, 3, 224, 400)
     e = max(rel_l2(img[v], ref[v]) for v in range(6))
     print(f"[SD-1.5 VAE decode, 6 views 224x400 vs oracle] worst per-view rel L2 {e:.4f}")
-    assert e < 3e-2
+    check("SD-1.5 VAE decode vs oracle", e, 2.2e-2)
 
 
 def test_pipeline_images_through_hip_vae(dev):
@@ -277,13 +279,13 @@ def test_module_api_forward_hires_plus_map_encoder(dev):
     t = G["timesteps"]
     down, mid, ctx = cn(lat.to(dev), t.to(dev), sc["camera_param"].to(dev), {k: v.to(dev) for k, v in sc["bboxes_3d_data"].items()},
                         sc["prompt_embeds"].to(dev), sc["bev_map"].to(dev), return_dict=False)
-    assert rel_l2(mid, G["mid"]) < 3e-2 and rel_l2(down[0][:, :, ::9, ::12], G["down_first"]) < 3e-2
+    check("tiny hires: mid", rel_l2(mid, G["mid"]), 3e-2); check("tiny hires: down0", rel_l2(down[0][:, :, ::9, ::12], G["down_first"]), 3e-2)
     eps = unet(lat.reshape(-1, 4, *hw).to(dev), t.repeat_interleave(6).to(dev), encoder_hidden_states=ctx,
                down_block_additional_residuals=down, mid_block_additional_residual=mid).sample
     torch.cuda.synchronize()
     e = max(rel_l2(eps[i], G["eps"][i].float()) for i in range(6))
     print(f"[hires 54x96 + Plus map encoder vs reference golden] eps per-view max rel {e:.4f}")
-    assert e < 4e-2
+    check("tiny hires: eps per view", e, 3.6e-2)
 
 
 @pytest.mark.parametrize("mode", ["concat", "self"])
@@ -308,7 +310,8 @@ def test_module_api_forward_neighboring_attn_modes(dev, mode):
     other = "self" if mode == "concat" else "concat"
     eo = min(rel_l2(eps[i], G["eps_" + other][i].float()) for i in range(6))
     print(f"[neighboring_attn_type={mode} vs reference golden] eps per-view max rel {e:.4f} (vs the other mode's golden: {eo:.4f})")
-    assert e < 4e-2 and eo > 2 * e
+    check(f"neighboring_attn_type={mode}: eps per view", e, 3.6e-2)
+    assert eo > 2 * e
 
 
 def test_real_size_ddim_loop_sd15(dev):
@@ -336,7 +339,8 @@ def test_real_size_ddim_loop_sd15(dev):
     err = rel_l2(out, ref)
     per_view = max(rel_l2(out[:, v], ref[:, v]) for v in range(6))
     print(f"[sd15 {steps}-step DDIM loop] rel L2 vs oracle {err:.4f} (worst view {per_view:.4f}), |x| = {ref.abs().mean().item():.2f}")
-    assert torch.isfinite(out).all() and per_view < (5e-2 if steps <= 10 else 1e-1), (err, per_view)
+    assert torch.isfinite(out).all()
+    check(f"sd15 {steps}-step loop vs oracle", per_view, 2e-2)
 
 
 def test_real_size_ddim_loop_sd15_full_conditioning(dev):
@@ -366,7 +370,8 @@ def test_real_size_ddim_loop_sd15_full_conditioning(dev):
     err = rel_l2(out, ref)
     per_view = max(rel_l2(out[:, v], ref[:, v]) for v in range(6))
     print(f"[sd15 {steps}-step DDIM loop, camera + 32 boxes + map + CFG 2] rel L2 vs oracle {err:.4f} (worst view {per_view:.4f})")
-    assert torch.isfinite(out).all() and per_view < (5e-2 if steps <= 10 else 1e-1), (err, per_view)
+    assert torch.isfinite(out).all()
+    check(f"sd15 {steps}-step loop vs oracle", per_view, 2e-2)
 
 
 def test_batch_consistency_sd15(dev):
@@ -390,7 +395,7 @@ def test_batch_consistency_sd15(dev):
         one = call(scs[k]["latents"], scs[k]["prompt_embeds"], scs[k]["negative_prompt_embeds"], scs[k]["bev_map"])
         e = max(rel_l2(big[k:k + 1, v], one[:, v]) for v in range(6))
         print(f"[batch consistency] scene {k} of {nb} vs alone: per-view max rel {e:.4f}")
-        assert e < 3e-2, (k, e)
+        check(f"batch consistency scene {k}", e, 1e-2)
 
 
 def test_sample_driver_end_to_end(dev, tmp_path):

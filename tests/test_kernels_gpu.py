@@ -694,7 +694,7 @@ def test_attention2_softmax_rescale_branch(dev, pre):
 
 @pytest.mark.parametrize("pre", [False, True])
 @pytest.mark.parametrize("b,heads,T,d", [(1, 8, 1400, 40), (3, 8, 350, 80), (2, 8, 700, 40)])
-def test_attention2_crossview(dev, b, heads, T, d, pre=False):
+def test_attention2_crossview(dev, b, heads, T, d, pre):
     ncam = 6
     pair = {0: [5, 1], 1: [0, 2], 2: [1, 3], 3: [2, 4], 4: [3, 5], 5: [4, 0]}
     Cc = heads * d; B = b * ncam

@@ -3,7 +3,7 @@ sd15cfg / sd15hires: /root/reference's StableDiffusionBEVControlNetPipeline.__ca
 BEVControlNetModel / UNet2DConditionModelMultiview forwards, fp32 arithmetic on the bf16-rounded seeded weights).  No CPU oracle runs
 here, so the full 50-step loop costs GPU seconds.  Plus the reference's two other shipped resolutions at tiny width.
 
-Tolerances are <= 2x what was measured on MI355X (recorded per test in gpurun_out/parity_measured.jsonl -> profiles/): the bf16 path
+Tolerances are <= 2x what was measured on MI355X (recorded per test in profiles/r03_parity_measured.jsonl): the bf16 path
 differs from the fp32 reference by the activation rounding only (same weights)."""
 import os
 
@@ -12,7 +12,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from helpers import parity_log, rel_l2, scene
+from helpers import check, parity_log, rel_l2, scene
 from magicdrive_amd.networks import spec
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -64,8 +64,8 @@ def test_sd15_50step_ddim_loop_vs_reference(dev, sd15_pipe):
     parity_log("sd15_50step_ddim_loop_vs_reference", worst_view_rel_l2=max(per_view), all_rel_l2=rel_l2(out, ref),
                trace={str(k): round(v, 5) for k, v in tr.items()}, absmean=ref.abs().mean().item())
     assert torch.isfinite(out).all() and sorted(trace) == sorted(G["trace"])
-    assert max(per_view) < 2e-2, per_view
-    assert max(tr.values()) < 2e-2, tr
+    check("sd15 50-step DDIM loop vs REAL reference: worst view", max(per_view), 1e-2)        # measured 0.41 %
+    check("sd15 50-step DDIM loop vs REAL reference: worst trace point", max(tr.values()), 1e-2)
 
 
 def test_sd15_cfg_loop_full_conditioning_vs_reference(dev, sd15_pipe):
@@ -91,8 +91,8 @@ def test_sd15_cfg_loop_full_conditioning_vs_reference(dev, sd15_pipe):
     parity_log("sd15_cfg_loop_full_conditioning_vs_reference", worst_view_rel_l2=max(per_view), all_rel_l2=rel_l2(out, ref),
                trace={str(k): round(v, 5) for k, v in tr.items()})
     assert torch.isfinite(out).all()
-    assert max(per_view) < 2e-2, per_view
-    assert max(tr.values()) < 2e-2, tr
+    check("sd15 10-step CFG loop vs REAL reference: worst view", max(per_view), 1.5e-2)        # measured 0.72 %
+    check("sd15 10-step CFG loop vs REAL reference: worst trace point", max(tr.values()), 1.5e-2)
 
 
 def _module_forward(cfg, G, dev, n_box=3, map_size=200):
@@ -123,7 +123,9 @@ def test_sd15_forward_hires_vs_reference(dev):
     dm = max(abs(x.float().abs().mean().item() / g.item() - 1.0) for x, g in zip(down, G["down_absmean"]))
     print(f"[sd15 54x96 + Plus map encoder vs REAL reference] eps per-view max rel {e:.4f}, mid residual {em:.4f}, down |x| ratio dev {dm:.4f}")
     parity_log("sd15_forward_hires_vs_reference", eps_worst_view_rel_l2=e, mid_rel_l2=em, down_absmean_dev=dm)
-    assert e < 2e-2 and em < 2e-2 and dm < 2e-2
+    check("sd15 hires forward vs REAL reference: eps per view", e, 2e-2)                       # measured 1.0 %
+    check("sd15 hires forward vs REAL reference: mid residual", em, 2.4e-2)                    # measured 1.2 %
+    check("sd15 hires forward vs REAL reference: down |x| ratio", dm, 1e-2)
 
 
 @pytest.mark.parametrize("which", ["272x736", "424x800"])
@@ -142,4 +144,5 @@ def test_reference_resolutions_tiny(dev, which):
     em = rel_l2(mid, G["mid"])
     print(f"[{which} vs REAL reference, tiny width] eps per-view max rel {e:.4f}, mid {em:.4f}")
     parity_log(f"reference_resolution_{which}_tiny", eps_worst_view_rel_l2=e, mid_rel_l2=em)
-    assert e < 4e-2 and em < 3e-2
+    check(f"{which} tiny vs REAL reference: eps per view", e, 3.6e-2)                           # measured 1.8 %
+    check(f"{which} tiny vs REAL reference: mid residual", em, 3e-2)
