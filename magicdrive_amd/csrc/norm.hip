@@ -394,10 +394,12 @@ extern "C" int mdx_groupnorm_bf16(const MdxGroupNormDesc* d, void* stream) {
     p.eps = (float)d->eps; p.silu = (int)d->silu;
     const int cpg = p.C / p.G;
     hipStream_t st = (hipStream_t)stream;
-    // big maps: two-stage streaming path (needs 16-byte rows, G <= 240 = the smallest workgroup, a partials workspace)
+    // big maps: two-stage streaming path (needs 16-byte rows, a partials workspace, and one thread per group: both kernels index
+    // pivots / partials / mean-rstd with `tid < G`, so G must not exceed the workgroup — rows * C8 threads, e.g. 160 at C = 1280)
     const int two_stage = (int)opt(OPT_GN_TWO_STAGE);
     const long elems = (long)p.HW * p.C;
-    if (two_stage && d->ws && elems >= 32768 && p.C % 8 == 0 && p.C <= GN2_MAXC && p.G <= 240 && p.ldx % 8 == 0 && p.ldy % 8 == 0 &&
+    const int nt_ws = (p.C % 8 == 0) ? ((p.C / 8) > GN2_NT ? GN2_NT : gn2_rows(p.C / 8) * (p.C / 8)) : 0;
+    if (two_stage && d->ws && elems >= 32768 && p.C % 8 == 0 && p.C <= GN2_MAXC && p.G <= nt_ws && p.ldx % 8 == 0 && p.ldy % 8 == 0 &&
         ((uintptr_t)p.X & 15) == 0 && ((uintptr_t)p.Y & 15) == 0) {
         GN2Params q;
         q.X = p.X; q.Y = p.Y; q.gamma = p.gamma; q.beta = p.beta; q.part = (float*)d->ws;

@@ -336,7 +336,11 @@ class SamplerPlan:
         self.step = O.build_program(self.step_ops)
 
     def release(self):
-        """Drop the captured graph and every device buffer this plan owns (called on LRU eviction)."""
+        """Drop the captured graph and every device buffer this plan owns (called on LRU eviction).  The plan's last replay may still
+        be in flight (an output_type='latent' caller that has not synchronised): destroying a hipGraphExec / freeing its buffers under
+        a running graph is not safe, so the device is drained first (evictions are rare: once per new batch geometry)."""
+        if self.device is not None and torch.device(self.device).type == "cuda":
+            torch.cuda.synchronize(self.device)
         for prog in (self.prologue, self.step):
             if prog is not None:
                 prog.destroy()

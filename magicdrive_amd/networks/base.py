@@ -70,8 +70,11 @@ def arch_config_from_json(js: Dict, base: Optional[Dict] = None) -> Dict:
         # ContinuousBBoxWithTextEmbedding's class default is minmax_normalize=True (bbox_embedder.py:42); the shipped config sets
         # false (configs/model/SDv1.5mv_rawbox.yaml:56).  A config that omits the key means the class default.
         cn["bbox"]["minmax_normalize"] = bool(bp.get("minmax_normalize", True))
-        if bp.get("mode", "all-xyz") not in ("all-xyz", "cxyz"):
-            raise NotImplementedError(f"bbox_embedder mode={bp['mode']!r} (bbox_embedder.py:14-25 builds cxyz / all-xyz only)")
+        # the class default is mode='cxyz' (4 points, bbox_embedder.py:41); the shipped config sets all-xyz (8 corners,
+        # configs/model/SDv1.5mv_rawbox.yaml:54), which is what the plan, the conditioning buffers and the input marshalling build
+        mode = bp.get("mode", "cxyz")
+        if mode != "all-xyz":
+            raise NotImplementedError(f"bbox_embedder mode={mode!r}: only 'all-xyz' (8 corners) is built; 'cxyz' checkpoints would fail later on a shape mismatch")
     # classifier-free-guidance map substitution (unet_addon_rawbox.py:188-202, 674-677): an `uncond_map` buffer exists in the
     # checkpoint only when use_uncond_map is set AND drop_cond_ratio > 0
     um, dr = js.get("use_uncond_map"), js.get("drop_cond_ratio", 0.0) or 0.0
@@ -79,6 +82,7 @@ def arch_config_from_json(js: Dict, base: Optional[Dict] = None) -> Dict:
         if um not in ("negative1", "random", "learnable"):
             raise TypeError(f"Unknown map type: {um}.")                 # the reference's error (:200)
         cn["use_uncond_map"] = um if dr > 0 else None
+        cn["drop_cond_ratio"] = float(dr)                             # kept so that save_pretrained writes the checkpoint's own value back
     for k in ("guess_mode",):
         if js.get(k):
             raise NotImplementedError(f"config option {k}={js[k]!r} is outside the built hot path")

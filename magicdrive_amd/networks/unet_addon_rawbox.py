@@ -43,7 +43,7 @@ class BEVControlNetModel(MdxModel):
                                            embedder_num_freq=cn["bbox"]["embedder_num_freq"], proj_dims=list(cn["bbox"]["proj_dims"]),
                                            minmax_normalize=bool(cn["bbox"].get("minmax_normalize", False)), mode="all-xyz"))
         if cn.get("use_uncond_map"):
-            js.update(use_uncond_map=cn["use_uncond_map"], drop_cond_ratio=0.25)
+            js.update(use_uncond_map=cn["use_uncond_map"], drop_cond_ratio=float(cn.get("drop_cond_ratio") or 0.25))
         if cn.get("map_embedder_cls"):
             js.update(map_embedder_cls=cn["map_embedder_cls"], map_embedder_param={k: list(v) for k, v in cn["map_embedder_param"].items()})
 

@@ -213,6 +213,10 @@ class StableDiffusionBEVControlNetPipeline:
         this body; not part of the reference signature."""
         if guess_mode:
             raise NotImplementedError("guess_mode is outside the built hot path")
+        if cross_attention_kwargs:
+            # the reference forwards these to the UNet's attention processors (:420); the fused attention has no such hooks — refuse,
+            # like attention_mask, instead of silently ignoring them
+            raise NotImplementedError(f"cross_attention_kwargs={cross_attention_kwargs!r}: the fused attention kernels take no processor kwargs")
         if eta != 0.0:
             raise NotImplementedError("the fused samplers are deterministic (DDIM eta = 0, UniPC)")
         if isinstance(self.scheduler, DDIMScheduler):

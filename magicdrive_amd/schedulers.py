@@ -126,15 +126,20 @@ class DDIMScheduler:
         if coef is None:
             coef = self._table_dev[dev] = tab.to(dev)
         if isinstance(timestep, torch.Tensor) and timestep.is_cuda:
-            idx_t = (self.timesteps.to(dev) == timestep.reshape(-1)[0].to(torch.int64)).nonzero()      # stays on the device
-            if idx_t.numel() == 0:      # (forces a sync only on the error path)
-                raise ValueError(f"timestep {int(timestep)} is not in this scheduler's timestep list")
-            step = idx_t.reshape(-1)[:1].to(torch.int32)
+            # no host round trip: the row index is computed on the device (argmax of the match mask; a timestep that is not in the list
+            # cannot be detected without a sync and selects row 0 — host timesteps below are validated)
+            ts_dev = self._table_dev.get(("timesteps", dev))
+            if ts_dev is None:
+                ts_dev = self._table_dev[("timesteps", dev)] = self.timesteps.to(dev, torch.int64)
+            step = (ts_dev == timestep.reshape(-1)[0].to(torch.int64)).to(torch.int32).argmax().reshape(1).to(torch.int32)
         else:
             hits = (self.timesteps == int(timestep)).nonzero()
             if hits.numel() == 0:
                 raise ValueError(f"timestep {int(timestep)} is not in this scheduler's timestep list")
-            step = torch.tensor([int(hits[0])], dtype=torch.int32, device=dev)
+            idx_dev = self._table_dev.get(("index", dev))       # all row indices, uploaded once: slicing it costs no host-to-device copy
+            if idx_dev is None:
+                idx_dev = self._table_dev[("index", dev)] = torch.arange(len(self.timesteps), dtype=torch.int32, device=dev)
+            step = idx_dev[int(hits[0]):int(hits[0]) + 1]
         x = sample.detach().to(torch.float32).contiguous().clone()
         eps = model_output.detach().to(torch.float32).contiguous()
         O.run_ops([O.DdimStep(x.view(-1), eps.view(-1), coef, step.clone())])

@@ -148,6 +148,9 @@ def test_pipeline_api_errors_without_gpu():
         pipe(None, sc["bev_map"], sc["camera_param"], 224, 400, prompt_embeds=sc["prompt_embeds"], negative_prompt_embeds=sc["negative_prompt_embeds"])
     with pytest.raises(AssertionError):
         StableDiffusionBEVControlNetPipeline(safety_checker=object())
+    with pytest.raises(NotImplementedError):   # the reference forwards these to attention processors (:420): refused, not dropped
+        pipe(None, sc["bev_map"], sc["camera_param"], 224, 400, prompt_embeds=sc["prompt_embeds"], negative_prompt_embeds=sc["negative_prompt_embeds"],
+             cross_attention_kwargs={"scale": 0.5})
 
     class GenScheduler(schedulers.DDIMScheduler):
         def step(self, model_output, timestep, sample, eta=0.0, generator=None):
@@ -306,6 +309,22 @@ def test_config_keys_that_change_samples_are_honoured_or_refused(tmp_path):
     cu.save_pretrained(str(tmp_path / "cn_um"))
     cu2 = BEVControlNetModel.from_pretrained(str(tmp_path / "cn_um"))
     assert torch.equal(cu2._uncond_map, cu._uncond_map)
+    js_dr = json.load(open(tmp_path / "cn_um" / "config.json"))
+    assert js_dr["drop_cond_ratio"] == 0.25
+    js_dr["drop_cond_ratio"] = 0.4                                   # the checkpoint's own ratio survives a load / save round trip
+    json.dump(js_dr, open(tmp_path / "cn_um" / "config.json", "w"))
+    BEVControlNetModel.from_pretrained(str(tmp_path / "cn_um")).save_pretrained(str(tmp_path / "cn_um2"))
+    assert json.load(open(tmp_path / "cn_um2" / "config.json"))["drop_cond_ratio"] == 0.4
+    # bbox_embedder mode: only all-xyz (8 corners) is built; the class default when the key is absent is cxyz (bbox_embedder.py:41)
+    for bad_mode in ("cxyz", None):
+        jsm = json.loads(json.dumps(js))
+        if bad_mode is None:
+            del jsm["bbox_embedder_param"]["mode"]
+        else:
+            jsm["bbox_embedder_param"]["mode"] = bad_mode
+        json.dump(jsm, open(p, "w"))
+        with pytest.raises(NotImplementedError):
+            BEVControlNetModel.from_pretrained(str(tmp_path / "cn"))
     js4 = json.loads(json.dumps(js)); js4.update(use_uncond_map="bogus", drop_cond_ratio=0.25)
     json.dump(js4, open(p, "w"))
     with pytest.raises(TypeError):

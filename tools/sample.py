@@ -109,6 +109,7 @@ def main(argv=None):
     ap.add_argument("--batch-size", type=int, default=1)
     ap.add_argument("--prompt-embeds", action="store_true", help="no text encoder available: sample with zero prompt embeddings")
     ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--reseed-per-run", action="store_true", help="deviation from the reference: an independent seed per (batch, validation run)")
     ap.add_argument("overrides", nargs="*")
     a = ap.parse_args(argv)
     from magicdrive_amd.dataset import FolderSet
@@ -117,7 +118,6 @@ def main(argv=None):
     data = FolderSet(a.data)
     os.makedirs(a.out, exist_ok=True)
     total = 0
-    glob_gen = torch.Generator().manual_seed(run["seed"]) if run["seed"] is not None else None
     for kw in iter_pipe_kwargs(data, run, a.batch_size):
         bs = kw["image"].shape[0]
         if pipe.text_encoder is None:
@@ -125,13 +125,19 @@ def main(argv=None):
                 raise SystemExit(f"{a.sd15} has no text_encoder/: pass --prompt-embeds to sample with zero embeddings")
             D = pipe.unet.cfg["cross_attention_dim"]
             kw.update(prompt=None, prompt_embeds=torch.zeros(bs, 77, D), negative_prompt_embeds=torch.zeros(bs, 77, D))
+        # Seeding as the reference entry point does it (tools/test.py passes no global_generator, so run_one_batch_pipe,
+        # magicdrive/misc/test_utils.py:221-237, builds torch.manual_seed(cfg.seed) ONCE per batch, before the validation_times loop: its
+        # state carries across the iterations; with fix_seed_within_batch every scene of the batch gets that same generator object) —
+        # the same seed reproduces the reference's initial latents.  --reseed-per-run (a deviation) draws a fresh seed per (batch, run).
+        if run["seed"] is None:
+            base_gen = None
+        else:
+            base_gen = torch.Generator().manual_seed(run["seed"])
         for ti in range(run["validation_times"]):
-            if glob_gen is None:
-                gen = None
-            elif run["fix_seed_within_batch"]:               # one generator per scene (misc/test_utils.py:224-237)
-                gen = [torch.Generator().manual_seed(int(torch.randint(0x7ffffffffffffff0, [1], generator=glob_gen))) for _ in range(bs)]
-            else:
-                gen = torch.Generator().manual_seed(int(torch.randint(0x7ffffffffffffff0, [1], generator=glob_gen)))
+            g = base_gen
+            if a.reseed_per_run and base_gen is not None:
+                g = torch.Generator().manual_seed(int(torch.randint(0x7ffffffffffffff0, [1], generator=base_gen)))
+            gen = None if g is None else ([g] * bs if run["fix_seed_within_batch"] else g)
             images = pipe(generator=gen, **kw).images                      # List[List[PIL]]: scene x view
             for bi, views in enumerate(images):
                 for vi, im in enumerate(views):
