@@ -41,10 +41,14 @@ def build_pipeline(cfg, device, scheduler="ddim"):
 
 
 def pmc_traffic(kernel_name):
-    """HBM-side bytes of ONE launch of `kernel_name` from the committed rocprofv3 --pmc passes (profiles/r02_pmc_summary.json:
-    FETCH_SIZE x 2 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, separate passes).  Counters cannot be collected
-    inside a timed run; the summary records the shape it was measured on next to the algorithmic bytes of that launch."""
-    p = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+    """Counter-derived numbers of ONE launch of `kernel_name` from the committed rocprofv3 --pmc passes (profiles/r03_pmc_summary.json,
+    collected at the bench batch of 768 views by tools/pmc_collect.sh: HBM-side bytes = FETCH_SIZE x 2 per the gfx950 correction of
+    MI355X_MICROARCH.md + WRITE_SIZE, hbm_gbps = those bytes / the profiled duration, mfma_util = SQ_VALU_MFMA_BUSY_CYCLES /
+    (GRBM_GUI_ACTIVE x 1024 SIMDs); separate passes).  Counters cannot be collected inside a timed run; the summary records the shape
+    it was measured on next to the algorithmic bytes of that launch."""
+    p = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+    if not os.path.exists(p):
+        p = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
     if not os.path.exists(p):
         return None
     try:
@@ -346,9 +350,15 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                                "traffic": None, "launches_per_step": d["launches"], "avg_launch_us": 1e3 * d["ms"] / d["launches"]}
         top = sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:10]
-        out["roofline"]["per_kernel"] = {k: {"ms_per_step": round(v["ms"], 3), "launches": v["launches"], "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 1),
-                                             "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["mfma"] and v["flops"] else None}
-                                         for k, v in top}
+        def pk(k, v):
+            row = {"ms_per_step": round(v["ms"], 3), "launches": v["launches"], "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 1),
+                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["mfma"] and v["flops"] else None,
+                   "alg_gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
+            c = pmc_traffic(k)                     # counters of one representative launch of this kernel (committed PMC passes)
+            if c:
+                row.update(mfma_util=c.get("mfma_util"), hbm_gbps=c.get("hbm_gbps"), l2_hit_rate=c.get("l2_hit_rate"), pmc_case=c.get("case"))
+            return row
+        out["roofline"]["per_kernel"] = {k: pk(k, v) for k, v in top}
         out["roofline"]["per_family"] = {k: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"],
                                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None}
                                          for k, v in fam.items()}

@@ -506,12 +506,17 @@ bool attn2_supported(const Attn2Params& p) {
 
 int launch_attn2(const Attn2Params& p, hipStream_t st) {
     // 64 queries per wave (see attn2_kernel) when there are enough queries per head; MDX_ATTN2_QT=1 forces 32
-    const int qt = (int)opt(OPT_ATTN2_QT);
+    const int qt_opt = (int)opt(OPT_ATTN2_QT);          // 0 (default): 64-query waves except where the 32-query FOLD form wins; 1 / 2: force
+    const int qt = qt_opt == 0 ? 2 : qt_opt;
+    const bool qt_forced64 = qt_opt == 2;
     const bool two = qt == 2 && p.Tq >= 512 && p.d == 40;
     // pre-scaled Q (scale * log2 e folded into to_q at pack time): scores are base-2 exponents as they come out of the MFMA
     const bool fold = p.q_prescaled && opt(OPT_ATTN2_FOLD) != 0;
     if (p.d == 40) {
-        if (fold) return two ? launch_attn2_d<5, 2, true>(p, st) : launch_attn2_d<5, 1, true>(p, st);
+        // FOLD frees the registers / VALU slots of the scale-and-subtract: with it the 32-query form (<= 142 VGPRs: three waves per SIMD)
+        // is the faster one for one kv source (768 views, T = 1400: self 3157 vs 3332 us, text context 640 vs 795 us; the two-source
+        // cross-view form is equal, 5888 vs 5882 us: profiles/r03_attn_qt_fold_ab.log); ATTN2_QT = 2 keeps 64-query waves everywhere.
+        if (fold) return (two && (qt_forced64 || (p.nsrc == 2 && !p.joint))) ? launch_attn2_d<5, 2, true>(p, st) : launch_attn2_d<5, 1, true>(p, st);
         return two ? launch_attn2_d<5, 2, false>(p, st) : launch_attn2_d<5, 1, false>(p, st);
     }
     return launch_attn2_d<10, 1, false>(p, st);

@@ -17,7 +17,7 @@ namespace mdx {
     X(ATTN2, 1, "attention2.hip for head dim 40") \
     X(ATTN2_D80, 0, "attention2.hip also for head dim 80") \
     X(ATTN2_FOLD, 1, "attention2.hip: subtract the running maximum inside the QK MFMA when Q is pre-scaled (head dim 40)") \
-    X(ATTN2_QT, 2, "32-query tiles per wave in attention2.hip (2 or 1)") \
+    X(ATTN2_QT, 0, "32-query tiles per wave in attention2.hip: 0 = automatic (2; 1 for one-source FOLD launches), 1 / 2 = force") \
     X(GEMM_SWZ, 1, "XCD-aware tile order of the generic / conv3x3 kernels") \
     X(C3_DBG, 0, "conv3x3 ablation bits (wrong results)") \
     X(GEMM_PIPE, 1, "software-pipelined fragment reads in the generic 128x128x64 tile") \

@@ -90,9 +90,17 @@ XL_HD int frag_off(int row0, int lane, int kk) {
 // gm consecutive M-tiles x gn consecutive N-tiles.  An XCD walks the N-groups of one M-group back to back (its A panels stay in that
 // L2), then takes its next M-group (M-group g belongs to XCD g % 8).  Blocks whose tile falls outside the ragged edge exit.
 XL_HD void raster_shape(int mt, int nt, int* gm, int* gn) {
-    int n = nt <= 5 ? nt : 4;                                  // all N-tiles of a narrow problem; groups of 4 otherwise
+    // gm x gn ~ 32 (the workgroups an XCD runs side by side).  Per round of tiles that XCD's L2 takes in gm A-panels + gn W-panels, so
+    // the squarest shape that divides nt well wins — subject to >= 64 M-groups (8 per XCD: groups are dealt out whole, and with few of
+    // them the XCD that draws one more runs an extra round).  Narrow problems (nt <= 5) take all their N-tiles in one group.
+    int n = nt <= 5 ? nt : 4;
     int m = 32 / n;
-    if (m > mt / 16) m = mt / 16;                              // at least two M-groups per XCD: short problems must still spread over all 8
+    if (nt > 5) {
+        // wide problems: trade M-tiles for N-tiles until there are enough M-groups (N = 10240 at the 7x13 level: 273 M-tiles -> 4 x 8)
+        while (m > 1 && (mt + m - 1) / m < 64) { m >>= 1; n <<= 1; }
+        if (n > nt) n = nt;
+    }
+    if (m > mt / 16) m = mt / 16;                              // short problems: at least two M-groups per XCD
     if (m < 1) m = 1;
     *gm = m; *gn = n;
 }

@@ -599,7 +599,7 @@ def test_attention_joint_sources(dev, b, heads, T, d, nsrc, expect, pre):
     qref = q
     if pre:                                  # MdxAttnDesc.q_prescaled (every kernel takes it; head dim 40 folds the maximum into the MFMA)
         q = (q.float() * qpre).to(BF); qref = q.float() / qpre
-        if d == 40: expect = expect.replace(">", ",fold>")
+        if d == 40: expect = expect.replace("q64>", "q32,fold>")      # joint one-softmax launches take the 32-query FOLD form
     O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=T, scale=d ** -0.5, kvmap=kvmap, nsrc=nsrc, joint=True, q_prescaled=pre)])
     kern = (L.lib().mdx_last_kernel() or b"").decode()
     torch.cuda.synchronize()
@@ -631,8 +631,9 @@ def attn2_route(d, Tq, xview=False, pre=False):
     mode = "xview" if xview else "self"
     if L.get_option("ATTN2") == 0 or (d == 80 and L.get_option("ATTN2_D80") == 0):
         return "attn_kernel<"                                       # attention.hip (prefix)
-    q = 64 if (d == 40 and Tq >= 512 and L.get_option("ATTN2_QT") == 2) else 32
     fold = ",fold" if (pre and d == 40 and L.get_option("ATTN2_FOLD")) else ""
+    qt = L.get_option("ATTN2_QT")                  # 0: automatic = 64-query waves, except one-source FOLD launches (32: three waves per SIMD)
+    q = 64 if (d == 40 and Tq >= 512 and qt != 1 and (qt == 2 or not fold or xview)) else 32
     return f"attn2_kernel<{d},{mode},q{q}{fold}>"
 
 

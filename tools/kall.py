@@ -15,7 +15,7 @@ from magicdrive_amd import _lib as L, ops as O, packing as PK  # noqa: E402
 
 BF = torch.bfloat16
 dev = torch.device("cuda")
-B = int(os.environ.get("KONE_VIEWS", "96"))
+B = int(os.environ.get("KONE_VIEWS", "768"))       # the bench batch: 128 scenes x 6 views
 REPS = int(os.environ.get("KONE_REPS", "3"))
 r = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(BF)
 ws = torch.empty(64 * 1024 * 1024 // 4, dtype=torch.float32, device=dev)
@@ -39,11 +39,12 @@ def gemm(name, M, N, K, epi=0, res=False):
 def attn(name, T, C, xview):
     d = C // 8
     qk = r(B, T, 2 * C); vt = torch.zeros(B, C, PK.round_up(T, 8), dtype=BF, device=dev); vt[:, :, :T] = r(B, C, T)
+    qk[:, :, :C] = (qk[:, :, :C].float() * (d ** -0.5 * 1.4426950408889634)).to(BF)      # pre-scaled Q, as the engine packs to_q
     o = torch.empty(B, T, C, dtype=BF, device=dev)
     kw = {}
     if xview:
         kw = dict(kvmap=torch.tensor([(i // 6) * 6 + ((i % 6 + s) % 6) for i in range(B) for s in (5, 1)], dtype=torch.int32, device=dev), nsrc=2)
-    cases.append((name, O.Attn(qk[:, :, :C], qk[:, :, C:], vt, o, heads=8, Tk=T, scale=d ** -0.5, **kw), (8.0 if xview else 4.0) * B * T * T * C,
+    cases.append((name, O.Attn(qk[:, :, :C], qk[:, :, C:], vt, o, heads=8, Tk=T, scale=d ** -0.5, q_prescaled=True, **kw), (8.0 if xview else 4.0) * B * T * T * C,
                   dict(read=B * T * C * 2 * 3, write=B * T * C * 2)))
 
 
@@ -54,11 +55,17 @@ gemm("geglu_L1", B * 350, 5120, 640, epi=1)
 gemm("ffout_L0", B * 1400, 320, 1280, res=True)
 gemm("geglu_L0", B * 1400, 2560, 320, epi=1)
 gemm("out_L0", B * 1400, 320, 320, res=True)
+gemm("cc_L1", B * 350, 640, 640, res=True)
+gemm("qk_L1", B * 350, 1280, 640)
+gemm("geglu_L2", B * 91, 10240, 1280, epi=1)
 attn("attn_self_L0", 1400, 320, False)
 attn("attn_xview_L0", 1400, 320, True)
 x = r(B, 1400, 320); y = torch.empty_like(x)
 cases.append(("gn_L0", O.GroupNorm(x, y, torch.ones(320, device=dev), torch.zeros(320, device=dev), 32, 1e-5, True, ws=ws), 0.0,
               dict(read=B * 1400 * 320 * 2 * 2, write=B * 1400 * 320 * 2)))
+xl_ = r(B * 1400, 320); yl_ = torch.empty_like(xl_)
+cases.append(("ln_L0", O.LayerNorm(xl_, yl_, torch.ones(320, device=dev), torch.zeros(320, device=dev)), 0.0,
+              dict(read=B * 1400 * 320 * 2, write=B * 1400 * 320 * 2)))
 st = torch.cuda.current_stream().cuda_stream
 info = {}
 for name, op, fl, by in cases:

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--views", type=int, default=24)
     ap.add_argument("--only", type=str, default="gemm,conv,attn,norm")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--prescaled", action="store_true", help="attention: Q pre-scaled by scale * log2(e) (q_prescaled, as the engine packs to_q)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     B = a.views
@@ -79,15 +80,20 @@ def main():
             T = h * w; d = C // 8
             qk = r(B, T, 2 * C); vt = torch.zeros(B, C, PK.round_up(T, 8), dtype=BF, device=dev); vt[:, :, :T] = r(B, C, T)
             o = torch.empty(B, T, C, dtype=BF, device=dev)
-            us = timeit(O.Attn(qk[:, :, :C], qk[:, :, C:], vt, o, heads=8, Tk=T, scale=d ** -0.5), a.reps)
+            pre = a.prescaled
+            if pre:
+                qk[:, :, :C] = (qk[:, :, :C].float() * (d ** -0.5 * 1.4426950408889634)).to(BF)
+            us = timeit(O.Attn(qk[:, :, :C], qk[:, :, C:], vt, o, heads=8, Tk=T, scale=d ** -0.5, q_prescaled=pre), a.reps)
             rec("attn", f"self T={T} d={d}", us, 4.0 * B * T * T * C / 1e9)
             kvmap = torch.tensor([(i // 6) * 6 + ((i % 6 + s) % 6) for i in range(B) for s in (5, 1)], dtype=torch.int32, device=dev)
-            us = timeit(O.Attn(qk[:, :, :C], qk[:, :, C:], vt, o, heads=8, Tk=T, scale=d ** -0.5, kvmap=kvmap, nsrc=2), a.reps)
+            us = timeit(O.Attn(qk[:, :, :C], qk[:, :, C:], vt, o, heads=8, Tk=T, scale=d ** -0.5, kvmap=kvmap, nsrc=2, q_prescaled=pre), a.reps)
             rec("attn", f"xview T={T} d={d}", us, 8.0 * B * T * T * C / 1e9)
             S = 78
             kc = r(B, S, C); vtc = torch.zeros(B, C, 80, dtype=BF, device=dev); vtc[:, :, :S] = r(B, C, S)
             q = r(B, T, C)
-            us = timeit(O.Attn(q, kc, vtc, o, heads=8, Tk=S, scale=d ** -0.5), a.reps)
+            if pre:
+                q = (q.float() * (d ** -0.5 * 1.4426950408889634)).to(BF)
+            us = timeit(O.Attn(q, kc, vtc, o, heads=8, Tk=S, scale=d ** -0.5, q_prescaled=pre), a.reps)
             rec("attn", f"ctx T={T} S={S} d={d}", us, 4.0 * B * T * S * C / 1e9)
     if "norm" in a.only:
         for (h, w, C) in [(28, 50, 320), (28, 50, 640), (14, 25, 640), (14, 25, 1920), (7, 13, 1280), (4, 7, 2560)]:

@@ -11,7 +11,7 @@ import os
 import sys
 
 d = sys.argv[1]
-out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_pmc_summary.json")
+out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_pmc_summary.json")
 cases = json.load(open(os.path.join(d, "cases.json")))
 reps = cases["reps"]
 by_kernel = collections.defaultdict(list)        # kernel name prefix -> [case]
@@ -22,6 +22,8 @@ for name, c in cases["cases"].items():
 def match(kname, case_kernel):
     """rocprofv3 prints the C++ template instance; kall.py records mdx_last_kernel()'s short tag."""
     base = case_kernel.split("<")[0]
+    if "+" in base:                                 # an op made of two launches (GroupNorm: statistics + apply): either kernel matches, values add up
+        return any(part in kname for part in base.split("+"))
     if base not in kname:
         return False
     tag = case_kernel[len(base):]
@@ -30,6 +32,9 @@ def match(kname, case_kernel):
         return f"<{bn}, {'true' if conv else 'false'}" in kname.replace("(int)", "").replace("Li", "") or f"{bn}, {'true' if conv else 'false'}" in kname
     if base == "attn_kernel":
         return ("true" in kname.split("attn_kernel")[1]) == ("xview" in tag)
+    if base == "attn2_kernel":                      # attn2_kernel<D8, TWO, QT, FOLD>: second argument = the two-neighbour (cross-view) form
+        args = kname.split("attn2_kernel<")[1].split(">")[0].replace(" ", "").split(",")
+        return (args[1] == "true") == ("xview" in tag) and (args[3] == "true") == ("fold" in tag)
     if base == "gemm_ws_kernel":
         return ("<true" in kname.replace(" ", "")) == ("geglu" in tag)
     return True
@@ -53,7 +58,8 @@ for f in sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), rec
                 for i, name in enumerate(names):
                     seg = vals[i * reps:(i + 1) * reps]
                     if seg:
-                        counters[name][cn] = seg
+                        prev = counters[name].get(cn)
+                        counters[name][cn] = [a + b for a, b in zip(prev, seg)] if (prev and len(prev) == len(seg) and "+" in case_kernel) else seg
 durations = collections.defaultdict(list)
 for f in sorted(glob.glob(os.path.join(d, "**", "stats_kernel_trace.csv"), recursive=True)):
     rows = list(csv.DictReader(open(f)))
@@ -65,7 +71,9 @@ for f in sorted(glob.glob(os.path.join(d, "**", "stats_kernel_trace.csv"), recur
         for case_kernel, names in by_kernel.items():
             if match(kname, case_kernel):
                 for i, name in enumerate(names):
-                    durations[name] = [(e - s) / 1e3 for s, e in rs[i * reps:(i + 1) * reps]]
+                    seg = [(e - s) / 1e3 for s, e in rs[i * reps:(i + 1) * reps]]
+                    prev = durations.get(name)
+                    durations[name] = [a + b for a, b in zip(prev, seg)] if (prev and len(prev) == len(seg) and "+" in case_kernel) else seg
 summary = {"note": "rocprofv3 --kernel-trace --pmc <group> (separate passes; tools/pmc_collect.sh over tools/kall.py), %d views, averages over %d launches; "
                    "fetch = FETCH_SIZE x 2 (gfx950 correction), sizes in bytes; *_frac counters are ratios of the SQ sums" % (cases["views"], reps),
            "cases": {}, "kernels": {}}
@@ -88,6 +96,16 @@ for name, c in cases["cases"].items():
         row["l2_hit_rate"] = round(cs["TCC_HIT_sum"] / (cs["TCC_HIT_sum"] + cs["TCC_MISS_sum"]), 4)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and cs.get("SQ_BUSY_CYCLES"):
         row["mfma_busy_over_sq_busy"] = round(cs["SQ_VALU_MFMA_BUSY_CYCLES"] / cs["SQ_BUSY_CYCLES"], 4)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and cs.get("GRBM_GUI_ACTIVE"):
+        # matrix-pipe utilisation from the counters: busy cycles summed over the 1024 SIMDs (256 CUs x 4) / (kernel cycles x 1024).
+        # rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (8 x the kernel's cycles: the ratio to the wall time is 15-19 "GHz"),
+        # so the kernel's cycles are GRBM_GUI_ACTIVE / 8 — the effective clock under load then reads 1.9-2.4 GHz as the guide says.
+        cycles = cs["GRBM_GUI_ACTIVE"] / 8.0
+        row["mfma_util"] = round(cs["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024.0), 4)
+        if durations.get(name):
+            row["effective_clock_ghz"] = round(cycles / (sum(durations[name]) / len(durations[name])) / 1e3, 3)
+    if "fetch_bytes" in row and "write_bytes" in row and durations.get(name):
+        row["hbm_gbps"] = round((row["fetch_bytes"] + row["write_bytes"]) / (sum(durations[name]) / len(durations[name])) / 1e3, 1)
     if "SQ_WAVE_CYCLES" in cs and cs["SQ_WAVE_CYCLES"]:
         for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
             if k in cs:
@@ -99,7 +117,8 @@ for name, c in cases["cases"].items():
         if k is None or row["gflop"] > k["gflop"]:
             summary["kernels"][c["kernel"]] = dict(case=name, views=cases["views"], gflop=row["gflop"], bytes=row["traffic_bytes"], fetch_bytes=row["fetch_bytes"],
                                                    write_bytes=row["write_bytes"], algorithmic_bytes=c["alg_read_bytes"] + c["alg_write_bytes"],
-                                                   l2_hit_rate=row.get("l2_hit_rate"), mfma_busy_over_sq_busy=row.get("mfma_busy_over_sq_busy"))
+                                                   l2_hit_rate=row.get("l2_hit_rate"), mfma_util=row.get("mfma_util"), hbm_gbps=row.get("hbm_gbps"),
+                                                   effective_clock_ghz=row.get("effective_clock_ghz"), avg_us_profiled=row.get("avg_us_profiled"))
 with open(out_path, "w") as f:
     json.dump(summary, f, indent=1)
 for name, row in summary["cases"].items():
