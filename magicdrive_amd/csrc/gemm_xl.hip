@@ -594,30 +594,34 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
     const int n0o = geglu ? n0 / 2 : n0, Nout = geglu ? p.N / 2 : p.N;
     const bf16_t* Rg = p.R ? (const bf16_t*)p.R : nullptr;
     bf16_t* Cg = (bf16_t*)p.C;
-    // The residual tile is fetched in ONE batch per half — issued before the accumulators are staged when the registers allow (256- and
-    // 160-wide tiles: the latency, an HBM round trip per tile, then overlaps the staging passes and the two barriers): in batches of
-    // four behind the staging it cost four dependent round trips per tile.  Unconditional loads from clamped addresses (a guarded load becomes its own branch + wait).
-    constexpr int RIT = NH == 1 ? (HROWS * (BN / 8) + NTH - 1) / NTH : 1;      // 16-byte chunks of the tile per thread
-    const bool rpref = NH == 1 && Rg != nullptr && p.wide && !geglu;   // not the 320-wide tile: no registers to spare (it keeps batches of four)
-    constexpr int RPASS = 1;
-    constexpr int RPB = (RIT + RPASS - 1) / RPASS;
-    uint4 rpre[RPB];
-    auto fetch_residual = [&](int hh, int pass) {
-        constexpr int cpr = BN >> 3;
+    // The residual of a (half) tile is fetched in ONE batch of unconditional loads from clamped addresses (a guarded load becomes its
+    // own branch + wait; in batches of four behind the staging it cost four to six dependent HBM round trips per tile).  256- / 160-wide:
+    // before the accumulators are staged (the round trip overlaps the staging and the two barriers).  320-wide (160 accumulators live,
+    // two 128-row halves): right behind each half's staging barrier.
+    // Row walk of the residual / store phase: thread t owns the 16-byte column chunk t % CPR of rows t / CPR + u * RPP — one base address
+    // and a wave-uniform row stride per pass (the linear index / CPR of round 2 was an integer division and a 64-bit address per chunk:
+    // at CPR = 40 that alone pushed the 320-wide kernel into scratch).  Threads >= RPP * CPR idle (32 of 512 at 320 columns).
+    constexpr int CPR = BN >> 3;
+    constexpr int RPP = NTH / CPR;
+    constexpr int RIT = (HROWS + RPP - 1) / RPP;                  // passes: 16 (256-wide), 11 (320-wide half, 160-wide)
+    const int rrow0 = tid / CPR, rc8 = (tid - rrow0 * CPR) * 8;
+    const bool ractive = tid < RPP * CPR && n0 + rc8 < p.N;
+    const bool rpref = Rg != nullptr && p.wide && !geglu;
+    uint4 rpre[RIT];
+    auto fetch_residual = [&](int hh) {
         const int mh_ = m0 + hh * HROWS;
+        const int c8 = (n0 + rc8 + 8 > p.N) ? (p.N - 8 - n0 < 0 ? 0 : p.N - 8 - n0) : rc8;
+        const bf16_t* rb = Rg + n0 + c8;
+        const int rmax = min(HROWS - 1, p.M - 1 - mh_);
 #pragma unroll
-        for (int u = 0; u < RPB; ++u) {
-            const int idx = (pass * RPB + u) * NTH + tid;
-            int row = idx / cpr;
-            int c8 = (idx - row * cpr) * 8;
-            row = min(min(row, HROWS - 1), p.M - 1 - mh_); if (row < 0) row = 0;
-            if (n0 + c8 + 8 > p.N) c8 = p.N - 8 - n0 < 0 ? 0 : p.N - 8 - n0;
-            rpre[u] = *(const uint4*)(Rg + (long)(mh_ + row) * p.ldr + n0 + c8);
+        for (int u = 0; u < RIT; ++u) {
+            int row = min(rrow0 + u * RPP, rmax); if (row < 0) row = 0;
+            rpre[u] = *(const uint4*)(rb + (long)(mh_ + row) * p.ldr);
         }
     };
 #pragma unroll 1
     for (int hh = 0; hh < NH; ++hh) {
-        if (rpref && NH == 1) fetch_residual(hh, 0);
+        if (rpref && NH == 1) fetch_residual(hh);
         // raw barrier + LDS wait only: __syncthreads() also drains the VM counter, i.e. it would sit out the residual fetch just issued
         xl_wait_lgkm0();
         __builtin_amdgcn_s_barrier();                            // ring dead / previous half stored (its LDS reads returned); addend visible
@@ -729,19 +733,16 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
                 }
             }
         } else if (rpref) {
-            constexpr int cpr = BN >> 3;
-#pragma unroll 1
-            for (int pass = 0; pass < RPASS; ++pass) {
-                if (NH == 2) fetch_residual(hh, pass);            // 320-wide: 160 accumulators are live before the staging, no room earlier
+            if (NH == 2) fetch_residual(hh);                      // 320-wide: one batch right behind the staging barrier
+            const bf16_t* cs_ = Cs + rrow0 * CSTR + rc8;
+            bf16_t* cg_ = Cg + (long)(mh + rrow0) * p.ldc + n0 + rc8;
 #pragma unroll
-                for (int u = 0; u < RPB; ++u) {
-                    const int idx = (pass * RPB + u) * NTH + tid;
-                    const int row = idx / cpr, c8 = (idx - row * cpr) * 8;
-                    if (idx >= HROWS * cpr || mh + row >= p.M || n0 + c8 >= p.N) continue;
-                    uint4 v = *(const uint4*)(Cs + row * CSTR + c8);
-                    v.x = add2bf(v.x, rpre[u].x); v.y = add2bf(v.y, rpre[u].y); v.z = add2bf(v.z, rpre[u].z); v.w = add2bf(v.w, rpre[u].w);
-                    *(uint4*)(Cg + (long)(mh + row) * p.ldc + n0 + c8) = v;
-                }
+            for (int u = 0; u < RIT; ++u) {
+                const int row = rrow0 + u * RPP;
+                if (!ractive || row >= HROWS || mh + row >= p.M) continue;
+                uint4 v = *(const uint4*)(cs_ + u * RPP * CSTR);
+                v.x = add2bf(v.x, rpre[u].x); v.y = add2bf(v.y, rpre[u].y); v.z = add2bf(v.z, rpre[u].z); v.w = add2bf(v.w, rpre[u].w);
+                *(uint4*)(cg_ + (long)u * RPP * p.ldc) = v;
             }
         } else if (BN != 320 && p.wide && !Rg) {
             // no residual: batches of eight unconditional LDS reads (clamped index), then the guarded stores
