@@ -29,13 +29,13 @@ if ROOT not in sys.path:
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 
 
-def build_pipeline(cfg, device, scheduler="ddim"):
+def build_pipeline(cfg, device, scheduler="ddim", torch_dtype=torch.bfloat16):
     from magicdrive_amd import schedulers
     from magicdrive_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiview
     from magicdrive_amd.networks.unet_addon_rawbox import BEVControlNetModel
     from magicdrive_amd.pipeline.pipeline_bev_controlnet import StableDiffusionBEVControlNetPipeline
-    unet = UNet2DConditionModelMultiview.from_config(cfg, seed=0)
-    cn = BEVControlNetModel.from_config(cfg, seed=1)
+    unet = UNet2DConditionModelMultiview.from_config(cfg, seed=0, torch_dtype=torch_dtype)
+    cn = BEVControlNetModel.from_config(cfg, seed=1, torch_dtype=torch_dtype)
     pipe = StableDiffusionBEVControlNetPipeline(unet=unet, controlnet=cn, scheduler=schedulers.DDIMScheduler() if scheduler == "ddim" else schedulers.UniPCMultistepScheduler())
     return pipe.to(device), unet, cn
 
@@ -66,7 +66,8 @@ def per_op_profile(plan, reps=3):
     """HIP-event timing of every launch of the step program on the stream it is launched on."""
     from magicdrive_amd import _lib as L, flops as FL
     st = torch.cuda.current_stream().cuda_stream
-    lowered = [op.lower() for op in plan.step_ops]
+    from magicdrive_amd import ops as O_
+    lowered = [O_.lower_with_dtype(op) for op in plan.step_ops]
     n = len(lowered)
     best = [float("inf")] * n
     kname = [""] * n
@@ -75,8 +76,8 @@ def per_op_profile(plan, reps=3):
         plan.step_ctr.zero_()
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
         evs[0].record()
-        for i, (code, desc) in enumerate(lowered):
-            L.call_op(code, desc, st)
+        for i, (code, desc, dt) in enumerate(lowered):
+            L.call_op(code, desc, st, dt)
             kname[i] = (last_kernel() or b"").decode()          # which kernel the library routed this op to
             evs[i + 1].record()
         torch.cuda.synchronize()
@@ -165,6 +166,9 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--scheduler", choices=["ddim", "unipc"], default="ddim",
                     help="ddim = the headline metric's sampler; unipc (with --ddim-steps 20) = what the reference's tools/test.py runs")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
+                    help="16-bit arithmetic type of the sampler (fp32 accumulate either way): bf16 = what BASELINE.json's configs[1] names; "
+                         "fp16 = what the reference samples in (magicdrive/misc/test_utils.py:95)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-profile", action="store_true")
@@ -205,7 +209,8 @@ def main():
     if world > 1:                                               # N ranks generate 1.3 G random weights each on the host: share the cores
         torch.set_num_threads(max(4, (os.cpu_count() or 8) // world))
     cfg = spec.SD15_CONFIG
-    pipe, unet, cn = build_pipeline(cfg, dev, args.scheduler)
+    tdt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    pipe, unet, cn = build_pipeline(cfg, dev, args.scheduler, tdt)
     pipe.use_graph = not args.no_graph
     b = args.scenes_per_gpu
     n_total = b * world
@@ -273,7 +278,7 @@ def main():
     if args.hires_scenes > 0:
         hh, hw_ = 432 // 8, 768 // 8
         hcfg = spec.with_plus_map_embedder(cfg, (hh, hw_))
-        hpipe, _, _ = build_pipeline(hcfg, dev, args.scheduler)
+        hpipe, _, _ = build_pipeline(hcfg, dev, args.scheduler, tdt)
         hpipe.use_graph = pipe.use_graph
         nh = args.hires_scenes
         hsc = [synthetic.make_scene_batch(1, seed=4321 + i, max_len=32, latent_hw=(hh, hw_)) for i in DD.shard_scenes(nh * world, rank, world)]
@@ -318,9 +323,9 @@ def main():
     out = {
         "metric": "6-view scenes/sec at 224x400, 50-step DDIM" if (args.scheduler, args.ddim_steps) == ("ddim", 50) else f"6-view scenes/sec at 224x400, {args.ddim_steps}-step {args.scheduler}", "value": scenes_per_s, "unit": "scenes/s",
         "n_gpus": n_devices, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": ("configs[2]: 6-view 224x400, camera+32 boxes+BEV map, CFG 2.0" if args.full_cond else
-                                f"configs[1]: 6-view 224x400, text-only conditioning (camera_param=None -> CFG off), {args.ddim_steps}-step {args.scheduler.upper() if args.scheduler == 'ddim' else 'UniPC'}, bf16"),
+                                f"configs[1]: 6-view 224x400, text-only conditioning (camera_param=None -> CFG off), {args.ddim_steps}-step {args.scheduler.upper() if args.scheduler == 'ddim' else 'UniPC'}, {args.dtype}"),
                    "scenes_per_gpu": b, "ddim_steps": args.ddim_steps, "scheduler": args.scheduler, "unet_params_M": round(unet.num_parameters() / 1e6, 1),
                    "controlnet_params_M": round(cn.num_parameters() / 1e6, 1), "parallelism": f"scene-sharded x{world}",
                    "hipgraph": pipe.use_graph, "output_type": "latent",

@@ -42,7 +42,7 @@ extern "C" {
 #define MDX_ELAUNCH (-2)     /* hip launch / runtime error */
 #define MDX_EUNSUPPORTED (-3)
 
-#define MDX_ABI_VERSION 5
+#define MDX_ABI_VERSION 6
 
 /* ---- epilogue flags shared by GEMM / conv ------------------------------- */
 #define MDX_EPI_NONE 0
@@ -309,12 +309,34 @@ int mdx_cfg_unipc_step(const MdxUniPCDesc* d, void* stream);
 #define MDX_OP_UNIPC 12
 #define MDX_OP_SOFTMAX 13
 
+/* 16-bit storage / MFMA operand type of an op's activations and weights.  The reference samples in fp16 (magicdrive/misc/test_utils.py:95
+ * `weight_dtype = torch.float16`); BASELINE.json's benchmark configuration names bf16.  Every op entry point exists in both builds:
+ * mdx_<op>_bf16 / mdx_<op> (bf16) and mdx_<op>_f16 (IEEE fp16) — same descriptors, fp32 accumulation, fp32 side inputs (bias, temb,
+ * norm affine, latents).  A program carries the choice per op. */
+#define MDX_DTYPE_BF16 0
+#define MDX_DTYPE_F16 1
+
 #define MDX_OP_BYTES 512
 typedef struct MdxOp {
     int64_t opcode;
-    int64_t reserved;
+    int64_t dtype;                           /* MDX_DTYPE_* */
     unsigned char desc[MDX_OP_BYTES - 16];   /* one of the Mdx*Desc above, zero padded */
 } MdxOp;
+
+/* the fp16 build of the op entry points above (identical descriptors and semantics; 16-bit tensors hold IEEE fp16) */
+int mdx_gemm_f16(const MdxGemmDesc* d, void* stream);
+int mdx_conv2d_f16(const MdxConvDesc* d, void* stream);
+int mdx_conv2d_direct_f16(const MdxConvDirectDesc* d, void* stream);
+int mdx_attention_f16(const MdxAttnDesc* d, void* stream);
+int mdx_groupnorm_f16(const MdxGroupNormDesc* d, void* stream);
+int mdx_layernorm_f16(const MdxLayerNormDesc* d, void* stream);
+int mdx_elementwise_f16(const MdxEwDesc* d, void* stream);
+int mdx_fourier_embed_f16(const MdxFourierDesc* d, void* stream);
+int mdx_gather_rows_f16(const MdxGatherDesc* d, void* stream);
+int mdx_timestep_embedding_f16(const MdxTimeEmbDesc* d, void* stream);
+int mdx_cfg_ddim_step_f16(const MdxDdimDesc* d, void* stream);
+int mdx_cfg_unipc_step_f16(const MdxUniPCDesc* d, void* stream);
+int mdx_softmax_rows_f16(const MdxSoftmaxDesc* d, void* stream);
 
 /* Run ops[0..n) in order on `stream`.  Stops at the first failing op (returns its code;
  * mdx_last_error() names the op index). */

@@ -13,7 +13,7 @@ from typing import Dict, List, Tuple
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDX_LIB_PATH") or os.path.join(_HERE, "libmdx.so")      # MDX_LIB_PATH: A/B a second build (tools only)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # opcodes (mdx.h)
 OP_GEMM, OP_CONV, OP_CONV_DIRECT, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM = 1, 2, 3, 4, 5, 6
@@ -58,20 +58,29 @@ DESC_OF_OP = {
     OP_GROUPNORM: MdxGroupNormDesc, OP_LAYERNORM: MdxLayerNormDesc, OP_EW: MdxEwDesc, OP_FOURIER: MdxFourierDesc,
     OP_GATHER: MdxGatherDesc, OP_TIMEEMB: MdxTimeEmbDesc, OP_DDIM: MdxDdimDesc, OP_UNIPC: MdxUniPCDesc, OP_SOFTMAX: MdxSoftmaxDesc,
 }
+DTYPE_BF16, DTYPE_F16 = 0, 1          # MdxOp.dtype: the 16-bit storage / MFMA operand type of an op (mdx.h)
 ENTRY_OF_OP = {
     OP_GEMM: "mdx_gemm_bf16", OP_CONV: "mdx_conv2d_bf16", OP_CONV_DIRECT: "mdx_conv2d_direct", OP_ATTN: "mdx_attention_bf16",
     OP_GROUPNORM: "mdx_groupnorm_bf16", OP_LAYERNORM: "mdx_layernorm_bf16", OP_EW: "mdx_elementwise",
     OP_FOURIER: "mdx_fourier_embed", OP_GATHER: "mdx_gather_rows", OP_TIMEEMB: "mdx_timestep_embedding", OP_DDIM: "mdx_cfg_ddim_step",
     OP_UNIPC: "mdx_cfg_unipc_step", OP_SOFTMAX: "mdx_softmax_rows",
 }
+def entry_name(opcode: int, dtype: int = DTYPE_BF16) -> str:
+    """C entry point of an op in the bf16 or the fp16 build (mdx_gemm_bf16 -> mdx_gemm_f16, mdx_elementwise -> mdx_elementwise_f16)."""
+    n = ENTRY_OF_OP[opcode]
+    if dtype == DTYPE_BF16:
+        return n
+    return (n[:-5] if n.endswith("_bf16") else n) + "_f16"
+
+
 # every symbol include/mdx.h declares
-EXPORTS = sorted(set(ENTRY_OF_OP.values()) | {
+EXPORTS = sorted(set(ENTRY_OF_OP.values()) | {entry_name(o, DTYPE_F16) for o in ENTRY_OF_OP} | {
     "mdx_program_run", "mdx_graph_create", "mdx_graph_launch", "mdx_graph_destroy",
     "mdx_abi_version", "mdx_last_error", "mdx_last_kernel", "mdx_device_info", "mdx_set_option", "mdx_get_option", "mdx_option_name"})
 
 
 class MdxOp(C.Structure):
-    _fields_ = [("opcode", I), ("reserved", I), ("desc", C.c_ubyte * (OP_BYTES - 16))]
+    _fields_ = [("opcode", I), ("dtype", I), ("desc", C.c_ubyte * (OP_BYTES - 16))]
 
 
 assert C.sizeof(MdxOp) == OP_BYTES
@@ -99,7 +108,7 @@ def lib() -> C.CDLL:
     for name in EXPORTS:
         if not hasattr(l, name):
             raise MdxError(f"libmdx.so does not export {name}")
-    for name in ENTRY_OF_OP.values():
+    for name in list(ENTRY_OF_OP.values()) + [entry_name(o, DTYPE_F16) for o in ENTRY_OF_OP]:
         fn = getattr(l, name)
         fn.restype = C.c_int
         fn.argtypes = [C.c_void_p, C.c_void_p]
@@ -134,20 +143,23 @@ def check(rc: int, what: str = "") -> None:
         raise MdxError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
 
 
-def call_op(opcode: int, desc: C.Structure, stream: int) -> None:
-    """Run a single op descriptor on `stream` (a raw hipStream_t value)."""
-    fn = getattr(lib(), ENTRY_OF_OP[opcode])
-    check(fn(C.byref(desc), C.c_void_p(stream)), ENTRY_OF_OP[opcode])
+def call_op(opcode: int, desc: C.Structure, stream: int, dtype: int = DTYPE_BF16) -> None:
+    """Run a single op descriptor on `stream` (a raw hipStream_t value) in the bf16 or the fp16 build of its kernel."""
+    name = entry_name(opcode, dtype)
+    fn = getattr(lib(), name)
+    check(fn(C.byref(desc), C.c_void_p(stream)), name)
 
 
 class Program:
-    """A flat array of MdxOp built from (opcode, descriptor) pairs; runnable eagerly or as a hipGraph."""
+    """A flat array of MdxOp built from (opcode, descriptor[, dtype]) tuples; runnable eagerly or as a hipGraph."""
 
-    def __init__(self, ops: List[Tuple[int, C.Structure]]):
+    def __init__(self, ops: List[Tuple]):
         self.n = len(ops)
         self.buf = (MdxOp * max(self.n, 1))()
-        for i, (code, desc) in enumerate(ops):
+        for i, t in enumerate(ops):
+            code, desc = t[0], t[1]
             self.buf[i].opcode = code
+            self.buf[i].dtype = t[2] if len(t) > 2 else DTYPE_BF16
             C.memmove(C.addressof(self.buf[i]) + 16, C.byref(desc), C.sizeof(desc))
         self._graph = C.c_void_p(None)
 

@@ -14,7 +14,7 @@
 #include <atomic>
 #include <cstdlib>
 
-namespace mdx {
+namespace mdx_rt {
 char* error_buffer() {
     static thread_local char buf[512] = {0};
     return buf;
@@ -28,15 +28,18 @@ int ensure_dyn_smem(const void* kernel, size_t bytes, const char* what) {
     static std::set<std::pair<const void*, int>> done;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return set_error(MDX_ELAUNCH, "hipGetDevice: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return mdx::set_error(MDX_ELAUNCH, "hipGetDevice: %s", hipGetErrorString(e));
     std::lock_guard<std::mutex> lk(mu);
     const auto key = std::make_pair(kernel, dev);
     if (done.count(key)) return MDX_OK;
     e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return set_error(MDX_ELAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+    if (e != hipSuccess) return mdx::set_error(MDX_ELAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
     done.insert(key);
     return MDX_OK;
 }
+}  // namespace mdx_rt
+
+namespace mdx {
 // ---- options (options.h) ----------------------------------------------------------------------------------------------
 namespace {
 struct OptRow { const char* key; int64_t dflt; const char* doc; };
@@ -66,8 +69,10 @@ int find_opt(const char* key) {
     return -1;
 }
 }  // namespace
-int64_t opt(int id) { return g_opt[id].load(std::memory_order_relaxed); }
 }  // namespace mdx
+namespace mdx_rt {
+int64_t opt(int id) { return mdx::g_opt[id].load(std::memory_order_relaxed); }
+}
 
 using namespace mdx;
 
@@ -87,6 +92,25 @@ extern "C" const char* mdx_option_name(int64_t index) { return (index >= 0 && in
 
 static int run_op(const MdxOp* op, hipStream_t st) {
     const void* d = op->desc;
+    if (op->dtype == MDX_DTYPE_F16) {
+        switch (op->opcode) {
+            case MDX_OP_GEMM: return mdx_gemm_f16((const MdxGemmDesc*)d, st);
+            case MDX_OP_CONV: return mdx_conv2d_f16((const MdxConvDesc*)d, st);
+            case MDX_OP_CONV_DIRECT: return mdx_conv2d_direct_f16((const MdxConvDirectDesc*)d, st);
+            case MDX_OP_ATTN: return mdx_attention_f16((const MdxAttnDesc*)d, st);
+            case MDX_OP_GROUPNORM: return mdx_groupnorm_f16((const MdxGroupNormDesc*)d, st);
+            case MDX_OP_LAYERNORM: return mdx_layernorm_f16((const MdxLayerNormDesc*)d, st);
+            case MDX_OP_EW: return mdx_elementwise_f16((const MdxEwDesc*)d, st);
+            case MDX_OP_FOURIER: return mdx_fourier_embed_f16((const MdxFourierDesc*)d, st);
+            case MDX_OP_GATHER: return mdx_gather_rows_f16((const MdxGatherDesc*)d, st);
+            case MDX_OP_TIMEEMB: return mdx_timestep_embedding_f16((const MdxTimeEmbDesc*)d, st);
+            case MDX_OP_DDIM: return mdx_cfg_ddim_step_f16((const MdxDdimDesc*)d, st);
+            case MDX_OP_UNIPC: return mdx_cfg_unipc_step_f16((const MdxUniPCDesc*)d, st);
+            case MDX_OP_SOFTMAX: return mdx_softmax_rows_f16((const MdxSoftmaxDesc*)d, st);
+            default: return set_error(MDX_EINVAL, "unknown opcode %ld", (long)op->opcode);
+        }
+    }
+    if (op->dtype != MDX_DTYPE_BF16) return set_error(MDX_EINVAL, "MdxOp.dtype %ld: 0 (bf16) or 1 (fp16)", (long)op->dtype);
     switch (op->opcode) {
         case MDX_OP_GEMM: return mdx_gemm_bf16((const MdxGemmDesc*)d, st);
         case MDX_OP_CONV: return mdx_conv2d_bf16((const MdxConvDesc*)d, st);

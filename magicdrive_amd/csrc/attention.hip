@@ -203,7 +203,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
                 for (int ks = 0; ks < D16; ++ks) {
                     Frag8 kf;
                     kf.u = *(const uint4*)(kr + ks * 16);
-                    sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v, qf[ks].v, sacc[sub], 0, 0, 0);
+                    sacc[sub] = MDX_MFMA_32x32x16(kf.v, qf[ks].v, sacc[sub]);
                 }
             }
             // ---- online softmax (this lane: one query, 32 of the 64 kv) ----
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
                     Frag8 vf;
                     vf.d2[0] = *(const uint2*)(vr + i * 32 * VSTR);
                     vf.d2[1] = *(const uint2*)(vr + i * 32 * VSTR + 8);
-                    oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, oacc[i], 0, 0, 0);
+                    oacc[i] = MDX_MFMA_32x32x16(vf.v, pf.v, oacc[i]);
                 }
             }
             __syncthreads();

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
     if (ONES) {
         for (int c = tid; c < A2_NBUF * 8; c += A2_NT) {       // row D of every buffer's V^T tile: 8 slots of 16 bytes (the swizzle permutes them within the row)
             const int bufi = c >> 3, slot = c & 7;
-            *(uint4*)(smem + bufi * BUF + K_BYTES + PAD_TAIL + D * 128 + slot * 16) = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+            *(uint4*)(smem + bufi * BUF + K_BYTES + PAD_TAIL + D * 128 + slot * 16) = make_uint4(MDX_ONE16 * 0x10001u, MDX_ONE16 * 0x10001u, MDX_ONE16 * 0x10001u, MDX_ONE16 * 0x10001u);
         }
     }
 
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
                     oacc[qt][i][t][e] = 0.f;
                 }
     }
-    const unsigned one_slot = half ? 0x00003F80u : 0u;          // FOLD: K fragment of the pad k-step for the upper half lanes = (1, 0, ..., 0)
+    const unsigned one_slot = half ? MDX_ONE16 : 0u;          // FOLD: K fragment of the pad k-step for the upper half lanes = (1, 0, ..., 0)
 
     // One kv tile for the first NQ_ query tiles of the wave: scores, online softmax, PV.  The K / V^T fragments are read once and used
     // by every query tile.  LAST adds the kv >= Tk mask (the V^T pad columns were scrubbed by the caller).
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) sacc[s][r] = 0.f;                                       \
                 _Pragma("unroll") for (int ks = 0; ks < D16; ++ks) {                                                   \
                     if (A2_ABL & 8) sacc[s][ks] += __uint_as_float(kf_[s][ks].u.x ^ qf[qt][ks].u.x);                   \
-                    else sacc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf_[s][ks].v, qf[qt][ks].v, sacc[s], 0, 0, 0); \
+                    else sacc[s] = MDX_MFMA_32x32x16(kf_[s][ks].v, qf[qt][ks].v, sacc[s]); \
                 }                                                                                                      \
             }                                                                                                          \
             if (LAST) {                                                                                                \
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
                 /* scores are already relative to m_run; raise it when a tile exceeds it by A2_DEFER — and always on a source's first tile */ \
                 if (((FIRST_) || __builtin_amdgcn_ballot_w64(mx > A2_DEFER) != 0) && !(A2_ABL & 4)) {                   \
                     const float inc_ = (FIRST_) ? mx : fmaxf(mx, 0.f);                                                 \
-                    const float m_new = __uint_as_float(pack2bf(m_run[qt] + inc_, 0.f) << 16);       /* on the bf16 grid */ \
+                    const float m_new = bf2f((bf16_t)(pack2bf(m_run[qt] + inc_, 0.f) & 0xffffu));   /* on the 16-bit grid */ \
                     const float delta_ = m_new - m_run[qt];                                                            \
                     alpha = (FIRST_) ? 0.f : __builtin_amdgcn_exp2f(-delta_);      /* first tile: O is zero; exp2 of a large -delta would be inf */ \
                     m_run[qt] = m_new;                                                                                 \
@@ -342,8 +342,8 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
                 _Pragma("unroll") for (int i = 0; i < D16; ++i) {                                                      \
                     if (A2_ABL & 16) { oacc[qt][i][0][0] += __uint_as_float(vf_[s][i].u.x ^ b0.u.x ^ b0.u.y ^ b0.u.z ^ b0.u.w); oacc[qt][i][1][0] += __uint_as_float(vf_[s][i].u.y ^ b1.u.x ^ b1.u.y ^ b1.u.z ^ b1.u.w); } \
                     else {                                                                                             \
-                        oacc[qt][i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf_[s][i].v, b0.v, oacc[qt][i][0], 0, 0, 0); \
-                        oacc[qt][i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf_[s][i].v, b1.v, oacc[qt][i][1], 0, 0, 0); \
+                        oacc[qt][i][0] = MDX_MFMA_16x16x32(vf_[s][i].v, b0.v, oacc[qt][i][0]); \
+                        oacc[qt][i][1] = MDX_MFMA_16x16x32(vf_[s][i].v, b1.v, oacc[qt][i][1]); \
                     }                                                                                                  \
                 }                                                                                                      \
             }                                                                                                          \
@@ -443,8 +443,8 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
                         a[0] *= inv; a[1] *= inv; a[2] *= inv; a[3] *= inv;
                         if (TWO) {
                             const unsigned u0 = osum[TWO ? qt : 0][TWO ? i : 0][tq][0], u1 = osum[TWO ? qt : 0][TWO ? i : 0][tq][1];
-                            a[0] += __uint_as_float(u0 << 16); a[1] += __uint_as_float(u0 & 0xffff0000u);
-                            a[2] += __uint_as_float(u1 << 16); a[3] += __uint_as_float(u1 & 0xffff0000u);
+                            a[0] += bf2f((bf16_t)(u0 & 0xffffu)); a[1] += bf2f((bf16_t)(u0 >> 16));
+                            a[2] += bf2f((bf16_t)(u1 & 0xffffu)); a[3] += bf2f((bf16_t)(u1 >> 16));
                         }
                     }
                 }

@@ -1,21 +1,55 @@
 // common.h — device helpers shared by the gfx950 kernels of libmdx.
-// CDNA4 only: wave64, MFMA bf16 (v_mfma_f32_32x32x16_bf16), 160 KiB LDS per CU.
+// CDNA4 only: wave64, MFMA (v_mfma_f32_32x32x16 / 16x16x32, bf16 or f16 operands), 160 KiB LDS per CU.
+//
+// The 16-bit storage / operand type is a BUILD parameter: every kernel source is compiled twice (csrc/Makefile), with MDX_F16 = 0
+// (bf16: the default, namespace mdx, entry points mdx_*_bf16 / mdx_*) and with MDX_F16 = 1 (IEEE fp16 — what the reference samples in,
+// magicdrive/misc/test_utils.py:95 — namespace mdx_f16 through -Dmdx=mdx_f16, entry points mdx_*_f16, launch.h).  Accumulation is fp32
+// in both; the MFMA rate is the same.  `bf16_t` and the helpers bf2f / f2bf / pack2bf / add2bf keep their round-1 names: they mean
+// "the 16-bit type of this build".
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef unsigned short bf16_t;  // raw bf16 storage (upper half of an fp32)
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // one MFMA A/B fragment (4 VGPRs)
+#ifndef MDX_F16
+#define MDX_F16 0
+#endif
+
+typedef unsigned short bf16_t;  // raw 16-bit storage: bf16 (upper half of an fp32) or, in the MDX_F16 build, IEEE fp16
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;   // 32x32 MFMA accumulator
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 #define MDX_WAVE 64
 
+#if MDX_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8_t;  // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(2))) _Float16 bf16x2_t;
+#define MDX_ONE16 0x3C00u                                        // 1.0 in the 16-bit type
+#define MDX_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define MDX_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+__device__ __forceinline__ float bf2f(bf16_t v) {
+    _Float16 h;
+    __builtin_memcpy(&h, &v, 2);
+    return (float)h;
+}
+// fp32 -> fp16, round-to-nearest-even (v_cvt_pk_f16_f32 on gfx950 for the pair)
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    bf16x2_t v = {(_Float16)lo, (_Float16)hi};
+    return *reinterpret_cast<uint32_t*>(&v);
+}
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    _Float16 v = (_Float16)f;
+    return *reinterpret_cast<bf16_t*>(&v);
+}
+#else
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+#define MDX_ONE16 0x3F80u
+#define MDX_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define MDX_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // fp32 -> bf16, round-to-nearest-even: hipcc lowers the __bf16 casts to v_cvt_pk_bf16_f32 on gfx950
 // (one instruction per PAIR of values — the hand-written integer rounding was ~7 VALU ops per value).
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     bf16x2_t v = {(__bf16)lo, (__bf16)hi};
     return *reinterpret_cast<uint32_t*>(&v);
@@ -24,6 +58,7 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     __bf16 v = (__bf16)f;
     return *reinterpret_cast<bf16_t*>(&v);
 }
+#endif
 
 // x * sigmoid(x) with v_rcp_f32 (1 ulp) instead of the IEEE division sequence (v_div_scale / v_div_fmas / v_div_fixup: ~12 instructions)
 __device__ __forceinline__ float silu_f(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(GCParams p) {
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][j].v, af[cur][i].v, acc[i][j], 0, 0, 0);
+                            acc[i][j] = MDX_MFMA_32x32x16(bfr[cur][j].v, af[cur][i].v, acc[i][j]);
                 }
                 if (ks + 1 < BK / 16) {
 #pragma unroll

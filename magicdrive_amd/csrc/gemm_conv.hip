@@ -212,7 +212,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 1) void gemm_con
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][j].v, af[cur][i].v, acc[i][j], 0, 0, 0);
+                        acc[i][j] = MDX_MFMA_32x32x16(bfr[cur][j].v, af[cur][i].v, acc[i][j]);
                 if (ks + 1 < BK / 16) {                              // {1 MFMA, 1 ds_read} x 4 (PIPE is only instantiated for TM = TN = 2)
                     static_assert(TM == 2 && TN == 2, "interleave pattern");
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 1) void gemm_con
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j].v, af[i].v, acc[i][j], 0, 0, 0);
+                        acc[i][j] = MDX_MFMA_32x32x16(bfr[j].v, af[i].v, acc[i][j]);
             }
         }
         if (t + 1 < nt) store_tile(buf ^ 1);

@@ -219,11 +219,11 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
                     if (vtile) {          // operands swapped: the accumulator comes out transposed (lane = channel, registers = tokens)
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i].v, wf[s * 4 + ks].v, acc[i], 0, 0, 0);
+                            acc[i] = MDX_MFMA_32x32x16(af[ks & 1][i].v, wf[s * 4 + ks].v, acc[i]);
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s * 4 + ks].v, af[ks & 1][i].v, acc[i], 0, 0, 0);
+                            acc[i] = MDX_MFMA_32x32x16(wf[s * 4 + ks].v, af[ks & 1][i].v, acc[i]);
                     }
                 }
                 // pin the order {4 fragment reads of k-step ks + 1} {4 MFMAs of k-step ks}: the machine scheduler otherwise sinks the

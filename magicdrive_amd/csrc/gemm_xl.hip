@@ -270,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
             _Pragma("unroll") for (int i = 0; i < TIH; ++i)                                                                       \
                 _Pragma("unroll") for (int j = 0; j < (NJ); ++j)                                                                  \
                     acc[(h) * TIH + i][(J0) + j] =                                                                                \
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[(D0) + j][kk].v, af[i][kk].v, acc[(h) * TIH + i][(J0) + j], 0, 0, 0); \
+                        MDX_MFMA_16x16x32(bfr[(D0) + j][kk].v, af[i][kk].v, acc[(h) * TIH + i][(J0) + j]); \
         __builtin_amdgcn_s_setprio(0);                                                                                            \
     }
     // D = Wfrag x Afrag: the accumulator holds 4 consecutive n (rows of D) of one m (column of D) per lane
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
             _Pragma("unroll") for (int i = 0; i < TIH; ++i)                                                                       \
                 _Pragma("unroll") for (int j = (J0); j < (J0) + (NJ); ++j)                                                        \
                     acc[(h) * TIH + i][j] =                                                                                       \
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j][kk].v, af[i][kk].v, acc[(h) * TIH + i][j], 0, 0, 0);       \
+                        MDX_MFMA_16x16x32(bfr[j][kk].v, af[i][kk].v, acc[(h) * TIH + i][j]);       \
         __builtin_amdgcn_s_setprio(0);                                                                                            \
     }
     // MFMA segment of the two-phase schedule: one A half x every B tile, with up to four DMA pieces interleaved between the MFMAs
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
             if (do_mma) {                                                                                                         \
                 _Pragma("unroll") for (int j = 0; j < TJ; ++j)                                                                    \
                     acc[(h) * TIH + i][j] =                                                                                       \
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j][kk].v, af[i][kk].v, acc[(h) * TIH + i][j], 0, 0, 0);       \
+                        MDX_MFMA_16x16x32(bfr[j][kk].v, af[i][kk].v, acc[(h) * TIH + i][j]);       \
             }                                                                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                                                    \
         }                                                                                                                         \

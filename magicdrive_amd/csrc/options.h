@@ -7,6 +7,10 @@
 #pragma once
 #include <cstdint>
 
+namespace mdx_rt {
+int64_t opt(int id);                 // current value of a switch (api.hip; one table for the bf16 and the fp16 kernels)
+}
+
 namespace mdx {
 
 #define MDX_OPTIONS(X) \
@@ -49,6 +53,6 @@ enum Opt : int {
     OPT_COUNT
 };
 
-int64_t opt(int id);                 // current value (api.hip)
+using mdx_rt::opt;
 
 }  // namespace mdx

@@ -95,6 +95,8 @@ class ConditioningBuffers:
 
     def __init__(self, bld: Builder, cn: PackedNet, cfg, n_scene: int, n_cam: int, L_box: int, latent_hw, n_text: int = 77):
         dev = bld.device
+        H16 = bld.dtype                     # the plan's 16-bit activation type (bf16 or fp16)
+        self.dtype = H16
         cc = cfg["controlnet"]; bb = cc["bbox"]
         self.minmax_normalize = bool(bb.get("minmax_normalize", False))
         self.n_scene, self.n_cam, self.L = n_scene, n_cam, L_box
@@ -103,12 +105,12 @@ class ConditioningBuffers:
         self.S = 1 + n_text + L_box
         self.n_text = n_text
         S = self.S
-        self.ctx = torch.zeros(B, S, D, dtype=BF16, device=dev)
+        self.ctx = torch.zeros(B, S, D, dtype=H16, device=dev)
         # camera: [B, 7, 3] fp32 (columns of the (3,7) matrix) -> Fourier 189 -> cam2token -> ctx[:, 0]
         ncol = cc["uncond_cam_in_dim"][1]
         F_cam = cc["cam_embedder_num_freqs"]
         self.cam_in = torch.zeros(B, ncol, 3, dtype=F32, device=dev)
-        cam_emb = torch.empty(B, ncol * (3 + 6 * F_cam), dtype=BF16, device=dev)
+        cam_emb = torch.empty(B, ncol * (3 + 6 * F_cam), dtype=H16, device=dev)
         bld.emit(O.Fourier(self.cam_in, cam_emb, F_cam, name="cam.fourier"))
         wc = cn.lin("cam2token.weight")
         bld.emit(O.Conv(cam_emb.view(B, 1, 1, -1), wc.view(wc.shape[0], 1, 1, wc.shape[1]), _rows_as_pixels(self.ctx[:, 0, :]),
@@ -122,17 +124,17 @@ class ConditioningBuffers:
             self.box_in = torch.zeros(n, P, 3, dtype=F32, device=dev)
             self.box_mask = torch.zeros(n, dtype=torch.uint8, device=dev)
             self.box_cls = torch.zeros(n, dtype=torch.int64, device=dev)
-            pos = torch.empty(n, fdim, dtype=BF16, device=dev)
+            pos = torch.empty(n, fdim, dtype=H16, device=dev)
             bld.emit(O.Fourier(self.box_in, pos, Fq, mask=self.box_mask, null_feat=cn.vec("bbox_embedder.null_pos_feature"), name="box.fourier"))
-            e1 = torch.empty(n, pd[0] + ctd, dtype=BF16, device=dev)       # [silu(bbox_proj) | class token]
+            e1 = torch.empty(n, pd[0] + ctd, dtype=H16, device=dev)       # [silu(bbox_proj) | class token]
             wp = cn.lin("bbox_embedder.bbox_proj.weight")
             bld.emit(O.Conv(pos.view(n, 1, 1, fdim), wp.view(pd[0], 1, 1, fdim), _rows_as_pixels(e1[:, :pd[0]]),
                             bias=cn.vec("bbox_embedder.bbox_proj.bias"), pad=(0, 0), epilogue=L.EPI_SILU, direct=True, name="box.bbox_proj"))
             bld.emit(O.Gather(cn.table("bbox_embedder._class_tokens"), e1[:, pd[0]:], self.box_cls, mask=self.box_mask,
                               null_row=cn.vec_bf16("bbox_embedder.null_class_feature"), name="box.class_token"))
-            e2 = torch.empty(n, pd[1], dtype=BF16, device=dev)
+            e2 = torch.empty(n, pd[1], dtype=H16, device=dev)
             bld.emit(O.Gemm(e1, cn.lin("bbox_embedder.second_linear.0.weight"), e2, bias=cn.vec("bbox_embedder.second_linear.0.bias"), epilogue=L.EPI_SILU, name="box.mlp0"))
-            e3 = torch.empty(n, pd[2], dtype=BF16, device=dev)
+            e3 = torch.empty(n, pd[2], dtype=H16, device=dev)
             bld.emit(O.Gemm(e2, cn.lin("bbox_embedder.second_linear.2.weight"), e3, bias=cn.vec("bbox_embedder.second_linear.2.bias"), epilogue=L.EPI_SILU, name="box.mlp2"))
             # last layer writes straight into the box rows of every view's context (batched over views)
             bld.emit(O.Gemm(e3.view(B, L_box, pd[2]), cn.lin("bbox_embedder.second_linear.4.weight"), self.ctx[:, 1 + n_text:, :],
@@ -144,7 +146,7 @@ class ConditioningBuffers:
         msz = cc["map_size"]
         ch = cc["conditioning_embedding_out_channels"]
         self.map_in = torch.zeros(n_scene, msz[0], msz[1], msz[2], dtype=F32, device=dev)
-        x = torch.empty(n_scene, msz[1], msz[2], msz[0], dtype=BF16, device=dev)
+        x = torch.empty(n_scene, msz[1], msz[2], msz[0], dtype=H16, device=dev)
         bld.emit(O.Layout(self.map_in, x, True, name="map.nhwc"))
         pre = "controlnet_cond_embedding."
         layers = [(pre + "conv_in.", (1, 1), (1, 1), True)]
@@ -172,7 +174,7 @@ class ConditioningBuffers:
             Hi, Wi = x.shape[1], x.shape[2]
             Ho = (Hi + 2 * pad[0] - 3) // stride[0] + 1
             Wo = (Wi + 2 * pad[1] - 3) // stride[1] + 1
-            y = torch.empty(n_scene, Ho, Wo, wt.shape[0], dtype=BF16, device=dev)
+            y = torch.empty(n_scene, Ho, Wo, wt.shape[0], dtype=H16, device=dev)
             bld.emit(O.Conv(x, wt, y, bias=cn.vec(key + "bias"), stride=stride, pad=pad, epilogue=L.EPI_SILU if act else L.EPI_NONE,
                             direct=(wt.shape[3] % 8 != 0 or wt.shape[0] % 4 != 0), ws=bld.ws, name="map." + key))
             keep.append(y)
@@ -181,7 +183,7 @@ class ConditioningBuffers:
             raise ValueError(f"map encoder output {tuple(x.shape[1:3])} != latent size {(h, w)}: select BEVControlNetConditioningEmbeddingPlus with "
                              f"conditioning_embedding_size={[h, w]} (configs/exp/272x736.yaml:15-22; spec.with_plus_map_embedder)")
         C0 = x.shape[3]
-        self.map_rep = torch.empty(B, h, w, C0, dtype=BF16, device=dev)
+        self.map_rep = torch.empty(B, h, w, C0, dtype=H16, device=dev)
         for s in range(n_scene):
             for c in range(n_cam):
                 bld.emit(O.Ew(L.EW_COPY, x[s].view(h * w, C0), self.map_rep[s * n_cam + c].view(h * w, C0), name="map.repeat"))
@@ -197,6 +199,7 @@ class ConditioningBuffers:
         n, Hi, Wi, C = x.shape
         Ho, Wo = out_hw
         dev = x.device
+        H16 = x.dtype
 
         def windows(I, Oo):
             m = torch.zeros(Oo, I, dtype=torch.float64)
@@ -204,10 +207,10 @@ class ConditioningBuffers:
                 a, b = (o * I) // Oo, -((-(o + 1) * I) // Oo)
                 m[o, a:b] = 1.0 / (b - a)
             return m
-        P = torch.kron(windows(Hi, Ho), windows(Wi, Wo)).to(BF16).to(dev)              # [(oy,ox), (iy,ix)]
-        xn = torch.empty(n, C, Hi, Wi, dtype=BF16, device=dev)
+        P = torch.kron(windows(Hi, Ho), windows(Wi, Wo)).to(H16).to(dev)              # [(oy,ox), (iy,ix)]
+        xn = torch.empty(n, C, Hi, Wi, dtype=H16, device=dev)
         bld.emit(O.Layout(x, xn, False, name="map.pool.nchw"))
-        y = torch.empty(n, Ho, Wo, C, dtype=BF16, device=dev)
+        y = torch.empty(n, Ho, Wo, C, dtype=H16, device=dev)
         bld.emit(O.Gemm(P, xn.view(n, C, Hi * Wi), y.view(n, Ho * Wo, C), epilogue=L.EPI_SILU, ws=bld.ws, name="map.pool"))
         keep += [P, xn, y]
         return y
@@ -220,7 +223,7 @@ class ConditioningBuffers:
         assert camera_param.shape[:2] == (ns, nc), f"camera_param {tuple(camera_param.shape)} vs scenes {ns} cams {nc}"
         self.cam_in.copy_(camera_param.to(self.cam_in.device, F32).permute(0, 1, 3, 2).reshape(ns * nc, -1, 3))
         assert text.shape[0] == ns and text.shape[1] == self.n_text
-        self.ctx.view(ns, nc, self.S, -1)[:, :, 1:1 + self.n_text, :] = text.to(self.ctx.device, BF16).unsqueeze(1)
+        self.ctx.view(ns, nc, self.S, -1)[:, :, 1:1 + self.n_text, :] = text.to(self.ctx.device, self.ctx.dtype).unsqueeze(1)
         self.map_in.copy_(bev_map.to(self.map_in.device, F32))
         if self.L > 0:
             assert boxes is not None
@@ -270,11 +273,13 @@ class SamplerPlan:
         B = self.c * b * n_cam
         self.B = B
         Cl = cfg["in_channels"]
-        bld = Builder(cfg, device, B, n_cam)
+        assert unet.dtype == cn.dtype, "UNet and ControlNet must be packed in the same 16-bit type"
+        self.dtype = unet.dtype
+        bld = Builder(cfg, device, B, n_cam, dtype=self.dtype)
         self.bld = bld
         # state
         self.x = torch.zeros(b * n_cam, h, w, Cl, dtype=F32, device=device)            # latents, NHWC
-        self.x_in = torch.zeros(B, h, w, CIN_PAD, dtype=BF16, device=device)            # model input ([uncond|cond] copies), channels padded
+        self.x_in = torch.zeros(B, h, w, CIN_PAD, dtype=self.dtype, device=device)      # model input ([uncond|cond] copies), channels padded
         self.eps = torch.zeros(B, h, w, cfg["out_channels"], dtype=F32, device=device)
         self.coef = torch.zeros(num_steps, 4 if scheduler_kind == "ddim" else 12, dtype=F32, device=device)
         if scheduler_kind == "unipc":       # multistep history of the fused UniPC update (scheduling_unipc_multistep.py:518-600)
@@ -403,10 +408,11 @@ class ControlNetPlan:
         B = n_scene * n_cam
         h, w = latent_hw
         self.cfg, self.device, self.B, self.n_scene, self.n_cam, self.h, self.w = cfg, device, B, n_scene, n_cam, h, w
-        bld = Builder(cfg, device, B, n_cam)
+        self.dtype = cn.dtype
+        bld = Builder(cfg, device, B, n_cam, dtype=self.dtype)
         self.bld = bld
         self.sample_nchw = torch.zeros(B, cfg["in_channels"], h, w, dtype=F32, device=device)
-        self.x_in = torch.zeros(B, h, w, CIN_PAD, dtype=BF16, device=device)
+        self.x_in = torch.zeros(B, h, w, CIN_PAD, dtype=self.dtype, device=device)
         bld.emit(O.Layout(self.sample_nchw, self.x_in[..., :cfg["in_channels"]], True, name="cn.sample.nhwc"))
         self.cond = ConditioningBuffers(bld, cn, cfg, n_scene, n_cam, L_box, latent_hw, n_text)
         self.temb = TembTable(cn, B, device, per_sample=True)        # one timestep per view row
@@ -418,12 +424,12 @@ class ControlNetPlan:
             key = f"controlnet_down_blocks.{k}."
             r = bld.new(s.B, s.H, s.W, s.C)
             bld.emit(O.Gemm(s.tok, cn.lin(key + "weight", conditioning_scale), r.tok, bias=cn.vec(key + "bias", conditioning_scale), name=f"zero_conv.{k}"))
-            o = torch.zeros(s.B, s.C, s.H, s.W, dtype=BF16, device=device)
+            o = torch.zeros(s.B, s.C, s.H, s.W, dtype=self.dtype, device=device)
             bld.emit(O.Layout(r.bhwc, o, False, name=f"res{k}.nchw"))
             self.down_out.append(o)
         r = bld.new(mid.B, mid.H, mid.W, mid.C)
         bld.emit(O.Gemm(mid.tok, cn.lin("controlnet_mid_block.weight", conditioning_scale), r.tok, bias=cn.vec("controlnet_mid_block.bias", conditioning_scale), name="zero_conv.mid"))
-        self.mid_out = torch.zeros(mid.B, mid.C, mid.H, mid.W, dtype=BF16, device=device)
+        self.mid_out = torch.zeros(mid.B, mid.C, mid.H, mid.W, dtype=self.dtype, device=device)
         bld.emit(O.Layout(r.bhwc, self.mid_out, False, name="mid.nchw"))
         self.ops = bld.ops
         self.program: Optional[L.Program] = None
@@ -452,12 +458,13 @@ class UNetPlan:
         assert B % n_cam == 0, "batch must hold whole scenes: (b n) views (blocks.py:196-197)"
         h, w = latent_hw
         self.cfg, self.device, self.B, self.S, self.h, self.w = cfg, device, B, S, h, w
-        bld = Builder(cfg, device, B, n_cam)
+        self.dtype = unet.dtype
+        bld = Builder(cfg, device, B, n_cam, dtype=self.dtype)
         self.bld = bld
         D = cfg["cross_attention_dim"]
         self.sample_nchw = torch.zeros(B, cfg["in_channels"], h, w, dtype=F32, device=device)
-        self.x_in = torch.zeros(B, h, w, CIN_PAD, dtype=BF16, device=device)
-        self.ctx = torch.zeros(B, S, D, dtype=BF16, device=device)
+        self.x_in = torch.zeros(B, h, w, CIN_PAD, dtype=self.dtype, device=device)
+        self.ctx = torch.zeros(B, S, D, dtype=self.dtype, device=device)
         bld.emit(O.Layout(self.sample_nchw, self.x_in[..., :cfg["in_channels"]], True, name="unet.sample.nhwc"))
         self.temb = TembTable(unet, B, device, per_sample=True)
         self.temb.emit_fill(bld, unet, cfg)
@@ -470,13 +477,13 @@ class UNetPlan:
         self.mid_in = None
         if with_residuals:
             for k, s in enumerate(skips):
-                rin = torch.zeros(s.B, s.C, s.H, s.W, dtype=BF16, device=device)
+                rin = torch.zeros(s.B, s.C, s.H, s.W, dtype=self.dtype, device=device)
                 rn = bld.new(s.B, s.H, s.W, s.C)
                 bld.emit(O.Layout(rin, rn.bhwc, True, name=f"res{k}.nhwc"))
                 bld.emit(O.Ew(L.EW_ADD, rn.tok, s.tok, name=f"skip{k}+=res"))
                 bld.free(rn)
                 self.res_in.append(rin)
-            self.mid_in = torch.zeros(mid.B, mid.C, mid.H, mid.W, dtype=BF16, device=device)
+            self.mid_in = torch.zeros(mid.B, mid.C, mid.H, mid.W, dtype=self.dtype, device=device)
             rn = bld.new(mid.B, mid.H, mid.W, mid.C)
             bld.emit(O.Layout(self.mid_in, rn.bhwc, True, name="midres.nhwc"))
             bld.emit(O.Ew(L.EW_ADD, rn.tok, mid.tok, name="mid+=res"))
@@ -495,12 +502,12 @@ class UNetPlan:
         self.sample_nchw.copy_(sample.to(self.device, F32))
         t = torch.as_tensor(timestep).to(self.device, F32).reshape(-1)
         self.temb.t.copy_(t.expand(self.B) if t.numel() == 1 else t)
-        self.ctx.copy_(ehs.to(self.device, BF16))
+        self.ctx.copy_(ehs.to(self.device, self.dtype))
         if self.res_in:
             assert down_res is not None and len(down_res) == len(self.res_in)
             for dst, src in zip(self.res_in, down_res):
-                dst.copy_(src.to(self.device, BF16))
-            self.mid_in.copy_(mid_res.to(self.device, BF16))
+                dst.copy_(src.to(self.device, self.dtype))
+            self.mid_in.copy_(mid_res.to(self.device, self.dtype))
         with torch.cuda.device(self.device):
             self.program.run(_stream(self.device))
         return self.out_nchw

@@ -38,9 +38,11 @@ def q_prescale(head_dim: int) -> float:
 class PackedNet:
     """Device-resident, kernel-layout weights of one network, packed lazily from a reference state dict."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], device):
+    def __init__(self, sd: Dict[str, torch.Tensor], device, dtype=BF16):
+        assert dtype in (torch.bfloat16, torch.float16), "the kernels take bf16 or fp16 operands (fp32 accumulate)"
         self.sd = sd
         self.device = device
+        self.dtype = dtype                 # 16-bit storage type of the packed weights = the type the activations are computed in
         self.cache: Dict[Tuple, torch.Tensor] = {}
 
     def has(self, key: str) -> bool:
@@ -53,58 +55,60 @@ class PackedNet:
         return self.cache[ck]
 
     def lin(self, key, scale: float = 1.0):            # [N,K] bf16 (1x1 convs too)
-        return self._get(("lin", scale), [key], lambda w: (w.reshape(w.shape[0], -1) * scale).contiguous().to(BF16))
+        return self._get(("lin", scale), [key], lambda w: (w.reshape(w.shape[0], -1) * scale).contiguous().to(self.dtype))
 
     def conv(self, key):                               # [Cout,kh,kw,Cin] bf16
-        return self._get("conv", [key], PK.pack_conv_weight)
+        return self._get("conv", [key], lambda w: PK.pack_conv_weight(w, self.dtype))
 
     def conv_cin_padded(self, key, cin_pad: int):      # [Cout,kh,kw,cin_pad] bf16, extra input channels zero
         def f(w):
             wp = torch.zeros(w.shape[0], cin_pad, w.shape[2], w.shape[3])
             wp[:, :w.shape[1]] = w
-            return PK.pack_conv_weight(wp)
+            return PK.pack_conv_weight(wp, self.dtype)
         return self._get(("convpad", cin_pad), [key], f)
 
     def vec(self, key, scale: float = 1.0):            # fp32 vector
         return self._get(("vec", scale), [key], lambda v: (v.reshape(-1) * scale).contiguous().to(F32))
 
     def vec_bf16(self, key):
-        return self._get("vecbf", [key], lambda v: v.reshape(-1).contiguous().to(BF16))
+        return self._get("vecbf", [key], lambda v: v.reshape(-1).contiguous().to(self.dtype))
 
     def cat_lin(self, keys: Sequence[str], scales: Sequence[float] = ()):            # rows concatenated (each part optionally scaled, in fp32)
         sc = tuple(scales) if scales else (1.0,) * len(keys)
         return self._get(("catlin",) + sc, keys,
-                         lambda *ws: torch.cat([w.reshape(w.shape[0], -1) * f for w, f in zip(ws, sc)], 0).contiguous().to(BF16))
+                         lambda *ws: torch.cat([w.reshape(w.shape[0], -1) * f for w, f in zip(ws, sc)], 0).contiguous().to(self.dtype))
 
     def cat_vec(self, keys: Sequence[str]):
         return self._get("catvec", keys, lambda *vs: torch.cat([v.reshape(-1) for v in vs]).contiguous().to(F32))
 
     def geglu(self, wkey, bkey):
-        w = self._get("gegluw", [wkey, bkey], lambda w, b: PK.pack_geglu(w, b)[0])
-        b = self._get("geglub", [wkey, bkey], lambda w, b: PK.pack_geglu(w, b)[1])
+        w = self._get("gegluw", [wkey, bkey], lambda w, b: PK.pack_geglu(w, b, self.dtype)[0])
+        b = self._get("geglub", [wkey, bkey], lambda w, b: PK.pack_geglu(w, b, self.dtype)[1])
         return w, b
 
     def folded_affine(self, w2key, b2key, w1key, b1key, b1_scale: float = 1.0):
         """y = W2 (W1 x + s b1) + b2  ->  (W2 W1) x + (W2 s b1 + b2), folded in fp32."""
         keys = [w2key, b2key, w1key, b1key]
-        w = self._get(("foldw", b1_scale), keys, lambda w2, b2, w1, b1: (w2 @ w1).contiguous().to(BF16))
+        w = self._get(("foldw", b1_scale), keys, lambda w2, b2, w1, b1: (w2 @ w1).contiguous().to(self.dtype))
         b = self._get(("foldb", b1_scale), keys, lambda w2, b2, w1, b1: (w2 @ (b1 * b1_scale) + b2).contiguous().to(F32))
         return w, b
 
     def table(self, key):                              # 2-D bf16 table (class tokens)
-        return self._get("table", [key], lambda t: t.contiguous().to(BF16))
+        return self._get("table", [key], lambda t: t.contiguous().to(self.dtype))
 
 
 class Pool:
     """Exact-size free-list of device buffers; the program's ops alias freed buffers, which is safe because
     a program executes in order on one stream."""
 
-    def __init__(self, device):
+    def __init__(self, device, dtype=BF16):
         self.device = device
+        self.dtype = dtype                 # default element type of a buffer: the plan's 16-bit activation type
         self.free_list: Dict[Tuple, List[torch.Tensor]] = {}
         self.total_bytes = 0
 
-    def get(self, shape, dtype=BF16) -> torch.Tensor:
+    def get(self, shape, dtype=None) -> torch.Tensor:
+        dtype = dtype or self.dtype
         n = 1
         for s in shape:
             n *= int(s)
@@ -156,12 +160,13 @@ class Act:
 class Builder:
     """Emits IR ops for the two networks at a fixed batch geometry."""
 
-    def __init__(self, cfg, device, n_views: int, n_cam: int, ws_mb: int = 64):
+    def __init__(self, cfg, device, n_views: int, n_cam: int, ws_mb: int = 64, dtype=BF16):
         self.cfg = cfg
         self.device = device
         self.B = n_views                  # c * b * n_cam views through the nets
         self.n_cam = n_cam
-        self.pool = Pool(device)
+        self.dtype = dtype                # bf16 or fp16: activations and weights of every op this builder emits
+        self.pool = Pool(device, dtype)
         self.ops: List[object] = []
         self.ws = torch.empty(ws_mb * 1024 * 1024 // 4, dtype=F32, device=device)
         self.groups = cfg["norm_num_groups"]
@@ -415,7 +420,7 @@ class TembTable:
         bld.emit(O.TimeEmb(self.t, sin, flip_sin_to_cos=cfg["flip_sin_to_cos"], freq_shift=cfg["freq_shift"], name="temb.sin"))
         h1 = torch.empty(self.rows, 4 * c0, dtype=F32, device=dev)
         h2 = torch.empty(self.rows, 4 * c0, dtype=F32, device=dev)
-        act = torch.empty(self.rows, 4 * c0, dtype=BF16, device=dev)
+        act = torch.empty(self.rows, 4 * c0, dtype=net.dtype, device=dev)
         as4 = lambda t: t.view(self.rows, 1, 1, t.shape[1])
         w1 = net.lin("time_embedding.linear_1.weight"); w2 = net.lin("time_embedding.linear_2.weight")
         bld.emit(O.Conv(as4(sin), w1.view(w1.shape[0], 1, 1, w1.shape[1]), as4(h1), bias=net.vec("time_embedding.linear_1.bias"),
@@ -439,8 +444,8 @@ def build_context_kv(bld: Builder, net: PackedNet, ctx: torch.Tensor, B: int, S:
             continue
         pre = k[:-len("to_k.weight")]
         C = net.sd[k].shape[0]
-        Kc = torch.empty(B, S, C, dtype=BF16, device=bld.device)
-        Vt = torch.zeros(B, C, ldv, dtype=BF16, device=bld.device)
+        Kc = torch.empty(B, S, C, dtype=net.dtype, device=bld.device)
+        Vt = torch.zeros(B, C, ldv, dtype=net.dtype, device=bld.device)
         bld.emit(O.Gemm(ctx.view(B * S, D), net.lin(k), Kc.view(B * S, C), ws=bld.ws, name=pre + "K"))
         bld.emit(O.Gemm(net.lin(pre + "to_v.weight"), ctx, Vt[:, :, :S], name=pre + "vT"))
         out[pre] = (Kc, Vt, S)

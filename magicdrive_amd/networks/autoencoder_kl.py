@@ -111,6 +111,9 @@ class AutoencoderKL:
         """.to(device) / .to(dtype) / .to(device, dtype) like a torch module (dtype = API dtype of decode()'s output)."""
         for a in list(args) + list(kw.values()):
             if isinstance(a, torch.dtype):
+                if (a == torch.float16) != (self._dtype == torch.float16):
+                    self._packed = None      # the decoder's 16-bit arithmetic type follows the requested dtype
+                    self._plans.clear()
                 self._dtype = a
             elif isinstance(a, (str, torch.device)):
                 dev = torch.device(a)
@@ -135,7 +138,9 @@ class AutoencoderKL:
 
     def packed(self) -> PackedNet:
         if self._packed is None:
-            self._packed = PackedNet(self._sd, self._device)
+            # arithmetic type: fp16 when the model was asked for in fp16 (what the reference samples in, misc/test_utils.py:95), bf16
+            # otherwise (incl. fp32 requests: operands are 16-bit on the MFMA path either way, accumulation is fp32)
+            self._packed = PackedNet(self._sd, self._device, torch.float16 if self._dtype == torch.float16 else torch.bfloat16)
         return self._packed
 
     @torch.no_grad()

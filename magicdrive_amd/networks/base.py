@@ -183,7 +183,10 @@ class MdxModel:
             if isinstance(a, torch.dtype):
                 if a not in (torch.bfloat16, torch.float16, torch.float32):
                     raise ValueError(a)
-                self._dtype = a          # API dtype of inputs/outputs; kernels compute in bf16 with fp32 accumulate
+                if (a == torch.float16) != (self._dtype == torch.float16):
+                    self._packed = None  # the 16-bit arithmetic type follows the requested dtype: repack (fp16 <-> bf16)
+                    self._plans.clear()
+                self._dtype = a          # API dtype of inputs/outputs; fp16 -> fp16 kernels, anything else -> bf16 kernels (fp32 accumulate)
             elif isinstance(a, (str, torch.device)):
                 dev = torch.device(a)
                 if dev != self._device:
@@ -197,7 +200,9 @@ class MdxModel:
 
     def packed(self) -> PackedNet:
         if self._packed is None:
-            self._packed = PackedNet(self._sd, self._device)
+            # arithmetic type: fp16 when the model was asked for in fp16 (what the reference samples in, misc/test_utils.py:95), bf16
+            # otherwise (incl. fp32 requests: operands are 16-bit on the MFMA path either way, accumulation is fp32)
+            self._packed = PackedNet(self._sd, self._device, torch.float16 if self._dtype == torch.float16 else torch.bfloat16)
         return self._packed
 
     def num_parameters(self) -> int:

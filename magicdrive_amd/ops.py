@@ -16,6 +16,8 @@ import torch
 from . import _lib as L
 
 BF16 = torch.bfloat16
+F16 = torch.float16
+H16 = (BF16, F16)          # the two 16-bit storage types: every 16-bit operand of ONE op must use the same one (dtype_code)
 F32 = torch.float32
 
 
@@ -89,11 +91,11 @@ class Gemm:
         if self.Vt is not None:
             _chk(self.epilogue == L.EPI_NONE and batch == 1 and No == self.vt_from and 0 < self.vt_from < N and self.vt_T > 0,
                  f"gemm {self.name}: fused V^T output needs a plain epilogue and C with vt_from columns")
-            _chk(self.Vt.dim() == 3 and self.Vt.dtype == BF16 and self.Vt.stride(2) == 1 and self.Vt.shape[1] == N - self.vt_from
+            _chk(self.Vt.dim() == 3 and self.Vt.dtype == A.dtype and self.Vt.stride(2) == 1 and self.Vt.shape[1] == N - self.vt_from
                  and self.Vt.shape[0] * self.vt_T == M and self.Vt.shape[2] >= self.vt_T, f"gemm {self.name}: Vt shape {tuple(self.Vt.shape)}")
         else:
             _chk(No == (N // 2 if self.epilogue == L.EPI_GEGLU else N), f"gemm {self.name}: C has {No} cols for N={N}")
-        _chk(A.dtype == BF16 and W.dtype == BF16 and Cm.dtype in (BF16, F32), f"gemm {self.name}: dtypes")
+        _chk(A.dtype in H16 and W.dtype == A.dtype and Cm.dtype in (A.dtype, F32), f"gemm {self.name}: dtypes")
         d = L.MdxGemmDesc()
         d.A, d.W, d.C = _p(A), _p(W), _p(C2)
         ldr = 0
@@ -154,7 +156,7 @@ class Conv:
         B, Hi, Wi, Cin, ldx = _nhwc(self.X)
         B2, Ho, Wo, Cout, ldy = _nhwc(self.Y)
         Co2, kh, kw, Ci2 = self.Wt.shape
-        _chk(self.Wt.is_contiguous() and self.Wt.dtype == BF16, f"conv {self.name}: weights must be packed bf16")
+        _chk(self.Wt.is_contiguous() and self.Wt.dtype in H16, f"conv {self.name}: weights must be packed bf16 / fp16")
         _chk(B == B2 and Cout == Co2 and Cin == Ci2, f"conv {self.name}: shape mismatch")
         sh, sw = self.stride
         ph, pw = self.pad
@@ -181,7 +183,7 @@ class Conv:
             d.x_is_f32 = int(self.X.dtype == F32)
             d.y_is_f32 = int(self.Y.dtype == F32)
         else:
-            _chk(self.X.dtype == BF16 and self.Y.dtype == BF16, f"conv {self.name}: MFMA path is bf16")
+            _chk(self.X.dtype == self.Wt.dtype and self.Y.dtype == self.Wt.dtype, f"conv {self.name}: the MFMA path takes one 16-bit type")
             d.splitk = self.splitk
             if self.ws is not None:
                 d.ws = _p(self.ws); d.ws_bytes = self.ws.numel() * self.ws.element_size()
@@ -288,7 +290,7 @@ class Softmax:
     opcode = L.OP_SOFTMAX
 
     def lower(self):
-        _chk(self.X.dtype == F32 and self.Y.dtype == BF16 and self.X.dim() == 2 and self.Y.dim() == 2, "softmax: dtypes / rank")
+        _chk(self.X.dtype == F32 and self.Y.dtype in H16 and self.X.dim() == 2 and self.Y.dim() == 2, "softmax: dtypes / rank")
         _chk(self.X.stride(1) == 1 and self.Y.stride(1) == 1 and self.X.shape[0] == self.Y.shape[0], "softmax: layout")
         _chk(0 < self.T <= self.X.shape[1] and self.T <= self.Y.shape[1], "softmax: T")
         d = L.MdxSoftmaxDesc()
@@ -382,7 +384,7 @@ class Fourier:
         n, Pn, three = self.X.shape
         _chk(three == 3 and self.X.is_contiguous() and self.X.dtype == F32, "fourier: X fp32 [n,P,3]")
         n2, width, ldy = _rows2d(self.Y)
-        _chk(n2 == n and width == Pn * (3 + 6 * self.F) and self.Y.dtype == BF16, "fourier: Y")
+        _chk(n2 == n and width == Pn * (3 + 6 * self.F) and self.Y.dtype in H16, "fourier: Y")
         d = L.MdxFourierDesc()
         d.X, d.Y, d.mask, d.null_feat = _p(self.X), _p(self.Y), _p(self.mask), _p(self.null_feat)
         if self.mask is not None:
@@ -461,7 +463,7 @@ class DdimStep:
             if self.x_in.dtype == F32:
                 _chk(self.x_in.is_contiguous() and self.x_in.numel() == self.eps.numel(), "ddim: x_in")
             else:
-                _chk(self.x_in.dtype == BF16 and self.x_in.dim() == 2 and self.x_in.is_contiguous() and self.xin_c > 0, "ddim: bf16 x_in must be [pixels, ld]")
+                _chk(self.x_in.dtype in H16 and self.x_in.dim() == 2 and self.x_in.is_contiguous() and self.xin_c > 0, "ddim: bf16 x_in must be [pixels, ld]")
                 _chk(self.x_in.shape[0] * self.xin_c == self.eps.numel() and self.x_in.shape[1] >= self.xin_c, "ddim: bf16 x_in shape")
                 d.xin_c, d.xin_ld = self.xin_c, self.x_in.shape[1]
         d.n, d.cfg, d.guidance = n, int(self.cfg), float(self.guidance)
@@ -504,14 +506,30 @@ class UniPCStep:
             if self.x_in.dtype == F32:
                 _chk(self.x_in.numel() == self.eps.numel(), "unipc: x_in")
             else:
-                _chk(self.x_in.dtype == BF16 and self.x_in.dim() == 2 and self.xin_c > 0 and self.x_in.shape[0] * self.xin_c == self.eps.numel(), "unipc: bf16 x_in")
+                _chk(self.x_in.dtype in H16 and self.x_in.dim() == 2 and self.xin_c > 0 and self.x_in.shape[0] * self.xin_c == self.eps.numel(), "unipc: bf16 x_in")
                 d.xin_c, d.xin_ld = self.xin_c, self.x_in.shape[1]
         d.n, d.cfg, d.guidance = n, int(self.cfg), float(self.guidance)
         return self.opcode, d
 
 
+def dtype_code(op) -> int:
+    """MdxOp.dtype of an IR op: fp16 when its 16-bit tensors are torch.float16, else bf16 (ops without 16-bit tensors run either build)."""
+    for v in vars(op).values():
+        if isinstance(v, torch.Tensor):
+            if v.dtype == F16:
+                return L.DTYPE_F16
+            if v.dtype == BF16:
+                return L.DTYPE_BF16
+    return L.DTYPE_BF16
+
+
+def lower_with_dtype(op):
+    code, desc = op.lower()
+    return code, desc, dtype_code(op)
+
+
 def build_program(ops) -> L.Program:
-    return L.Program([op.lower() for op in ops])
+    return L.Program([lower_with_dtype(op) for op in ops])
 
 
 def run_ops(ops, stream: Optional[int] = None) -> None:
@@ -528,9 +546,7 @@ def run_ops(ops, stream: Optional[int] = None) -> None:
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             for op in ops:
-                code, desc = op.lower()
-                L.call_op(code, desc, stream)
+                L.call_op(*op.lower(), stream, dtype_code(op))
         return
     for op in ops:
-        code, desc = op.lower()
-        L.call_op(code, desc, stream)
+        L.call_op(*op.lower(), stream, dtype_code(op))

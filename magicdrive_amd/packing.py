@@ -12,17 +12,17 @@ import numpy as np
 import torch
 
 
-def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+def pack_conv_weight(w: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:
     assert w.dim() == 4
-    return w.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+    return w.detach().permute(0, 2, 3, 1).contiguous().to(dtype)
 
 
-def pack_linear_weight(w: torch.Tensor) -> torch.Tensor:
+def pack_linear_weight(w: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:
     assert w.dim() == 2
-    return w.detach().contiguous().to(torch.bfloat16)
+    return w.detach().contiguous().to(dtype)
 
 
-def pack_geglu(w: torch.Tensor, b: torch.Tensor):
+def pack_geglu(w: torch.Tensor, b: torch.Tensor, dtype=torch.bfloat16):
     """[2F, K] with rows [value(F) | gate(F)] -> rows [v0..31, g0..31, v32..63, g32..63, ...]."""
     two_f, k = w.shape
     f = two_f // 2
@@ -33,7 +33,7 @@ def pack_geglu(w: torch.Tensor, b: torch.Tensor):
     bv = b[:f].reshape(f // 32, 32)
     bg = b[f:].reshape(f // 32, 32)
     bp = torch.stack([bv, bg], dim=1).reshape(two_f)
-    return wp.contiguous().to(torch.bfloat16), bp.contiguous().to(torch.float32)
+    return wp.contiguous().to(dtype), bp.contiguous().to(torch.float32)
 
 
 def nearest_index(n_in: int, n_out: int) -> torch.Tensor:

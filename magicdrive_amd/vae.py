@@ -34,7 +34,9 @@ class VaeDecodePlan:
         self.ws = torch.empty(64 * 1024 * 1024 // 4, dtype=F32, device=device)
         emit = self.ops.append
 
-        def buf(*shape, dtype=BF16, zero=False):
+        H16 = net.dtype                     # bf16 or fp16: the type the decoder's weights were packed in
+
+        def buf(*shape, dtype=H16, zero=False):
             t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=device)
             self.keep.append(t)
             return t

@@ -1,0 +1,126 @@
+"""-m gpu: the fp16 build of the kernels (MDX_DTYPE_F16: f16 MFMA operands and storage, fp32 accumulate — what the reference samples
+in, magicdrive/misc/test_utils.py:95 `weight_dtype = torch.float16`; its runtime attention check is 2e-3,
+third_party/diffusers/src/diffusers/models/attention_processor.py:34).
+
+Kernel level: the bf16 kernel tests of tests/test_kernels_gpu.py / test_routes_gpu.py re-run on torch.float16 tensors against the same
+fp32 torch references, at xformers' fp16 table (atol 4e-3 x mean|ref|, rtol 4e-4: helpers.close kind="f16").
+Loop level: the drop-in pipeline with torch_dtype=torch.float16 models at SD-1.5 size vs the REAL reference's fixtures."""
+import contextlib
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import helpers
+from helpers import bf16_round, check, parity_log, rel_l2, scene
+from magicdrive_amd import _lib as L
+from magicdrive_amd.networks import spec
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@contextlib.contextmanager
+def fp16_tensors():
+    """Make the kernel test modules build fp16 tensors: their `rnd` helpers default to the module constant BF."""
+    import test_kernels_gpu as TK
+    import test_routes_gpu as TR
+    saved = []
+    for m in (TK, TR):
+        saved.append((m, m.BF, m.rnd.__defaults__))
+        m.BF = torch.float16
+        m.rnd.__defaults__ = tuple(torch.float16 if d is torch.bfloat16 else d for d in m.rnd.__defaults__)
+    helpers.DEFAULT_KIND = "f16"
+    try:
+        yield TK, TR
+    finally:
+        helpers.DEFAULT_KIND = "bf16"
+        for m, bf, dfl in saved:
+            m.BF = bf
+            m.rnd.__defaults__ = dfl
+
+
+def test_fp16_gemm_conv_norm_kernels(dev):
+    with fp16_tensors() as (TK, TR):
+        TK.test_gemm(dev, 8400, 320, 320, True, True, False)            # weight-stationary K = 320
+        TK.test_gemm(dev, 2100, 640, 2560, True, False, False)          # generic tile
+        TK.test_gemm(dev, 168, 1280, 5120, True, True, False)           # split-K
+        TK.test_gemm(dev, 777, 96, 136, True, False, False)             # ragged
+        TR.test_xl_gemm(dev, 41037, 1280, 1280, True, True, False, 0, "gemm_xl_kernel<256x")
+        TR.test_xl_gemm(dev, 82000, 320, 1280, True, True, True, 0, "gemm_xl_kernel<256x")
+        TR.test_xl_gemm_geglu(dev)
+        TR.test_xl_gemm_temb_rows(dev)
+        TR.test_xl_conv(dev, 48, 28, 50, 320, 320, (1, 1), True, True, "gemm_xl_kernel<256x")
+        TR.test_xl_conv(dev, 480, 7, 13, 1280, 1280, (1, 1), True, True, "gemm_xl_kernel<256x")
+        TR.test_xl_conv(dev, 240, 28, 50, 320, 320, (2, 2), False, False, "gemm_xl_kernel<256x")
+        assert TR.geglu_case(26400, 1280, 320) == "gemm_ws_kernel<geglu>"
+        TR.test_flattened_batched_vt(dev, 60, 350, 640)
+        with L.options(GEMM_XL=0):
+            TR.conv_case(16, 28, 50, 320, 320, expect="conv3x3_kernel")
+            TR.gemm_case(8736, 1280, 1280, res=True, expect="gemm_conv_kernel<128,128,64")
+
+
+def test_fp16_attention_kernels(dev):
+    with fp16_tensors() as (TK, TR):
+        for pre in (False, True):
+            for case in TK.ATTN2_CASES[:5] + TK.ATTN2_CASES[6:]:
+                TK.test_attention2(dev, *case, pre)
+            TK.test_attention2_softmax_rescale_branch(dev, pre)
+            TK.test_attention2_crossview(dev, 1, 8, 1400, 40, pre)
+            TK.test_attention2_crossview(dev, 3, 8, 350, 80, pre)
+        TK.test_attention_joint_sources(dev, 2, 8, 1400, 40, 2, "attn2_kernel<40,joint,q64>", True)
+        TK.test_attention_joint_sources(dev, 2, 8, 91, 160, 6, "attn_kernel<10,2,joint>", False)
+
+
+def _pipe16(cfg, dev):
+    """fp16 models holding the bf16-rounded seeded weights of the fixtures (a bf16 value is exactly representable in fp16 unless it is
+    below 2^-14: the comparison measures fp16 ARITHMETIC, not a different weight rounding)."""
+    from magicdrive_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiview
+    from magicdrive_amd.networks.unet_addon_rawbox import BEVControlNetModel
+    from magicdrive_amd.pipeline.pipeline_bev_controlnet import StableDiffusionBEVControlNetPipeline
+    usd = bf16_round(spec.random_state_dict(spec.unet_param_shapes(cfg), 0))
+    csd = bf16_round(spec.random_state_dict(spec.controlnet_param_shapes(cfg), 1))
+    unet = UNet2DConditionModelMultiview(cfg, usd, torch_dtype=torch.float16)
+    cn = BEVControlNetModel(cfg, csd, torch_dtype=torch.float16)
+    pipe = StableDiffusionBEVControlNetPipeline(unet=unet, controlnet=cn).to(dev)
+    assert unet.packed().dtype == torch.float16 and cn.packed().dtype == torch.float16
+    return pipe
+
+
+@pytest.fixture(scope="module")
+def sd15_pipe16(dev):
+    return _pipe16(spec.SD15_CONFIG, dev)
+
+
+def test_fp16_sd15_50step_ddim_loop_vs_reference(dev, sd15_pipe16):
+    """BASELINE configs[1] in fp16: the full 50 DDIM steps vs the real reference pipeline's latents."""
+    G = torch.load(os.path.join(GOLD, "sd15_loop50.pt"), weights_only=False)
+    cfg = spec.SD15_CONFIG
+    sc = scene(cfg, 1, None, (28, 50), zero_map=True)
+    out = sd15_pipe16(prompt=None, image=sc["bev_map"], camera_param=None, height=224, width=400, num_inference_steps=G["steps"],
+                      guidance_scale=G["guidance"], latents=sc["latents"], prompt_embeds=sc["prompt_embeds"].half(),
+                      negative_prompt_embeds=sc["negative_prompt_embeds"].half(), output_type="latent",
+                      bev_controlnet_kwargs={"bboxes_3d_data": None}).images
+    torch.cuda.synchronize()
+    assert out.dtype == torch.float16 and torch.isfinite(out).all()
+    ref = G["latents"].float()
+    e = max(rel_l2(out[:, v], ref[:, v]) for v in range(6))
+    print(f"[fp16 sd15 50-step DDIM vs REAL reference] worst view {e:.5f}")
+    check("fp16 sd15 50-step DDIM loop vs REAL reference: worst view", e, 3e-3)
+
+
+def test_fp16_sd15_cfg_loop_full_conditioning_vs_reference(dev, sd15_pipe16):
+    """BASELINE configs[2] in fp16: camera + 32 boxes + BEV map + CFG 2.0, 10 DDIM steps vs the real reference pipeline."""
+    G = torch.load(os.path.join(GOLD, "sd15_loop_cfg.pt"), weights_only=False)
+    cfg = spec.SD15_CONFIG
+    sc = scene(cfg, 1, 32, (28, 50))
+    out = sd15_pipe16(prompt=None, image=sc["bev_map"], camera_param=sc["camera_param"], height=224, width=400, num_inference_steps=G["steps"],
+                      guidance_scale=G["guidance"], latents=sc["latents"], prompt_embeds=sc["prompt_embeds"].half(),
+                      negative_prompt_embeds=sc["negative_prompt_embeds"].half(), output_type="latent",
+                      bev_controlnet_kwargs={"bboxes_3d_data": sc["bboxes_3d_data"]}).images
+    torch.cuda.synchronize()
+    ref = G["latents"].float()
+    e = max(rel_l2(out[:, v], ref[:, v]) for v in range(6))
+    print(f"[fp16 sd15 10-step CFG loop vs REAL reference] worst view {e:.5f}")
+    check("fp16 sd15 10-step CFG loop vs REAL reference: worst view", e, 5e-3)

@@ -97,7 +97,7 @@ def test_gemm_weight_stationary_geglu_ragged(dev):
     M, F_, K = 8250, 320, 320
     A = rnd(M, K, seed=1); W = rnd(2 * F_, K, scale=K ** -0.5, seed=2, dtype=torch.float32, dev="cpu")
     b = rnd(2 * F_, seed=3, dtype=torch.float32, dev="cpu")
-    Wp, bp = PK.pack_geglu(W, b)
+    Wp, bp = PK.pack_geglu(W, b, BF)
     C = torch.zeros(M, F_, dtype=BF, device=dev)
     O.run_ops([O.Gemm(A, Wp.to(dev), C, bias=bp.to(dev), epilogue=L.EPI_GEGLU)])
     torch.cuda.synchronize()
@@ -134,7 +134,7 @@ def test_gemm_strided_views_and_temb(dev):
 def test_gemm_geglu(dev, M, F_, K):
     A = rnd(M, K, seed=1); W = rnd(2 * F_, K, scale=K ** -0.5, seed=2, dtype=torch.float32, dev="cpu")
     b = rnd(2 * F_, seed=3, dtype=torch.float32, dev="cpu")
-    Wp, bp = PK.pack_geglu(W, b)
+    Wp, bp = PK.pack_geglu(W, b, BF)
     C = torch.zeros(M, F_, dtype=BF, device=dev)
     O.run_ops([O.Gemm(A, Wp.to(dev), C, bias=bp.to(dev), epilogue=L.EPI_GEGLU, ws=ws_buf(dev))])
     torch.cuda.synchronize()
@@ -177,7 +177,7 @@ def test_conv_mfma(dev, B, H, W, Cin, Cout, k, stride, pad, res, temb):
     y = torch.zeros(B, Ho, Wo, Cout, dtype=BF, device=dev)
     R = rnd(B, Ho, Wo, Cout, seed=4) if res else None
     tb = rnd(B, Cout, seed=5, dtype=torch.float32) if temb else None
-    O.run_ops([O.Conv(x, PK.pack_conv_weight(w).to(dev), y, bias=b, R=R, temb=tb, temb_b_stride=Cout if temb else 0,
+    O.run_ops([O.Conv(x, PK.pack_conv_weight(w, BF).to(dev), y, bias=b, R=R, temb=tb, temb_b_stride=Cout if temb else 0,
                       stride=stride, pad=pad, ws=ws_buf(dev))])
     torch.cuda.synchronize()
     ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.to(BF).float(), b.cpu(), stride=stride, padding=pad)
@@ -191,7 +191,7 @@ def test_conv_silu_epilogue(dev):
     x = rnd(1, 20, 20, 16, seed=1)
     w = rnd(16, 16, 3, 3, scale=0.1, seed=2, dtype=torch.float32, dev="cpu"); b = rnd(16, seed=3, dtype=torch.float32)
     y = torch.zeros(1, 20, 20, 16, dtype=BF, device=dev)
-    O.run_ops([O.Conv(x, PK.pack_conv_weight(w).to(dev), y, bias=b, epilogue=L.EPI_SILU)])
+    O.run_ops([O.Conv(x, PK.pack_conv_weight(w, BF).to(dev), y, bias=b, epilogue=L.EPI_SILU)])
     torch.cuda.synchronize()
     ref = F.silu(F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.to(BF).float(), b.cpu(), padding=1)).permute(0, 2, 3, 1)
     close(y, ref, name="conv+silu")
@@ -211,7 +211,7 @@ def test_conv_direct(dev, case):
     w = rnd(Cout, Cin, k, k, scale=(Cin * k * k) ** -0.5, seed=2, dtype=torch.float32, dev="cpu"); b = rnd(Cout, seed=3, dtype=torch.float32)
     y = torch.zeros(B, H, W, Cout, dtype=torch.float32 if yf else BF, device=dev)
     pad = (k // 2, k // 2)
-    O.run_ops([O.Conv(x, PK.pack_conv_weight(w).to(dev), y, bias=b, pad=pad, direct=True)])
+    O.run_ops([O.Conv(x, PK.pack_conv_weight(w, BF).to(dev), y, bias=b, pad=pad, direct=True)])
     torch.cuda.synchronize()
     ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.to(BF).float(), b.cpu(), padding=pad).permute(0, 2, 3, 1)
     close(y, ref, name=case)

@@ -78,7 +78,7 @@ def test_xl_gemm_geglu(dev):
     """Packed GEGLU at the bench shape of level 1 (N = 8C = 5120, K = 640): value / gate tiles meet in one lane."""
     M, F_, K = 40960 + 100, 2560, 640
     A = rnd(M, K, seed=1); W = rnd(2 * F_, K, scale=K ** -0.5, seed=2, dtype=torch.float32); b = rnd(2 * F_, seed=3, dtype=torch.float32)
-    Wp, bp = PK.pack_geglu(W.cpu(), b.cpu())
+    Wp, bp = PK.pack_geglu(W.cpu(), b.cpu(), BF)
     C = torch.zeros(M, F_, dtype=BF, device=dev)
     k = run_one(O.Gemm(A, Wp.to(dev), C, bias=bp.to(dev), epilogue=L.EPI_GEGLU, ws=ws_buf()))
     assert k == "gemm_xl_kernel<256x256,gemm>", k
@@ -128,7 +128,7 @@ def test_xl_conv(dev, B, H, W, Cin, Cout, stride, res, temb, expect):
     y = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=BF, device=dev)
     R = rnd(B, Ho, Wo, Cout, seed=4) if res else None
     tb = rnd(B, Cout, seed=5, dtype=torch.float32) if temb else None
-    k = run_one(O.Conv(x, PK.pack_conv_weight(w.cpu()).to(dev), y, bias=b, R=R, temb=tb, temb_b_stride=Cout if temb else 0,
+    k = run_one(O.Conv(x, PK.pack_conv_weight(w.cpu(), BF).to(dev), y, bias=b, R=R, temb=tb, temb_b_stride=Cout if temb else 0,
                        stride=stride, pad=(1, 1), ws=ws_buf()))
     assert k.startswith(expect) and k.endswith(",conv>"), f"routed to {k!r}, expected {expect!r}"
     close(y, conv_ref(x, w, b, stride, (1, 1), tb, R), name=f"xl conv {B}x{H}x{W} {Cin}->{Cout}")
@@ -137,7 +137,7 @@ def test_xl_conv(dev, B, H, W, Cin, Cout, stride, res, temb, expect):
 def geglu_case(M, F_, K, expect=None):
     dev = torch.device("cuda")
     A = rnd(M, K, seed=1); W = rnd(2 * F_, K, scale=K ** -0.5, seed=2, dtype=torch.float32); b = rnd(2 * F_, seed=3, dtype=torch.float32)
-    Wp, bp = PK.pack_geglu(W.cpu(), b.cpu())
+    Wp, bp = PK.pack_geglu(W.cpu(), b.cpu(), BF)
     C = torch.zeros(M, F_, dtype=BF, device=dev)
     k = run_one(O.Gemm(A, Wp.to(dev), C, bias=bp.to(dev), epilogue=L.EPI_GEGLU, ws=ws_buf()))
     h, g = (A.float() @ W.to(BF).float().T + b).chunk(2, dim=-1)
@@ -197,7 +197,7 @@ def conv_case(B, H, W, Cin, Cout, stride=(1, 1), res=True, temb=True, expect=Non
     y = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=BF, device=dev)
     R = rnd(B, Ho, Wo, Cout, seed=4) if res else None
     tb = rnd(B, Cout, seed=5, dtype=torch.float32) if temb else None
-    k = run_one(O.Conv(x, PK.pack_conv_weight(w.cpu()).to(dev), y, bias=b, R=R, temb=tb, temb_b_stride=Cout if temb else 0, stride=stride, pad=(1, 1), ws=ws_buf()))
+    k = run_one(O.Conv(x, PK.pack_conv_weight(w.cpu(), BF).to(dev), y, bias=b, R=R, temb=tb, temb_b_stride=Cout if temb else 0, stride=stride, pad=(1, 1), ws=ws_buf()))
     close(y, conv_ref(x, w, b, stride, (1, 1), tb, R), name=f"conv {B}x{H}x{W} {Cin}->{Cout} ({k})")
     assert expect is None or k.startswith(expect), (k, expect)
     return k
