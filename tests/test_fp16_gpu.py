@@ -28,9 +28,9 @@ def fp16_tensors():
     import test_routes_gpu as TR
     saved = []
     for m in (TK, TR):
-        saved.append((m, m.BF, m.rnd.__defaults__))
+        saved.append((m, m.BF, dict(m.rnd.__kwdefaults__)))
         m.BF = torch.float16
-        m.rnd.__defaults__ = tuple(torch.float16 if d is torch.bfloat16 else d for d in m.rnd.__defaults__)
+        m.rnd.__kwdefaults__ = {k: (torch.float16 if d is torch.bfloat16 else d) for k, d in m.rnd.__kwdefaults__.items()}   # rnd(*shape, dtype=BF, ...)
     helpers.DEFAULT_KIND = "f16"
     try:
         yield TK, TR
@@ -38,7 +38,7 @@ def fp16_tensors():
         helpers.DEFAULT_KIND = "bf16"
         for m, bf, dfl in saved:
             m.BF = bf
-            m.rnd.__defaults__ = dfl
+            m.rnd.__kwdefaults__ = dfl
 
 
 def test_fp16_gemm_conv_norm_kernels(dev):
@@ -107,7 +107,7 @@ def test_fp16_sd15_50step_ddim_loop_vs_reference(dev, sd15_pipe16):
     ref = G["latents"].float()
     e = max(rel_l2(out[:, v], ref[:, v]) for v in range(6))
     print(f"[fp16 sd15 50-step DDIM vs REAL reference] worst view {e:.5f}")
-    check("fp16 sd15 50-step DDIM loop vs REAL reference: worst view", e, 3e-3)
+    check("fp16 sd15 50-step DDIM loop vs REAL reference: worst view", e, 6e-4)            # measured 0.028 % (bf16: 0.41 %)
 
 
 def test_fp16_sd15_cfg_loop_full_conditioning_vs_reference(dev, sd15_pipe16):
@@ -123,4 +123,4 @@ def test_fp16_sd15_cfg_loop_full_conditioning_vs_reference(dev, sd15_pipe16):
     ref = G["latents"].float()
     e = max(rel_l2(out[:, v], ref[:, v]) for v in range(6))
     print(f"[fp16 sd15 10-step CFG loop vs REAL reference] worst view {e:.5f}")
-    check("fp16 sd15 10-step CFG loop vs REAL reference: worst view", e, 5e-3)
+    check("fp16 sd15 10-step CFG loop vs REAL reference: worst view", e, 1.5e-3)          # measured 0.069 % (bf16: 0.72 %)
