@@ -606,7 +606,11 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
     constexpr int RIT = (HROWS + RPP - 1) / RPP;                  // passes: 16 (256-wide), 11 (320-wide half, 160-wide)
     const int rrow0 = tid / CPR, rc8 = (tid - rrow0 * CPR) * 8;
     const bool ractive = tid < RPP * CPR && n0 + rc8 < p.N;
+#ifdef MDX_XL_R2_RESIDUAL                                       // A/B side build: the 320-wide tile keeps round 2's batches of four
+    const bool rpref = NH == 1 && Rg != nullptr && p.wide && !geglu;
+#else
     const bool rpref = Rg != nullptr && p.wide && !geglu;
+#endif
     uint4 rpre[RIT];
     auto fetch_residual = [&](int hh) {
         const int mh_ = m0 + hh * HROWS;
