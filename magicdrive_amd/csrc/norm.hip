@@ -152,6 +152,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_kernel(GNParams p) {
 struct GN2Params {
     const bf16_t* X; bf16_t* Y; const float* gamma; const float* beta; float* part;   // part: [B][nchunk][G][3]
     int B, HW, C, G, PCH, nchunk; long ldx, ldy; float eps; int silu;
+    int rev;      // statistics pass walks images and chunks in DEscending order (see mdx_groupnorm_bf16)
 };
 
 constexpr int GN2_NT = 320;       // most threads per workgroup
@@ -164,7 +165,7 @@ template <int NCV>
 __global__ __launch_bounds__(GN2_NT) void gn_stats_kernel(GN2Params p) {
     __shared__ float ls1[GN2_NT * 8 * NCV], ls2[GN2_NT * 8 * NCV];       // [row][C] sums (rows * C <= 2560 * NCV)
     __shared__ float lpiv[256];                                    // per group pivot (G <= 256)
-    const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int chunk = p.rev ? p.nchunk - 1 - (int)blockIdx.x : (int)blockIdx.x, b = p.rev ? p.B - 1 - (int)blockIdx.y : (int)blockIdx.y, tid = threadIdx.x;
     const int px0 = chunk * p.PCH;
     const int npx = min(p.PCH, p.HW - px0);
     const int C8 = p.C / 8, cpg = p.C / p.G;
@@ -404,6 +405,10 @@ extern "C" int mdx_groupnorm_bf16(const MdxGroupNormDesc* d, void* stream) {
         GN2Params q;
         q.X = p.X; q.Y = p.Y; q.gamma = p.gamma; q.beta = p.beta; q.part = (float*)d->ws;
         q.B = p.B; q.HW = p.HW; q.C = p.C; q.G = p.G; q.ldx = p.ldx; q.ldy = p.ldy; q.eps = p.eps; q.silu = p.silu;
+        // Read order vs the 256 MiB Infinity Cache: the producer wrote the tensor in ascending order, so its TAIL is what is still
+        // cached — the statistics pass walks the tensor from the end, and ends at the head, which is where the apply pass (ascending)
+        // starts: both passes begin on cached lines instead of on the lines evicted longest ago.  GN_REVERSE = 0 restores ascending.
+        q.rev = (int)opt(OPT_GN_REVERSE);
         // chunks: about 4096 workgroups in the grid, at least GN2_U passes of the workgroup's rows each
         const int C8 = p.C / 8, rows = gn2_rows(C8);
         const int nt = C8 > GN2_NT ? GN2_NT : rows * C8;

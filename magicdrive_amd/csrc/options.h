@@ -43,6 +43,7 @@ namespace mdx {
     X(XL_DBG, 0, "ablation bits, only in -DMDX_XL_ABLATE builds") \
     X(XL_TIMING, 0, "per-workgroup s_memtime stamps into the op workspace") \
     X(XL_SCHED, 0, "XL main-loop schedule variant 0..3 (0 = four quadrant phases)") \
+    X(GN_REVERSE, 1, "two-stage GroupNorm: statistics pass reads the tensor back to front (Infinity-Cache reuse between producer / passes)") \
     X(GN_TWO_STAGE, 1, "streaming two-stage GroupNorm for maps >= 32768 elements") \
     X(XL_RASTER, 2, "XL tile order: 0 row-major, 1 XCD-strided M-tiles, 2 XCD-blocked (M-group x N-group panels per XCD)")
 

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--views", type=int, default=384)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--bn", type=str, default="", help="comma list of XL tile widths to force one after the other (160,256,320); default: the library's choice")
     a = ap.parse_args()
     dev = torch.device("cuda")
     B = a.views
@@ -39,6 +40,11 @@ def main():
             return O.Gemm(A, W, C, bias=torch.randn(N, device=dev), R=r(M, No) if res else None, epilogue=epi, ws=ws), 2.0 * M * N * K
         cases[name] = mk
 
+    conv("c_28x50_640_320", 28, 50, 640, 320)
+    conv("c_28x50_960_320", 28, 50, 960, 320)
+    conv("c_14x25_640_640", 14, 25, 640, 640)
+    conv("c_14x25_1920_640", 14, 25, 1920, 640)
+    conv("c_7x13_2560_1280", 7, 13, 2560, 1280)
     conv("c160_28x50_640_640", 28, 50, 640, 640)
     conv("c160_28x50_320_320", 28, 50, 320, 320)
     conv("c256_14x25_1280_1280", 14, 25, 1280, 1280)
@@ -50,25 +56,34 @@ def main():
     gemm("g256_cc_L1", B * 350, 640, 640, res=True)
     gemm("g256_cc_L2", B * 91, 1280, 1280, res=True)
     gemm("g256_geglu_L2", B * 91, 10240, 1280, epi=1)
+    gemm("g256_ffout_L2", B * 91, 1280, 5120, res=True)
+    gemm("g256_qk_L2", B * 91, 2560, 1280)
     gemm("g_geglu_L0", B * 1400, 2560, 320, epi=1)
     gemm("g_out_L0", B * 1400, 320, 320, res=True)
     only = [s for s in a.only.split(",") if s]
     st = torch.cuda.current_stream().cuda_stream
+    bns = [int(x) for x in a.bn.split(",") if x] or [0]
     for name, mk in cases.items():
         if only and not any(name.startswith(o) for o in only):
             continue
         op, fl = mk()
         code, desc = op.lower()
-        for _ in range(2):
-            L.call_op(code, desc, st)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(a.reps):
-            L.call_op(code, desc, st)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / a.reps * 1e3
-        print(f"{name:26s} {us:9.1f} us {fl / us / 1e6:8.1f} TF/s  {(L.lib().mdx_last_kernel() or b'').decode()}", flush=True)
+        for bn in bns:
+            with L.options(**({"GEMM_XL": 2, "XL_BN": bn} if bn else {})):
+                try:
+                    for _ in range(2):
+                        L.call_op(code, desc, st)
+                except L.MdxError as e:
+                    print(f"{name:26s} bn={bn}: {e}")
+                    continue
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.reps):
+                    L.call_op(code, desc, st)
+                e1.record()
+                torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / a.reps * 1e3
+            print(f"{name:26s} {('bn=%d' % bn) if bn else '':7s} {us:9.1f} us {fl / us / 1e6:8.1f} TF/s  {(L.lib().mdx_last_kernel() or b'').decode()}", flush=True)
         del op
         torch.cuda.empty_cache()
 
