@@ -185,9 +185,10 @@ def main():
                     help="after the headline measurement also time ONE configs[2] call of this many scenes per GPU (CFG doubles the views: 32 scenes = "
                          "the headline's 384 views) and report it as config.full_cond_scenes_per_s; 0 skips it")
     ap.add_argument("--no-consistency-check", action="store_true")
-    ap.add_argument("--hires-scenes", type=int, default=0,
+    ap.add_argument("--hires-scenes", type=int, default=4,
                     help="outside the timed region: also sample this many scenes per GPU of BASELINE configs[3] (6-view 432x768, camera + 32 boxes + BEV map "
-                         "through the ...Plus map encoder, CFG 2.0, same sampler) and report config.hires; 0 (default) skips it — it takes minutes")
+                         "through the ...Plus map encoder, CFG 2.0, same sampler) and report config.hires (~1 minute at 4 scenes incl. building the "
+                         "second model); 0 skips it")
     ap.add_argument("--vae-scenes", type=int, default=8,
                     help="outside the timed region: decode this many scenes' latents with the HIP AutoencoderKL (VAE_SD15_CONFIG, random weights) — what output_type='np' "
                          "adds per scene (config.vae_decode_ms_per_scene, config.scenes_per_s_incl_vae_decode); 0 skips it")
