@@ -17,6 +17,7 @@ struct GCParams {
     long ws_bytes;
     int mt, nt, swz;              // tile counts along M / N; swz: XCD-aware tile order (1-D grid); gemm_xl.hip: 2 = XCD-blocked panels
     int gm, gn;                   // swz == 2: an XCD walks panels of gm M-tiles x gn N-tiles (xl_tile_coords in gemm_xl.hip)
+    int nblk;                     // blocks of the tile order incl. the padding blocks of a ragged grid (persistent kernels walk it)
     unsigned long long* timing;   // debug: per-block s_memtime stamps (MDX_GEMM_TIMING=1), else null
     // conv geometry (CONV only); lda doubles as the pixel stride of X
     int Hi, Wi, Cin, Ho, Wo, kh, kw, sh, sw, ph, pw;
@@ -42,14 +43,14 @@ struct GCParams {
 // A rows of that M-tile (and, for conv, the overlapping rows of its 9 taps) are fetched into ONE XCD's L2 once
 // instead of N-tiles times into different L2s at different times (activations at b>=4 exceed the 4 MiB L2s;
 // without this the re-reads come from the Infinity Cache).  Returns false for padding blocks of a ragged grid.
-__device__ __forceinline__ bool tile_coords(const GCParams& p, int& tm, int& tn) {
-    const int bid = blockIdx.x;
+__device__ __forceinline__ bool tile_coords_at(const GCParams& p, int bid, int& tm, int& tn) {
     if (!p.swz) { tm = bid % p.mt; tn = bid / p.mt; return true; }
     const int xcd = bid & 7, local = bid >> 3;
     tn = local % p.nt;
     tm = (local / p.nt) * 8 + xcd;
     return tm < p.mt;
 }
+__device__ __forceinline__ bool tile_coords(const GCParams& p, int& tm, int& tn) { return tile_coords_at(p, (int)blockIdx.x, tm, tn); }
 
 // ---- shared epilogue ---------------------------------------------------------------
 // v[4] are raw accumulators for output row m, raw columns nb..nb+3 (nb % 4 == 0).

@@ -29,64 +29,25 @@
 #include "options.h"
 #include "gemm_params.h"
 #include "xl_layout.h"
+#include "xl_dma.h"
 #include <type_traits>
 
 namespace mdx {
 
 using namespace mdx_xl;
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-
-constexpr unsigned XL_OOB = 0x80000000u;       // voffset >= num_records (also with any soffset < 2^31 added): the load returns 0
-constexpr unsigned XL_RECORDS = 0x80000000u;
 constexpr int XL_SLOTS = 12;                   // distinct temb rows (images) one 256-row tile may span (4x7 images: 11)
-
-template <int N>
-__device__ __forceinline__ void xl_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void xl_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-typedef __attribute__((ext_vector_type(4))) unsigned xl_rsrc_t;   // buffer descriptor words, held in SGPRs
-
-// Raw buffer descriptor (stride 0, 2 GiB window) over `base`.  Every word is made provably wave-uniform so the inline-asm "s"
-// operands below get SGPRs.
-__device__ __forceinline__ xl_rsrc_t xl_make_rsrc(const void* base) {
-    const unsigned long long a = (unsigned long long)base;
-    xl_rsrc_t r;
-    r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
-    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
-    r.z = XL_RECORDS;
-    r.w = 0x00020000u;
-    return r;
-}
-
-// One LDS-DMA piece: 64 lanes x 16 bytes from (descriptor base + soff + voff[lane]) to LDS bytes [lds_addr, lds_addr + 1024).
-// Inline asm on purpose: hipcc models the builtin as an LDS store of unknown extent and drains `vmcnt(0)` in front of the next
-// ds_read — every phase — which serialises the whole pipeline (seen in the .s of the builtin version).  An asm statement is absent
-// from the compiler's wait bookkeeping: completion is counted by hand (xl_wait_vmcnt + s_barrier before any read of the slot, see
-// the schedule in the kernel).  M0 (the DMA's LDS base) is compiler-reserved: saved and restored inside the statement; the s_nop
-// covers the SALU-write-M0 -> LDS-DMA hazard.
-__device__ __forceinline__ void xl_glds(const xl_rsrc_t rs, unsigned lds_addr, unsigned voff, int soff) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
-        : "memory");
-}
 
 // Tile order.  swz == 2 ("XCD-blocked panels", round 3; index math in xl_layout.h: raster_tile): the 32 workgroups an XCD runs side
 // by side are ONE panel of gm M-tiles x gn N-tiles, so the operand bytes that XCD's L2 takes in per round of tiles are gm A-panels +
 // gn W-panels instead of ~32 / nt A-panels + nt W-panels: at N = 5120 (20 N-tiles) the round-2 order streamed the whole 6.5 MB weight
 // matrix through every 4 MiB L2 once per 1.6 M-tiles (13x read over-fetch, 60 % L2 hits: profiles/r02_pmc_summary.json); contiguous
 // M-tiles also share their 3x3 halo rows inside one L2 (conv).
-__device__ __forceinline__ bool xl_tile_coords(const GCParams& p, int& tm, int& tn) {
-    if (p.swz != 2) return tile_coords(p, tm, tn);
-    return raster_tile((int)blockIdx.x, p.mt, p.nt, p.gm, p.gn, &tm, &tn);
+__device__ __forceinline__ bool xl_tile_coords_at(const GCParams& p, int bid, int& tm, int& tn) {
+    if (p.swz != 2) return tile_coords_at(p, bid, tm, tn);
+    return raster_tile(bid, p.mt, p.nt, p.gm, p.gn, &tm, &tn);
 }
+__device__ __forceinline__ bool xl_tile_coords(const GCParams& p, int& tm, int& tn) { return xl_tile_coords_at(p, (int)blockIdx.x, tm, tn); }
 
 template <int BN, bool CONV, int SCHED>
 __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
@@ -829,6 +790,279 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
 #undef XL_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// gemm_xlp_kernel — the PERSISTENT form of the 256 x 256 GEMM tile (round 3).
+//
+// Why: at K = 640 a tile of the kernel above is 16.2 us of main loop + 7.2 us that overlap with nothing (first-slab latency 2.7,
+// accumulator staging through LDS 1.2, store issue 2.2, setup + barriers 1.1: s_memtime stamps, profiles/r03_xl_timing_stamps.log), and
+// with the whole epilogue compiled out the K = 640 GEMMs run 23-37 % faster (profiles/r03_xl_epilogue_ablation.log).  One workgroup
+// per CU owns the CU for the whole launch and walks the tile order; per tile:
+//   main loop (the same quadrant-phase schedule, same LDS layout, same reduction order)
+//   -> the ring is dead: the NEXT tile's slabs 0 and 1 are issued right away (they land while this tile is stored)
+//   -> epilogue WITHOUT LDS: bias / GEGLU in registers, the 16 x 64 strip of a wave is transposed between the four 16-lane rows with
+//      4 v_permlane32_swap + 4 v_permlane16_swap so that every lane holds 16-byte row segments (64 contiguous bytes per row per
+//      instruction), residual added from 16-byte loads, 16-byte stores — no staging pass, no epilogue barriers.
+// The per-lane DMA offsets do not depend on the tile: row / column tails are expressed through the buffer descriptors' num_records
+// (xl_make_rsrc_bounded), so moving to the next tile is two descriptors in SGPRs.
+// Hand-counted VM counter (gfx9: ONE in-order counter for loads, stores and LDS-DMA): at the top of a tile its slab 0 must have
+// landed; younger than it are slab 1's three units and whatever the previous epilogue issued afterwards (its stores, the next bias
+// vectors).  Those are counted exactly when every store instruction of the previous tile was executed by every wave (interior tile:
+// unconditional stores); after an edge tile the wait is conservative (it sits the stores out).
+// Takes: plain / GEGLU epilogue, optional residual, wide (16-byte) C rows; everything else stays on gemm_xl_kernel.
+template <bool GEGLU, bool HAS_R>
+__global__ __launch_bounds__(512, 2) void gemm_xlp_kernel(GCParams p) {
+    using G = Geo<256>;
+    constexpr int BM = 256, BN = 256;
+    constexpr int TI = G::TI, TJ = G::TJ, TJ0 = G::TJ0, TJ1 = TJ - TJ0, TIH = TI / 2;
+    constexpr int A_BYTES = BM * 128, B_BYTES = G::BNP * 128, BUF = A_BYTES + B_BYTES;
+    constexpr int PA = G::PA, PB0 = G::PB0, PB1 = G::PB1;
+    static_assert(TJ == 4 && TI == 8 && PB0 == PB1, "the register epilogue is written for the 128 x 64 wave tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wm = wave % G::WM, wn = wave / G::WM;
+    const int nt = p.K / 64;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_void_t*)smem;
+
+    // ---- tile-invariant DMA bookkeeping ----
+    unsigned a_voff[2][PA]; int a_lds[2][PA];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < PA; ++e) {
+            const int row0 = a_piece_row0<BN>(h, wave, e);
+            a_lds[h][e] = row0 * 128;
+            a_voff[h][e] = (unsigned)(((long)piece_lane_row(row0, lane) * p.lda) * 2 + piece_lane_chunk(row0, lane) * 16);
+        }
+    unsigned b_voff[2][PB0]; int b_lds[2][PB0];
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+        for (int e = 0; e < PB0; ++e) {
+            const int row0 = b_piece_row0<BN>(part, wave, e);
+            b_lds[part][e] = A_BYTES + row0 * 128;
+            b_voff[part][e] = (unsigned)(((long)piece_lane_row(row0, lane) * p.ldw) * 2 + piece_lane_chunk(row0, lane) * 16);
+        }
+    const int fo0 = frag_off(0, lane, 0), fo1 = frag_off(0, lane, 1);
+    const int a_rd = a_tile_row0<BN>(wm, 0) * 128;
+    const int b_rd = A_BYTES + b_tile_row0<BN>(wn, 0) * 128;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // ---- tile walk ----
+    int bid = blockIdx.x, tm = 0, tn = 0;
+    auto advance = [&](int& b) -> bool {
+        for (; b < p.nblk; b += (int)gridDim.x)
+            if (xl_tile_coords_at(p, b, tm, tn)) return true;
+        return false;
+    };
+    if (!advance(bid)) return;
+    int m0 = tm * BM, n0 = tn * BN;
+    xl_rsrc_t rsA, rsB;
+    auto set_tile = [&](int m, int n) {
+        rsA = xl_make_rsrc_bounded(p.A + (long)m * p.lda, (long)(p.M - m) * p.lda * 2);
+        rsB = xl_make_rsrc_bounded(p.W + (long)n * p.ldw, (long)(p.N - n) * p.ldw * 2);
+    };
+    set_tile(m0, n0);
+
+#define XLP_PIECE_A(h, e, T) { if ((T) < nt) xl_glds(rsA, lds0 + ((T) & 1) * BUF + a_lds[h][e], a_voff[h][e], (T) * 128); }
+#define XLP_PIECE_B(part, e, T) { if ((T) < nt) xl_glds(rsB, lds0 + ((T) & 1) * BUF + b_lds[part][e], b_voff[part][e], (T) * 128); }
+#define XLP_ISSUE_A(h, T) { XLP_PIECE_A(h, 0, T) XLP_PIECE_A(h, 1, T) }
+#define XLP_ISSUE_B(part, T) { XLP_PIECE_B(part, 0, T) XLP_PIECE_B(part, 1, T) }
+#define XLP_PROLOGUE() { XLP_ISSUE_A(0, 0) XLP_ISSUE_B(0, 0) XLP_ISSUE_B(1, 0) XLP_ISSUE_A(1, 0) XLP_ISSUE_A(0, 1) XLP_ISSUE_B(0, 1) XLP_ISSUE_B(1, 1) }
+
+    // bias of this lane's 16 columns (4 per MFMA tile j; GEGLU: j = 0, 1 values, j = 2, 3 their gates), fetched per tile
+    float4 bq[TJ];
+    const bool has_bias = p.bias != nullptr;
+    auto load_bias = [&](int n) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) bq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_bias) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int col = n + wn * 64 + j * 16 + 4 * fq;
+                bq[j] = *(const float4*)(p.bias + min(col, p.N - 4));      // clamped: columns past N are never stored
+            }
+        }
+    };
+    load_bias(n0);
+    XLP_PROLOGUE()
+
+    constexpr int INFLIGHT = PA + PB0 + PB1;                      // slab 1's first three units follow slab 0's last
+    constexpr int NST = GEGLU ? TI : 2 * TI;                      // 16-byte stores per lane per tile
+    bool first = true, counted = false;
+    f32x4_t acc[TI][TJ];
+    Frag8 af[TIH][2], bfr[TJ][2];
+#define XLP_READ_A(h, buf_)                                                                                                       \
+    {                                                                                                                             \
+        const unsigned char* s_ = smem + (buf_) * BUF + a_rd + (h) * TIH * 2048;                                                  \
+        _Pragma("unroll") for (int i = 0; i < TIH; ++i) {                                                                         \
+            af[i][0].u = *(const uint4*)(s_ + i * 2048 + fo0);                                                                    \
+            af[i][1].u = *(const uint4*)(s_ + i * 2048 + fo1);                                                                    \
+        }                                                                                                                         \
+    }
+#define XLP_READ_B(J0, NJ, buf_)                                                                                                  \
+    {                                                                                                                             \
+        const unsigned char* s_ = smem + (buf_) * BUF + b_rd;                                                                     \
+        _Pragma("unroll") for (int j = (J0); j < (J0) + (NJ); ++j) {                                                              \
+            bfr[j][0].u = *(const uint4*)(s_ + j * 2048 + fo0);                                                                   \
+            bfr[j][1].u = *(const uint4*)(s_ + j * 2048 + fo1);                                                                   \
+        }                                                                                                                         \
+    }
+#define XLP_MMA(h, J0, NJ)                                                                                                        \
+    {                                                                                                                             \
+        __builtin_amdgcn_s_setprio(1);                                                                                            \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                                          \
+            _Pragma("unroll") for (int i = 0; i < TIH; ++i)                                                                       \
+                _Pragma("unroll") for (int j = (J0); j < (J0) + (NJ); ++j)                                                        \
+                    acc[(h) * TIH + i][j] = MDX_MFMA_16x16x32(bfr[j][kk].v, af[i][kk].v, acc[(h) * TIH + i][j]);                  \
+        __builtin_amdgcn_s_setprio(0);                                                                                            \
+    }
+#define XLP_SEG_END() { xl_wait_lgkm0(); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+#define XLP_MMA_END() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+        // slab 0 of this tile has landed once only the younger VM operations are outstanding
+        if (nt <= 1) xl_wait_vmcnt<0>();
+        else if (first) xl_wait_vmcnt<INFLIGHT>();
+        else if (counted) { if (has_bias) xl_wait_vmcnt<INFLIGHT + NST + TJ>(); else xl_wait_vmcnt<INFLIGHT + NST>(); }
+        else xl_wait_vmcnt<INFLIGHT>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 1) {                                              // the stagger: group 1 runs one barrier behind group 0
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int t = 0; t < nt; ++t) {                               // schedule 0 of gemm_xl_kernel
+            const int buf = t & 1;
+            XLP_READ_A(0, buf)
+            XLP_READ_B(0, TJ0, buf)
+            XLP_ISSUE_A(1, t + 1)
+            XLP_SEG_END()
+            XLP_MMA(0, 0, TJ0)
+            XLP_MMA_END()
+            XLP_READ_B(TJ0, TJ1, buf)
+            XLP_ISSUE_A(0, t + 2)
+            XLP_SEG_END()
+            XLP_MMA(0, TJ0, TJ1)
+            XLP_MMA_END()
+            XLP_READ_A(1, buf)
+            XLP_ISSUE_B(0, t + 2)
+            XLP_SEG_END()
+            XLP_MMA(1, TJ0, TJ1)
+            XLP_MMA_END()
+            XLP_ISSUE_B(1, t + 2)
+            if (t + 2 < nt) xl_wait_vmcnt<INFLIGHT>(); else xl_wait_vmcnt<0>();
+            XLP_SEG_END()
+            XLP_MMA(1, 0, TJ0)
+            XLP_MMA_END()
+        }
+        if (grp == 0) {                                              // balance the stagger: after this barrier the ring is dead
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // close the compiler's bookkeeping of the bias loads BEFORE new DMA traffic is issued (it would otherwise guard their first
+        // use in the epilogue with a wait that also sits out the prefetch)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) asm volatile("" : "+v"(bq[j].x), "+v"(bq[j].y), "+v"(bq[j].z), "+v"(bq[j].w));
+
+        // ---- next tile: descriptors + its first two slabs, before this tile is stored ----
+        int nb = bid + (int)gridDim.x;
+        const int cm0 = m0, cn0 = n0;
+        const bool has_next = advance(nb);
+        if (has_next) {
+            m0 = tm * BM; n0 = tn * BN;
+            set_tile(m0, n0);
+            XLP_PROLOGUE()
+        }
+
+        // ---- epilogue of tile (cm0, cn0): registers -> global ----
+        {
+            const int No = GEGLU ? p.N / 2 : p.N;
+            const int ocol0 = (GEGLU ? cn0 / 2 + wn * 32 : cn0 + wn * 64) + 8 * fq;     // first of this lane's 8 (+ 8 at +32) output columns
+            const int rowb = cm0 + wm * (TI * 16) + fr;                                  // row of MFMA tile i = rowb + 16 i
+            const bool interior = cm0 + BM <= p.M && cn0 + BN <= p.N;                   // wave-uniform
+            bf16_t* cg = (bf16_t*)p.C + (long)rowb * p.ldc + ocol0;
+            const bf16_t* rg = HAS_R ? (const bf16_t*)p.R + (long)min(rowb, p.M - 1) * p.ldr + min(ocol0, No - 8) : nullptr;
+            constexpr int NCH = GEGLU ? 1 : 2;                                            // 16-byte chunks per lane per row tile
+            uint4 rres[HAS_R ? TI : 1][NCH];
+            if (HAS_R) {                                                                   // one batch, clamped rows (edge tiles), unconditional
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    const long ro = (long)(min(rowb + 16 * i, p.M - 1) - min(rowb, p.M - 1)) * p.ldr;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) rres[HAS_R ? i : 0][c] = *(const uint4*)(rg + ro + (c && ocol0 + 32 + 8 <= No ? 32 : 0));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                unsigned tx[TJ], ty[TJ];                                                  // packed pairs of MFMA tile j: columns 4 fq + {0,1} / {2,3}
+#pragma unroll
+                for (int j = 0; j < (GEGLU ? 2 : TJ); ++j) {
+                    const float bb[4] = {bq[j].x, bq[j].y, bq[j].z, bq[j].w};
+                    float o[4];
+                    if (GEGLU) {
+                        const float gg[4] = {bq[j + 2].x, bq[j + 2].y, bq[j + 2].z, bq[j + 2].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (acc[i][j][e] + bb[e]) * gelu_erf_f(acc[i][j + 2][e] + gg[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = acc[i][j][e] + bb[e];
+                    }
+                    tx[j] = pack2bf(o[0], o[1]); ty[j] = pack2bf(o[2], o[3]);
+                }
+                // 4 x 4 transpose of 8-byte items between the four 16-lane rows (fq) of the wave: lane fq ends up with columns
+                // 8 fq .. 8 fq + 7 of tiles (0, 1) [chunk 0] and of tiles (2, 3) [chunk 1, +32 columns]
+                uint4 ch[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    unsigned ax = tx[2 * c], ay = ty[2 * c], bx = tx[2 * c + 1], by = ty[2 * c + 1];
+                    { auto r_ = __builtin_amdgcn_permlane32_swap(ax, bx, false, false); ax = r_[0]; bx = r_[1]; }
+                    { auto r_ = __builtin_amdgcn_permlane32_swap(ay, by, false, false); ay = r_[0]; by = r_[1]; }
+                    { auto r_ = __builtin_amdgcn_permlane16_swap(ax, bx, false, false); ax = r_[0]; bx = r_[1]; }
+                    { auto r_ = __builtin_amdgcn_permlane16_swap(ay, by, false, false); ay = r_[0]; by = r_[1]; }
+                    ch[c] = make_uint4(ax, ay, bx, by);
+                    if (HAS_R) {
+                        const uint4 r4 = rres[HAS_R ? i : 0][c];
+                        ch[c].x = add2bf(ch[c].x, r4.x); ch[c].y = add2bf(ch[c].y, r4.y); ch[c].z = add2bf(ch[c].z, r4.z); ch[c].w = add2bf(ch[c].w, r4.w);
+                    }
+                }
+                bf16_t* crow = cg + (long)(16 * i) * p.ldc;
+                if (interior) {                                                           // every lane stores: the instruction count is exact
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) *(uint4*)(crow + 32 * c) = ch[c];
+                } else if (rowb + 16 * i < p.M) {
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c)
+                        if (ocol0 + 32 * c + 8 <= No) *(uint4*)(crow + 32 * c) = ch[c];
+                }
+            }
+            counted = interior;
+        }
+        if (!has_next) break;
+        bid = nb;
+        first = false;
+        load_bias(n0);
+    }
+#undef XLP_PIECE_A
+#undef XLP_PIECE_B
+#undef XLP_ISSUE_A
+#undef XLP_ISSUE_B
+#undef XLP_PROLOGUE
+#undef XLP_READ_A
+#undef XLP_READ_B
+#undef XLP_MMA
+#undef XLP_SEG_END
+#undef XLP_MMA_END
+}
+
 // LDS: operand ring (2 slabs) or the bf16 C tile, whichever is larger, + the addend rows
 template <int BN>
 constexpr size_t xl_smem_bytes() {
@@ -863,6 +1097,30 @@ static int launch_xl(const GCParams& p, hipStream_t st) {
     const unsigned nblk_t = q.swz == 2 ? nblk_raster : q.swz ? (unsigned)((q.mt + 7) / 8 * 8 * q.nt) : (unsigned)(q.mt * q.nt);
     q.timing = (timing && p.ws && (long)nblk_t * 64 <= p.ws_bytes) ? (unsigned long long*)p.ws : nullptr;
     const unsigned nblk = nblk_t;
+    q.nblk = (int)nblk;
+    if constexpr (BN == 256 && !CONV && SCHED == 0) {
+        // persistent form (gemm_xlp_kernel): one workgroup per CU walks the tile order, the next tile's first slabs land while this one
+        // is stored.  Plain / GEGLU epilogue, optional residual, 16-byte C rows, enough tiles for the walk to matter.
+        static const int cus = [] { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
+        if (opt(OPT_XL_PERSIST) && q.wide && !q.col_split && !q.temb && (q.epi == 0 || q.epi == 1) && !q.timing && nblk >= 2u * (unsigned)cus &&
+            (long)q.M * q.lda * 2 > 0 && q.bias != (const float*)q.C) {
+            const bool geglu = q.epi == 1, has_r = q.R != nullptr;
+            if (geglu && has_r) goto not_persistent;
+            {
+                auto launch_p = [&](auto kp) -> int {
+                    if (int rc = ensure_dyn_smem((const void*)kp, smem, "xlp")) return rc;
+                    hipLaunchKernelGGL(kp, dim3((unsigned)cus), dim3(512), smem, st, q);
+                    char tag[96];
+                    snprintf(tag, sizeof tag, "gemm_xlp_kernel<256x256,%s%s>", geglu ? "geglu" : "gemm", has_r ? "+res" : "");
+                    return check_launch(tag);
+                };
+                if (geglu) return launch_p(gemm_xlp_kernel<true, false>);
+                if (has_r) return launch_p(gemm_xlp_kernel<false, true>);
+                return launch_p(gemm_xlp_kernel<false, false>);
+            }
+        }
+    not_persistent:;
+    }
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), smem, st, q);
     char tag[96];
     snprintf(tag, sizeof tag, "gemm_xl_kernel<256x%d,%s>", BN, CONV ? "conv" : "gemm");   // (the schedule is a tuning knob, not part of the name)

@@ -47,9 +47,11 @@ def test_fp16_gemm_conv_norm_kernels(dev):
         TK.test_gemm(dev, 2100, 640, 2560, True, False, False)          # generic tile
         TK.test_gemm(dev, 168, 1280, 5120, True, True, False)           # split-K
         TK.test_gemm(dev, 777, 96, 136, True, False, False)             # ragged
-        TR.test_xl_gemm(dev, 41037, 1280, 1280, True, True, False, 0, "gemm_xl_kernel<256x")
-        TR.test_xl_gemm(dev, 82000, 320, 1280, True, True, True, 0, "gemm_xl_kernel<256x")
-        TR.test_xl_gemm_geglu(dev)
+        for persist in (1, 0):
+            TR.test_xl_gemm(dev, 41037, 1280, 1280, True, True, False, 0, "gemm_xl_kernel<256x", persist)
+            TR.test_xl_gemm_geglu(dev, persist)
+        TR.test_xl_gemm(dev, 82000, 320, 1280, True, True, True, 0, "gemm_xl_kernel<256x", 1)
+        TR.test_persistent_xl_gemm_bench_shapes(dev, 131072 + 77, 768, 192, True)
         TR.test_xl_gemm_temb_rows(dev)
         TR.test_xl_conv(dev, 48, 28, 50, 320, 320, (1, 1), True, True, "gemm_xl_kernel<256x")
         TR.test_xl_conv(dev, 480, 7, 13, 1280, 1280, (1, 1), True, True, "gemm_xl_kernel<256x")

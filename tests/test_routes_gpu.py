@@ -51,7 +51,15 @@ def run_one(op):
     (40960, 512, 128, False, True, False, 0, "gemm_xl_kernel<256x"),       # two slabs
     (40960, 512, 192, True, True, False, 0, "gemm_xl_kernel<256x"),        # three slabs (odd count: both ring buffers end mid-cycle)
 ])
-def test_xl_gemm(dev, M, N, K, bias, res, inplace, epi, expect):
+@pytest.mark.parametrize("persist", [1, 0])
+def test_xl_gemm(dev, M, N, K, bias, res, inplace, epi, expect, persist):
+    """persist: XL_PERSIST — the persistent 256 x 256 kernel (gemm_xlp_kernel) takes the plain-epilogue shapes with >= 512 tiles and
+    16-byte C rows; with the option off every shape runs gemm_xl_kernel."""
+    with L.options(XL_PERSIST=persist):
+        _xl_gemm(dev, M, N, K, bias, res, inplace, epi, expect, persist)
+
+
+def _xl_gemm(dev, M, N, K, bias, res, inplace, epi, expect, persist):
     A = rnd(M, K, seed=1); W = rnd(N, K, scale=K ** -0.5, seed=2)
     b = rnd(N, seed=3, dtype=torch.float32) if bias else None
     Cbig = torch.full((M, N + 24), float("nan"), dtype=BF, device=dev)
@@ -64,7 +72,15 @@ def test_xl_gemm(dev, M, N, K, bias, res, inplace, epi, expect):
         else:
             R = R0
     k = run_one(O.Gemm(A, W, C, bias=b, R=R, epilogue=epi, ws=ws_buf()))
-    assert k.startswith(expect) and k.endswith(",gemm>"), f"routed to {k!r}, expected {expect!r}"
+    if expect.startswith("gemm_xl_kernel") and persist:
+        # the persistent kernel must take exactly the shapes it is built for (256-wide choice, wide rows, >= 512 tiles)
+        tiles256 = ((M + 255) // 256) * ((N + 255) // 256)
+        if k.startswith("gemm_xlp_kernel"):
+            assert N % 8 == 0 and tiles256 >= 512 and k == f"gemm_xlp_kernel<256x256,gemm{'+res' if res else ''}>", k
+        else:
+            assert k.startswith(expect) and k.endswith(",gemm>"), f"routed to {k!r}, expected {expect!r}"
+    else:
+        assert k.startswith(expect) and k.endswith(",gemm>"), f"routed to {k!r}, expected {expect!r}"
     ref = A.float() @ W.float().T
     if bias: ref += b
     if epi == 2: ref = F.silu(ref)
@@ -74,14 +90,20 @@ def test_xl_gemm(dev, M, N, K, bias, res, inplace, epi, expect):
     assert torch.isnan(Cbig[:, :lo].float()).all() and torch.isnan(Cbig[:, lo + N:].float()).all(), "wrote outside the C view"
 
 
-def test_xl_gemm_geglu(dev):
+@pytest.mark.parametrize("persist", [1, 0])
+def test_xl_gemm_geglu(dev, persist):
     """Packed GEGLU at the bench shape of level 1 (N = 8C = 5120, K = 640): value / gate tiles meet in one lane."""
+    with L.options(XL_PERSIST=persist):
+        _xl_gemm_geglu(dev, persist)
+
+
+def _xl_gemm_geglu(dev, persist):
     M, F_, K = 40960 + 100, 2560, 640
     A = rnd(M, K, seed=1); W = rnd(2 * F_, K, scale=K ** -0.5, seed=2, dtype=torch.float32); b = rnd(2 * F_, seed=3, dtype=torch.float32)
     Wp, bp = PK.pack_geglu(W.cpu(), b.cpu(), BF)
     C = torch.zeros(M, F_, dtype=BF, device=dev)
     k = run_one(O.Gemm(A, Wp.to(dev), C, bias=bp.to(dev), epilogue=L.EPI_GEGLU, ws=ws_buf()))
-    assert k == "gemm_xl_kernel<256x256,gemm>", k
+    assert k == ("gemm_xlp_kernel<256x256,geglu>" if persist else "gemm_xl_kernel<256x256,gemm>"), k
     h, g = (A.float() @ W.to(BF).float().T + b).chunk(2, dim=-1)
     close(C, h * F.gelu(g), name="xl geglu")
 
@@ -242,7 +264,7 @@ def test_forced_no_xl(dev):
 
 def test_forced_geglu320_on_xl(dev):
     with L.options(XL_GEGLU320=1):
-        assert geglu_case(26400, 1280, 320) == "gemm_xl_kernel<256x256,gemm>"
+        assert geglu_case(26400, 1280, 320) in ("gemm_xl_kernel<256x256,gemm>", "gemm_xlp_kernel<256x256,geglu>")
 
 
 @pytest.mark.parametrize("mode,opts", [("attn_q32", {"ATTN2_QT": 1}), ("attn_d80", {"ATTN2_D80": 1}), ("attn_old", {"ATTN2": 0}), ("attn_nofold", {"ATTN2_FOLD": 0})])
@@ -257,6 +279,33 @@ def test_forced_attention_routes(dev, mode, opts):
             T.test_attention2_softmax_rescale_branch(dev, pre)
             for case in [(1, 8, 1400, 40), (3, 8, 350, 80), (2, 8, 700, 40)]:
                 T.test_attention2_crossview(dev, *case, pre)
+
+
+@pytest.mark.parametrize("M,N,K,res", [
+    (268800, 640, 640, True),        # C x C + residual at level 1, the bench row count: 1050 x 3 tiles, the last N-tile half empty
+    (268800, 1280, 640, False),      # q|k projection at level 1
+    (69888, 1280, 1280, True),       # level 2
+    (131072 + 77, 768, 192, True),   # ragged M (the last tile of some walks is an edge tile: conservative wait), 3 slabs, 3 N-tiles
+    (140000, 512, 64, False),        # ONE slab per tile: the ring is refilled for the next tile while this one is stored
+    (140000, 512, 128, True),        # two slabs
+])
+def test_persistent_xl_gemm_bench_shapes(dev, M, N, K, res):
+    """gemm_xlp_kernel at the bench batch's shapes and at the corners of its tile walk (K of one / two / three slabs, ragged last
+    M-tile, half-empty last N-tile, in-place residual), vs torch; and bit-identical to the non-persistent kernel (same reduction order,
+    same epilogue arithmetic)."""
+    A = rnd(M, K, seed=1); W = rnd(N, K, scale=K ** -0.5, seed=2); b = rnd(N, seed=3, dtype=torch.float32)
+    R = rnd(M, N, seed=4) if res else None
+    outs = {}
+    for persist in (1, 0):
+        C = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+        with L.options(XL_PERSIST=persist):
+            k = run_one(O.Gemm(A, W, C, bias=b, R=R, ws=ws_buf()))
+        assert k.startswith("gemm_xlp_kernel<256x256" if persist else "gemm_xl_kernel<256x256"), (persist, k)
+        outs[persist] = C
+    ref = A.float() @ W.float().T + b
+    if res: ref += R.float()
+    close(outs[1], ref, name=f"persistent xl gemm {M}x{N}x{K}")
+    assert torch.equal(outs[1], outs[0]), "persistent and per-tile kernels must agree bit for bit"
 
 
 def test_set_option_rejects_unknown_key():

@@ -30,6 +30,9 @@ def match(kname, case_kernel):
     if base == "gemm_xl_kernel":
         bn = tag.split("x")[1].split(",")[0]; conv = "conv" in tag
         return f"<{bn}, {'true' if conv else 'false'}" in kname.replace("(int)", "").replace("Li", "") or f"{bn}, {'true' if conv else 'false'}" in kname
+    if base == "gemm_xlp_kernel":                   # gemm_xlp_kernel<GEGLU, HAS_R>
+        args = kname.split("gemm_xlp_kernel<")[1].split(">")[0].replace(" ", "").split(",")
+        return (args[0] == "true") == ("geglu" in tag) and (args[1] == "true") == ("+res" in tag)
     if base == "attn_kernel":
         return ("true" in kname.split("attn_kernel")[1]) == ("xview" in tag)
     if base == "attn2_kernel":                      # attn2_kernel<D8, TWO, QT, FOLD>: second argument = the two-neighbour (cross-view) form
@@ -112,13 +115,20 @@ for name, c in cases["cases"].items():
                 row[k.lower() + "_frac"] = round(cs[k] / cs["SQ_WAVE_CYCLES"], 4)
     row["raw"] = {k: round(v, 1) for k, v in sorted(cs.items())}
     summary["cases"][name] = row
-    if "traffic_bytes" in row:          # what bench.py's roofline.traffic reports for this kernel (largest case wins)
+    if "traffic_bytes" in row:          # what bench.py's roofline.traffic / per_kernel report for this kernel: every profiled case is kept
+        # (bench.py picks the case whose duration is closest to the kernel's average launch in the timed run); top level = largest case
         k = summary["kernels"].get(c["kernel"])
+        entry = dict(case=name, views=cases["views"], gflop=row["gflop"], bytes=row["traffic_bytes"], fetch_bytes=row["fetch_bytes"],
+                     write_bytes=row["write_bytes"], algorithmic_bytes=c["alg_read_bytes"] + c["alg_write_bytes"],
+                     traffic_over_algorithmic=row.get("traffic_over_algorithmic"), l2_hit_rate=row.get("l2_hit_rate"), mfma_util=row.get("mfma_util"),
+                     hbm_gbps=row.get("hbm_gbps"), effective_clock_ghz=row.get("effective_clock_ghz"), avg_us_profiled=row.get("avg_us_profiled"))
+        prev_cases = (k or {}).get("cases", [])
         if k is None or row["gflop"] > k["gflop"]:
             summary["kernels"][c["kernel"]] = dict(case=name, views=cases["views"], gflop=row["gflop"], bytes=row["traffic_bytes"], fetch_bytes=row["fetch_bytes"],
                                                    write_bytes=row["write_bytes"], algorithmic_bytes=c["alg_read_bytes"] + c["alg_write_bytes"],
                                                    l2_hit_rate=row.get("l2_hit_rate"), mfma_util=row.get("mfma_util"), hbm_gbps=row.get("hbm_gbps"),
                                                    effective_clock_ghz=row.get("effective_clock_ghz"), avg_us_profiled=row.get("avg_us_profiled"))
+        summary["kernels"][c["kernel"]]["cases"] = prev_cases + [entry]
 with open(out_path, "w") as f:
     json.dump(summary, f, indent=1)
 for name, row in summary["cases"].items():
