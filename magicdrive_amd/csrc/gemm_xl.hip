@@ -990,15 +990,31 @@ __global__ __launch_bounds__(512, 2) void gemm_xlp_kernel(GCParams p) {
             const int rowb = cm0 + wm * (TI * 16) + fr;                                  // row of MFMA tile i = rowb + 16 i
             const bool interior = cm0 + BM <= p.M && cn0 + BN <= p.N;                   // wave-uniform
             bf16_t* cg = (bf16_t*)p.C + (long)rowb * p.ldc + ocol0;
-            const bf16_t* rg = HAS_R ? (const bf16_t*)p.R + (long)min(rowb, p.M - 1) * p.ldr + min(ocol0, No - 8) : nullptr;
             constexpr int NCH = GEGLU ? 1 : 2;                                            // 16-byte chunks per lane per row tile
+            // Store layout.  After the transpose lane (fr, fq) holds, for row tile i, chunk 0 = columns 8 fq .. +7 and (plain epilogue)
+            // chunk 1 = the same columns + 32 of row fr: storing them as they are writes 16 rows x 64 bytes per instruction — half cache
+            // lines, twice the requests of the LDS-staged epilogue's 512-byte row segments (measured: the prefetch's gain was eaten by the
+            // stores).  Instead chunk 1 is rotated by 8 lanes inside each 16-lane row (DPP row_ror:8) and the two instructions of a row
+            // tile cover rows 0-7 and rows 8-15 in FULL 128-byte lines: lanes fr < 8 carry chunk 0 of their row in A and the rotated
+            // chunk 1 (row fr + 8) in B; lanes fr >= 8 carry the rotated chunk 1 (row fr - 8) in A and chunk 0 of their row in B.
+            // GEGLU has one chunk (64 bytes per row and wave): stored as it is.
+            const bool lo8 = fr < 8;
+            const int rA = (fr & 7), rB = 8 + (fr & 7);                                   // row inside the 16-row tile of store A / B
+            const int cA = lo8 ? 0 : 32, cB = lo8 ? 32 : 0;                               // column offset of this lane's 16 bytes in store A / B
+            const int rowt = cm0 + wm * (TI * 16);                                        // first row of the wave's strip
+            bf16_t* cgA = (bf16_t*)p.C + (long)(rowt + rA) * p.ldc + ocol0 + cA;
+            bf16_t* cgB = (bf16_t*)p.C + (long)(rowt + rB) * p.ldc + ocol0 + cB;
             uint4 rres[HAS_R ? TI : 1][NCH];
             if (HAS_R) {                                                                   // one batch, clamped rows (edge tiles), unconditional
 #pragma unroll
                 for (int i = 0; i < TI; ++i) {
-                    const long ro = (long)(min(rowb + 16 * i, p.M - 1) - min(rowb, p.M - 1)) * p.ldr;
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) rres[HAS_R ? i : 0][c] = *(const uint4*)(rg + ro + (c && ocol0 + 32 + 8 <= No ? 32 : 0));
+                    if (GEGLU) {
+                        rres[HAS_R ? i : 0][0] = *(const uint4*)((const bf16_t*)p.R + (long)min(rowb + 16 * i, p.M - 1) * p.ldr + min(ocol0, No - 8));
+                    } else {
+                        const int ra = min(rowt + 16 * i + rA, p.M - 1), rb = min(rowt + 16 * i + rB, p.M - 1);
+                        rres[HAS_R ? i : 0][0] = *(const uint4*)((const bf16_t*)p.R + (long)ra * p.ldr + min(ocol0 + cA, No - 8));
+                        rres[HAS_R ? i : 0][NCH - 1] = *(const uint4*)((const bf16_t*)p.R + (long)rb * p.ldr + min(ocol0 + cB, No - 8));
+                    }
                 }
             }
 #pragma unroll
@@ -1029,19 +1045,38 @@ __global__ __launch_bounds__(512, 2) void gemm_xlp_kernel(GCParams p) {
                     { auto r_ = __builtin_amdgcn_permlane16_swap(ax, bx, false, false); ax = r_[0]; bx = r_[1]; }
                     { auto r_ = __builtin_amdgcn_permlane16_swap(ay, by, false, false); ay = r_[0]; by = r_[1]; }
                     ch[c] = make_uint4(ax, ay, bx, by);
-                    if (HAS_R) {
-                        const uint4 r4 = rres[HAS_R ? i : 0][c];
-                        ch[c].x = add2bf(ch[c].x, r4.x); ch[c].y = add2bf(ch[c].y, r4.y); ch[c].z = add2bf(ch[c].z, r4.z); ch[c].w = add2bf(ch[c].w, r4.w);
-                    }
                 }
-                bf16_t* crow = cg + (long)(16 * i) * p.ldc;
-                if (interior) {                                                           // every lane stores: the instruction count is exact
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) *(uint4*)(crow + 32 * c) = ch[c];
-                } else if (rowb + 16 * i < p.M) {
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c)
-                        if (ocol0 + 32 * c + 8 <= No) *(uint4*)(crow + 32 * c) = ch[c];
+                if (GEGLU) {
+                    if (HAS_R) {
+                        const uint4 r4 = rres[HAS_R ? i : 0][0];
+                        ch[0].x = add2bf(ch[0].x, r4.x); ch[0].y = add2bf(ch[0].y, r4.y); ch[0].z = add2bf(ch[0].z, r4.z); ch[0].w = add2bf(ch[0].w, r4.w);
+                    }
+                    bf16_t* crow = cg + (long)(16 * i) * p.ldc;
+                    if (interior) *(uint4*)crow = ch[0];
+                    else if (rowb + 16 * i < p.M && ocol0 + 8 <= No) *(uint4*)crow = ch[0];
+                } else {
+                    // rotate chunk 1 by 8 lanes inside each row of 16 (DPP row_ror:8 = 0x128), then pick the store layout
+                    uint4 rot;
+                    rot.x = (unsigned)__builtin_amdgcn_mov_dpp((int)ch[NCH - 1].x, 0x128, 0xf, 0xf, false);
+                    rot.y = (unsigned)__builtin_amdgcn_mov_dpp((int)ch[NCH - 1].y, 0x128, 0xf, 0xf, false);
+                    rot.z = (unsigned)__builtin_amdgcn_mov_dpp((int)ch[NCH - 1].z, 0x128, 0xf, 0xf, false);
+                    rot.w = (unsigned)__builtin_amdgcn_mov_dpp((int)ch[NCH - 1].w, 0x128, 0xf, 0xf, false);
+                    uint4 vA, vB;
+                    vA.x = lo8 ? ch[0].x : rot.x; vA.y = lo8 ? ch[0].y : rot.y; vA.z = lo8 ? ch[0].z : rot.z; vA.w = lo8 ? ch[0].w : rot.w;
+                    vB.x = lo8 ? rot.x : ch[0].x; vB.y = lo8 ? rot.y : ch[0].y; vB.z = lo8 ? rot.z : ch[0].z; vB.w = lo8 ? rot.w : ch[0].w;
+                    if (HAS_R) {
+                        const uint4 r0 = rres[HAS_R ? i : 0][0], r1 = rres[HAS_R ? i : 0][NCH - 1];
+                        vA.x = add2bf(vA.x, r0.x); vA.y = add2bf(vA.y, r0.y); vA.z = add2bf(vA.z, r0.z); vA.w = add2bf(vA.w, r0.w);
+                        vB.x = add2bf(vB.x, r1.x); vB.y = add2bf(vB.y, r1.y); vB.z = add2bf(vB.z, r1.z); vB.w = add2bf(vB.w, r1.w);
+                    }
+                    bf16_t* pa = cgA + (long)(16 * i) * p.ldc;
+                    bf16_t* pb = cgB + (long)(16 * i) * p.ldc;
+                    if (interior) {                                                       // every lane stores: the instruction count is exact
+                        *(uint4*)pa = vA; *(uint4*)pb = vB;
+                    } else {
+                        if (rowt + 16 * i + rA < p.M && ocol0 + cA + 8 <= No) *(uint4*)pa = vA;
+                        if (rowt + 16 * i + rB < p.M && ocol0 + cB + 8 <= No) *(uint4*)pb = vB;
+                    }
                 }
             }
             counted = interior;

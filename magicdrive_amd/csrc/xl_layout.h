@@ -90,19 +90,24 @@ XL_HD int frag_off(int row0, int lane, int kk) {
 // gm consecutive M-tiles x gn consecutive N-tiles.  An XCD walks the N-groups of one M-group back to back (its A panels stay in that
 // L2), then takes its next M-group (M-group g belongs to XCD g % 8).  Blocks whose tile falls outside the ragged edge exit.
 XL_HD void raster_shape(int mt, int nt, int* gm, int* gn) {
-    // gm x gn ~ 32 (the workgroups an XCD runs side by side).  Per round of tiles that XCD's L2 takes in gm A-panels + gn W-panels, so
-    // the squarest shape that divides nt well wins — subject to >= 64 M-groups (8 per XCD: groups are dealt out whole, and with few of
-    // them the XCD that draws one more runs an extra round).  Narrow problems (nt <= 5) take all their N-tiles in one group.
-    int n = nt <= 5 ? nt : 4;
-    int m = 32 / n;
-    if (nt > 5) {
-        // wide problems: trade M-tiles for N-tiles until there are enough M-groups (N = 10240 at the 7x13 level: 273 M-tiles -> 4 x 8)
-        while (m > 1 && (mt + m - 1) / m < 64) { m >>= 1; n <<= 1; }
-        if (n > nt) n = nt;
+    // gm x gn ~ 32 (the workgroups an XCD runs side by side).  Per tile that XCD's L2 takes in (gm + gn) / (gm gn) operand panels, so
+    // the squarest shape wins — weighed against the padding blocks of a ragged grid (they are cheap for the per-tile kernel but
+    // unbalance the persistent one: a workgroup that draws padding idles while its XCD neighbours multiply) and against having
+    // fewer than 64 M-groups (8 per XCD: groups are dealt out whole; with few of them the XCD that draws one more runs an extra round).
+    // Narrow problems (nt <= 5) take all their N-tiles in one group.
+    int bm = 1, bn = nt <= 5 ? nt : 1;
+    double best = 1e30;
+    for (int n = (nt <= 5 ? nt : 2); n <= (nt <= 5 ? nt : (nt < 32 ? nt : 32)); ++n) {
+        int m = 32 / n;
+        if (m > mt / 16) m = mt / 16;                          // short problems: at least two M-groups per XCD
+        if (m < 1) m = 1;
+        const int gmn = (mt + m - 1) / m, gnn = (nt + n - 1) / n;
+        const double pad = (double)gmn * m * gnn * n / ((double)mt * nt);
+        double cost = (double)(m + n) / (double)(m * n) * pad * pad;
+        if (gmn < 64) cost *= 1.5;
+        if (cost < best) { best = cost; bm = m; bn = n; }
     }
-    if (m > mt / 16) m = mt / 16;                              // short problems: at least two M-groups per XCD
-    if (m < 1) m = 1;
-    *gm = m; *gn = n;
+    *gm = bm; *gn = bn;
 }
 XL_HD long raster_blocks(int mt, int nt, int gm, int gn) {
     const int ngm = (mt + gm - 1) / gm, ngn = (nt + gn - 1) / gn;

@@ -207,7 +207,7 @@ def gemm_case(M, N, K, bias=True, res=False, epi=0, expect=None):
     if epi == 2: ref = F.silu(ref)
     if res: ref += R.float()
     close(C, ref, name=f"gemm {M}x{N}x{K} ({k})")
-    assert expect is None or k.startswith(expect), (k, expect)
+    assert expect is None or k.startswith(expect), (k, expect)      # (str.startswith takes a tuple of alternatives)
     return k
 
 
@@ -230,12 +230,12 @@ def conv_case(B, H, W, Cin, Cout, stride=(1, 1), res=True, temb=True, expect=Non
 def test_forced_xl_widths(dev, bn, raster):
     with L.options(GEMM_XL=2, XL_BN=bn, XL_RASTER=raster):
         g, c = f"gemm_xl_kernel<256x{bn},gemm>", f"gemm_xl_kernel<256x{bn},conv>"
-        gemm_case(2000, 640, 640, res=True, expect=g)                 # ragged M (7.8 tiles), N = 2-4 tiles
+        gemm_case(2000, 640, 640, res=True, expect=g)                 # ragged M (7.8 tiles), N = 2-4 tiles (too few tiles for the persistent walk)
         gemm_case(777, 324, 128, bias=False, expect=g)                # N % 8 != 0: narrow stores; ragged everything; two slabs
         gemm_case(5000, 320, 64, expect=g)                            # one slab
         gemm_case(5000, 320, 64, epi=2, expect="gemm_conv_kernel<")   # SiLU epilogues stay off the XL kernel even when it is forced
         gemm_case(3000, 1280, 960, res=True, expect=g)                # 15 slabs (K < 1024: no automatic split-K)
-        gemm_case(30000, 1600, 128, res=True, expect=g)               # 118 M-tiles x 5-10 N-tiles: several XCD panels, ragged last N-group
+        gemm_case(30000, 1600, 128, res=True, expect=(g, "gemm_xlp_kernel<256x256") if bn == 256 else g)   # 118 M-tiles x 5-10 N-tiles: several XCD panels, ragged last N-group
         conv_case(6, 28, 50, 320, 320, expect=c)                      # level-0 resnet conv
         conv_case(12, 14, 25, 128, 640, res=False, expect=c)          # 350-px images, 2 channel blocks
         conv_case(40, 7, 13, 64, 320, temb=True, expect=c)            # 91-px images: temb slots

@@ -106,7 +106,7 @@ static int check() {
 // gm M-tiles x gn N-tiles of ONE panel or the tail of one and the head of the next; M-tiles of a panel are contiguous.
 static int check_raster() {
     int errors = 0;
-    const int shapes[][2] = {{64, 1}, {64, 2}, {65, 3}, {84, 5}, {273, 5}, {1050, 20}, {1050, 3}, {4200, 2}, {333, 7}, {100, 40}, {71, 4}, {4200, 1}};
+    const int shapes[][2] = {{64, 1}, {64, 2}, {65, 3}, {84, 5}, {273, 5}, {1050, 20}, {1050, 3}, {4200, 2}, {333, 7}, {100, 40}, {71, 4}, {4200, 1}, {273, 10}, {273, 40}, {1050, 5}};
     for (auto& sh : shapes) {
         const int mt = sh[0], nt = sh[1];
         int gm, gn;
