@@ -42,7 +42,7 @@ extern "C" {
 #define MDX_ELAUNCH (-2)     /* hip launch / runtime error */
 #define MDX_EUNSUPPORTED (-3)
 
-#define MDX_ABI_VERSION 6
+#define MDX_ABI_VERSION 7
 
 /* ---- epilogue flags shared by GEMM / conv ------------------------------- */
 #define MDX_EPI_NONE 0
@@ -83,6 +83,18 @@ typedef struct MdxGemmDesc {
      * it is implemented by the weight-stationary kernel only; anything else is rejected with MDX_EINVAL.  Vt = NULL: off. */
     void* Vt;
     int64_t vt_from, vt_T, vt_ld, vt_stride;
+    /* Optional LayerNorm of the A rows, fused into the projection that consumes them (BasicTransformerBlock: norm1 -> attn1.to_q/k/v,
+     * norm2 -> attn2.to_q, attention.py:85-120; BasicMultiviewTransformerBlock norm4 -> attn4, blocks.py:190-205).  ln_eps > 0: A holds
+     * the RAW rows (K = the whole row); the caller has folded the affine part into the operands,
+     *     W' = W diag(gamma),  bias' = bias + W beta,  ln_csum[n] = sum_k W'[n][k]   (sum of the 16-bit W' values, fp32),
+     * and the result is  C[m][n] = rstd_m (sum_k A[m][k] W'[n][k] - mean_m ln_csum[n]) + bias'[n]  (+ R) with mean / rstd of row m over K
+     * (biased variance, as torch.nn.LayerNorm).  The K = 320 weight-stationary kernel takes the statistics from the rows it streams
+     * (the tokens are read once; no normalised copy exists); every other route first writes (A - mean) rstd to ln_scratch ([M][lda]
+     * 16-bit, 16-byte aligned) and multiplies that — same weights, same result up to the rounding of the normalised copy.
+     * The fused route takes a plain epilogue (optionally Vt); one batch, no split-K.  ln_eps = 0: off. */
+    double ln_eps;
+    const float* ln_csum;
+    void* ln_scratch;
 } MdxGemmDesc;
 int mdx_gemm_bf16(const MdxGemmDesc* d, void* stream);
 

@@ -31,6 +31,8 @@ int launch_conv3x3(const GCParams& p, hipStream_t st);                          
 bool conv3x3_supported(const GCParams& p);
 int launch_gemm_ws(const GCParams& p, hipStream_t st);                          // gemm_ws.hip: weight-stationary K = 320 GEMM
 bool ws_supported(const GCParams& p);
+bool ws_fuses_layernorm(const GCParams& p);
+int launch_layernorm_plain(const bf16_t* X, bf16_t* Y, int M, int C, long ldx, long ldy, float eps, hipStream_t st);   // norm.hip
 int launch_gemm_xl(const GCParams& p, bool conv, int bn, hipStream_t st);       // gemm_xl.hip: 256 x {256,160} LDS-DMA quadrant-phase tiles
 bool xl_supported(const GCParams& p, bool conv, int bn);
 
@@ -380,6 +382,24 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
         }
         return bn_out != 0;
     };
+    // K = 320 GEGLU with many rows: gemm_ws.hip (384 views: 1642 us) vs the 256 x 256 XL tile (1694-1757 us).  Before the ring of
+    // gemm_ws.hip really ran ahead (its DMA builtin drained the VM counter every slab: 1994 us) the XL tile was the faster one;
+    // MDX_XL_GEGLU320=1 selects it again.
+    const int xl_geglu320 = (int)opt(OPT_XL_GEGLU320);
+    const bool geglu_xl = xl_geglu320 && xl_mode == 1 && impl == 0 && !conv && geglu && p.K == 320 && p.splitk <= 1 && ws_mode < 2 &&
+                          xl_supported(p, false, 256) && (long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 1024;
+    const bool ws_first = !conv && ws_mode > 0 && p.splitk <= 1 && ws_supported(p) && (ws_mode >= 2 || p.M >= 8192);
+    const bool ws_taken = impl == 0 && !geglu_xl && ws_first && !(xl_k320 && xl_mode > 0);
+    if (p.ln_eps > 0.f) {
+        // LayerNorm fused into this GEMM (MdxGemmDesc.ln_eps): the weight-stationary kernel normalises in-kernel; every other route gets
+        // the rows normalised (no affine part: it is in W / bias) into the caller's scratch first.
+        if (conv || p.batch > 1) return set_error(MDX_EINVAL, "fused LayerNorm: plain 2-D GEMM only");
+        if (!(ws_taken && ws_fuses_layernorm(p) && opt(OPT_LN_FUSE))) {
+            if (!p.ln_scratch) return set_error(MDX_EINVAL, "fused LayerNorm: this shape is not normalised in-kernel and no ln_scratch was given");
+            if (int rc = launch_layernorm_plain(p.A, p.ln_scratch, p.M, p.K, p.lda, p.lda, p.ln_eps, st)) return rc;
+            p.A = p.ln_scratch; p.ln_eps = 0.f; p.ln_csum = nullptr;
+        }
+    }
     if (xl_mode >= 2 && p.splitk <= 1 && p.batch <= 1 && !(p.K == 320 && !conv && !xl_k320)) {
         // "whenever supported" (tests / benchmarking): ahead of the automatic split-K below, which would otherwise claim small grids
         GCParams q = p;
@@ -391,16 +411,8 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
         p.splitk = keep;
         if (ok) return launch_gemm_xl(q, conv, bn_f, st);
     }
-    // K = 320 GEGLU with many rows: gemm_ws.hip (384 views: 1642 us) vs the 256 x 256 XL tile (1694-1757 us).  Before the ring of
-    // gemm_ws.hip really ran ahead (its DMA builtin drained the VM counter every slab: 1994 us) the XL tile was the faster one;
-    // MDX_XL_GEGLU320=1 selects it again.
-    const int xl_geglu320 = (int)opt(OPT_XL_GEGLU320);
-    const bool geglu_xl = xl_geglu320 && xl_mode == 1 && impl == 0 && !conv && geglu && p.K == 320 && p.splitk <= 1 && ws_mode < 2 &&
-                          xl_supported(p, false, 256) && (long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 1024;
     if (geglu_xl) return launch_gemm_xl(p, false, 256, st);
-    const bool ws_first = !conv && ws_mode > 0 && p.splitk <= 1 && ws_supported(p) && (ws_mode >= 2 || p.M >= 8192);
-    if (impl == 0 && ws_first && !(xl_k320 && xl_mode > 0))
-        return launch_gemm_ws(p, st);
+    if (ws_taken) return launch_gemm_ws(p, st);
     int BM, BN;
     {
         BN = 128;
@@ -518,11 +530,21 @@ extern "C" int mdx_gemm_bf16(const MdxGemmDesc* d, void* stream) {
     p.temb_sel_stride = d->temb_sel_stride; p.temb_b_stride = d->temb_b_stride;
     p.rows_per_b = d->rows_per_b > 0 ? (int)d->rows_per_b : 1;
     p.epi = (int)d->epilogue; p.splitk = (int)d->splitk; p.c_f32 = (int)d->c_is_f32; p.ws_bytes = d->ws_bytes;
+    if (d->ln_eps > 0.0) {   // LayerNorm of the A rows fused in: W / bias carry gamma / beta, ln_csum the row sums of W (see include/mdx.h)
+        if (!d->ln_csum || p.batch > 1 || d->splitk > 1 || d->c_is_f32 || d->temb || ((uintptr_t)d->ln_scratch & 15))
+            return set_error(MDX_EINVAL, "mdx_gemm_bf16: fused LayerNorm needs ln_csum, one batch, no split-K / fp32 C / temb, 16-byte aligned ln_scratch");
+        p.ln_eps = (float)d->ln_eps; p.ln_csum = d->ln_csum; p.ln_scratch = (bf16_t*)d->ln_scratch;
+    }
     if (d->Vt) {   // fused q/k/v projection with a transposed V output: weight-stationary kernel only
         p.Vt = (bf16_t*)d->Vt; p.vt_from = (int)d->vt_from; p.vt_T = (int)d->vt_T; p.vt_ld = d->vt_ld; p.vt_stride = d->vt_stride;
-        if (!ws_supported(p) || d->epilogue || d->bias || d->R || (d->vt_from % 128) || d->vt_from <= 0 || d->vt_from >= d->N || d->vt_T <= 0 ||
+        if (!ws_supported(p) || d->epilogue || d->R || (d->vt_from % 128) || d->vt_from <= 0 || d->vt_from >= d->N || d->vt_T <= 0 ||
             (d->vt_T % 8) || (d->M % d->vt_T) || (d->vt_ld % 8) || (d->vt_stride % 8) || ((uintptr_t)d->Vt & 15))
-            return set_error(MDX_EINVAL, "mdx_gemm_bf16: transposed V output needs K=320, plain epilogue, vt_from %% 128 == 0, vt_T %% 8 == 0, aligned Vt");
+            return set_error(MDX_EINVAL, "mdx_gemm_bf16: transposed V output needs K=320, plain epilogue, no residual, vt_from %% 128 == 0, vt_T %% 8 == 0, aligned Vt");
+        if (p.ln_eps > 0.f && !opt(OPT_LN_FUSE)) {            // A/B switch: normalised copy first, then the plain fused q/k/v launch pair
+            if (!p.ln_scratch) return set_error(MDX_EINVAL, "fused LayerNorm: LN_FUSE=0 needs ln_scratch");
+            if (int rc2 = launch_layernorm_plain(p.A, p.ln_scratch, p.M, p.K, p.lda, p.lda, p.ln_eps, (hipStream_t)stream)) return rc2;
+            p.A = p.ln_scratch; p.ln_eps = 0.f; p.ln_csum = nullptr;
+        }
         { GCParams q = p; const long nout = d->vt_from;      // wide-path check of the C part
           q.wide = (nout % 8) == 0 && (p.ldc % 8) == 0 && (((uintptr_t)p.C) & 15) == 0;
           return launch_gemm_ws(q, (hipStream_t)stream); }

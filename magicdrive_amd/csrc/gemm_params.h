@@ -34,6 +34,10 @@ struct GCParams {
     // output column n lands in batch n / col_split at column n % col_split: C + (n / col_split) * sC + m * ldc + n % col_split.
     // 0 = off.  Used for the level-1/2 V^T projections: V^T[b][c][t] = sum_k Wv[c][k] X[b][t][k] as ONE GEMM over all views.
     int col_split;
+    // LayerNorm of the A rows fused into the GEMM (MdxGemmDesc.ln_eps; K is the whole row): ln_eps > 0 -> A holds the RAW rows, W / bias carry
+    // the affine part, ln_csum[n] = sum_k W[n][k].  gemm_ws.hip computes the row statistics from the slabs it streams and applies
+    // C = rstd_m (acc - mean_m csum_n) + bias_n; every other route normalises into ln_scratch first (launch_gemm_conv).
+    const float* ln_csum; float ln_eps; bf16_t* ln_scratch;
     int dbg;                      // debug knobs of gemm_pp.hip (MDX_PP_DBG): 1 skip LDS stores, 2 skip global loads, 4 skip MFMAs
 };
 

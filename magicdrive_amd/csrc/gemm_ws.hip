@@ -60,8 +60,21 @@ __device__ __forceinline__ void ws_lds_barrier() {
 // XOR-swizzled by (row >> 1) & 7 on the SOURCE side and again on the fragment reads: conflict-free ds_read_b128.
 // VT: every tile of the launch is stored transposed to p.Vt (the V part of a fused q/k/v projection is its own launch over the
 // V rows of the weight: one kernel carrying both operand orders spilled 89 VGPRs).
-template <bool GEGLU, int ST, bool VT>
+// LN: LayerNorm of the A rows fused in (GCParams.ln_eps): K = 320 IS the whole row and every workgroup streams all of it through
+// LDS, so wave w sums x and x^2 of rows 32 w .. 32 w + 31 from the slabs as they land (one extra 16-byte LDS read per k-step, 24 VALU
+// operations beside 4 MFMAs), publishes (rstd, -mean rstd) per row in LDS at the end of the tile, and the epilogue turns the raw
+// product into rstd_m acc + (-mean_m rstd_m) csum_n + bias_n.  gamma / beta are in W / bias (packed by the host).  The tokens are
+// read ONCE (by this GEMM) instead of read + written by layernorm_kernel and read again here.  One-pass variance in fp32
+// (E[x^2] - mean^2 over 320 values of a 16-bit tensor).  Every N-tile's workgroup repeats the row sums, and they are NOT free: measured
+// (tools/lnone.py, 768 views, side builds -DMDX_WS_LN_ABLATE) the fused q/k/v launch pair is 150 us slower than the plain one (1200 us) —
+// 100 us the 96 VALU operations per slab (each costs its 4-cycle issue slot whether it sits in front of the slab's MFMAs or between
+// them), 15 us the extra fragment read, 35 us the epilogue — against the 240-400 us LayerNorm pass it replaces; to_q: +105 us.  For
+// the GEGLU (20 N-tiles, a VALU-heavy epilogue already) the same scheme cost +485 us per launch, more than the pass: not built
+// (the engine keeps layernorm_kernel in front of ff.net.0; profiles/README.md round 3).
+template <bool GEGLU, int ST, bool VT, bool LN>
 __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
+    static_assert(!(GEGLU && LN), "fused LayerNorm: plain and V^T epilogues only");
+
     constexpr int BM = 128, BN = 128, BK = 64, KS = 20, NSLAB = 5;
     constexpr int BNO = GEGLU ? BN / 2 : BN;
     constexpr int CSTR = BNO + 8;
@@ -71,6 +84,9 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
     constexpr int PPW = 4;                                       // 1-KiB DMA pieces per wave per slab
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Cs = (bf16_t*)(smem + ST * STAGE);                   // [ROWS_PASS][CSTR]
+    float2* Ls = (float2*)(smem + ST * STAGE + 128 * (64 + 8) * 2);   // LN: (rstd, -mean rstd) of the tile's 128 rows (after the staging)
+    float* Lc = (float*)(Ls + 128);                                   // LN: column sums of W, this tile's 128 columns
+    float* Lb = Lc + 128;                                             // LN: bias of the same columns (LDS instead of 2 x 16 VGPRs)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,11 +126,25 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
     float4 bA[4];                                                // GEGLU: {value g0, value g1, gate g0, gate g1}; else g = 0..3
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+        if (LN) { bA[g] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }          // LN: bias sits in LDS next to the column sums (Lb)
         int col;
         if (GEGLU) col = n0 + (wave >> 1) * 64 + 16 * (wave & 1) + 8 * (g & 1) + 4 * half + 32 * (g >> 1);
         else col = n0 + ocol + 8 * g + 4 * half;
         const float4 bv = p.bias ? *(const float4*)(p.bias + min(col, p.N - 4)) : make_float4(0.f, 0.f, 0.f, 0.f);   // unconditional, clamped (p.bias is wave-uniform)
         bA[g] = col < p.N ? bv : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // V tiles: lane = channel, so bias (and the LN column sum) are one value per lane
+    float bch = 0.f, csch = 0.f;
+    if (VT) {
+        bch = p.bias ? p.bias[min(wrow, p.N - 1)] : 0.f;
+        if (LN) csch = p.ln_csum[min(wrow, p.N - 1)];
+        if (wrow >= p.N) { bch = 0.f; csch = 0.f; }
+    }
+    if (LN && !VT) {                                             // column sums of W for the tile's 128 (packed) columns: LDS (read per tile; 16 VGPRs otherwise)
+        if (tid < 128) {
+            Lc[tid] = n0 + tid < p.N ? p.ln_csum[n0 + tid] : 0.f;
+            Lb[tid] = (p.bias && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
+        }
     }
 
     // ---- activation stream: DMA cursor (runs ST-1 slabs ahead of the multiply) ----
@@ -132,6 +162,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wf[ks].u.x), "+v"(wf[ks].u.y), "+v"(wf[ks].u.z), "+v"(wf[ks].u.w));
 #pragma unroll
     for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bA[g].x), "+v"(bA[g].y), "+v"(bA[g].z), "+v"(bA[g].w));
+    if (VT) asm volatile("" : "+v"(bch), "+v"(csch));
     const int crow = lane >> 3, cphys = lane & 7;
     unsigned r_row[PPW], r_coff[PPW];                            // row inside the tile; byte offset of the (swizzled) source chunk
 #pragma unroll
@@ -185,6 +216,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
 #endif
     const int n0o = GEGLU ? n0 / 2 : n0, Nout = GEGLU ? p.N / 2 : p.N;
     int q = 0;                                                   // slab counter (ring stage = q % ST)
+    float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;            // LN: sums of x / x^2 of row 32 wave + frow over this lane's half of the k chunks
+    const float ln_eps = p.ln_eps;
     for (int t = 0; t < ntiles; ++t) {
         const int m0 = (walker + t * nwalk) * BM;
 #pragma unroll
@@ -202,18 +235,55 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
             for (int j = 0; j < PPW; ++j) WS_ISSUE_PIECE(j)      // refill of the stage freed by this iteration's barrier
             WS_ADVANCE()
             const unsigned char* as = a_rd + (q % ST) * STAGE;
-            // fragment reads one k-step ahead of their MFMAs (two register sets): left to the compiler each k-step read two fragments,
-            // waited, multiplied — the LDS latency sat between every pair of MFMAs
             Frag8 af[2][4];
+            // LN: this wave also sums x and x^2 of rows 32 wave .. 32 wave + 31 (the chunks its m-tile `wave` fragments hold — a second
+            // read: selecting af[.][wave] by a wave-uniform index would need a branch per k-step).  The 24 VALU operations of a k-step sit
+            // between its 4 MFMAs, 6 behind each.
+            Frag8 sf[2];
+            const unsigned char* sr = as + wave * (32 * 128);
+#if defined(MDX_WS_LN_ABLATE) && (MDX_WS_LN_ABLATE & 2)              // ... and the read too (one per tile keeps the code shape)
+            if constexpr (LN) { if (s == 0) sf[0].u = *(const uint4*)(sr + (x0 << 4)); }
+#else
+            if constexpr (LN) sf[0].u = *(const uint4*)(sr + (x0 << 4));
+#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[0][i].u = *(const uint4*)(as + i * 32 * 128 + (x0 << 4));
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            if constexpr (LN) __builtin_amdgcn_sched_barrier(0); else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 if (ks + 1 < 4) {
                     const int co = (x0 ^ ((ks + 1) << 1)) << 4;
+#if defined(MDX_WS_LN_ABLATE) && (MDX_WS_LN_ABLATE & 2)
+                    if constexpr (LN) sf[(ks + 1) & 1].u = sf[ks & 1].u;
+#else
+                    if constexpr (LN) sf[(ks + 1) & 1].u = *(const uint4*)(sr + co);
+#endif
 #pragma unroll
                     for (int i = 0; i < 4; ++i) af[(ks + 1) & 1][i].u = *(const uint4*)(as + i * 32 * 128 + co);
+                }
+                if constexpr (LN) {
+                    // {1 MFMA, the sums of 2 of the fragment's 8 values (6 VALU)} x 4, each group fenced: the VALU work issues in the shadow of
+                    // the MFMA in front of it (sched_group_barrier pipelines of this shape were only partly honoured: half of the VALU ended up
+                    // in one block behind the slab's last MFMA)
+                    if (ks + 1 < 4) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (do_mma) {
+                            if (vtile) acc[i] = MDX_MFMA_32x32x16(af[ks & 1][i].v, wf[s * 4 + ks].v, acc[i]);
+                            else acc[i] = MDX_MFMA_32x32x16(wf[s * 4 + ks].v, af[ks & 1][i].v, acc[i]);
+                        }
+#if defined(MDX_WS_LN_ABLATE) && (MDX_WS_LN_ABLATE & 1)      // side builds (tools/lnone.py): drop the sums, keep the extra fragment read
+                        if (i == 0) s1a += bf2f(sf[ks & 1].h[0]);
+#else
+                        const float xa = bf2f(sf[ks & 1].h[2 * i]), xb = bf2f(sf[ks & 1].h[2 * i + 1]);
+                        s1a += xa; s1b += xb;
+                        s2a = __builtin_fmaf(xa, xa, s2a); s2b = __builtin_fmaf(xb, xb, s2b);
+#endif
+                        // (the empty asm ties the sums to this point: instruction selection orders only side-effecting nodes against the fence)
+                        asm volatile("" : "+v"(s1a), "+v"(s1b), "+v"(s2a), "+v"(s2b));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    continue;
                 }
                 if (do_mma) {
                     if (vtile) {          // operands swapped: the accumulator comes out transposed (lane = channel, registers = tokens)
@@ -226,14 +296,27 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
                             acc[i] = MDX_MFMA_32x32x16(wf[s * 4 + ks].v, af[ks & 1][i].v, acc[i]);
                     }
                 }
-                // pin the order {4 fragment reads of k-step ks + 1} {4 MFMAs of k-step ks}: the machine scheduler otherwise sinks the
+                // pin the order {fragment reads of k-step ks + 1} {4 MFMAs of k-step ks}: the machine scheduler otherwise sinks the
                 // reads back next to their use to save registers
                 if (ks + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
+            // LN: the sums must be formed in THIS slab: left alone, LLVM sinks the whole add chain to the end of the tile and keeps all 20
+            // fragments of the tile alive until then (80 VGPRs -> 70 spilled registers, reloaded behind s_waitcnt vmcnt(0) inside the ring)
+            if constexpr (LN) asm volatile("" : "+v"(s1a), "+v"(s1b), "+v"(s2a), "+v"(s2b));
         }
         // ---- epilogue of tile t: staging is separate from the ring, which keeps streaming ----
         if (no_epi) continue;                                    // ablation: main loop only
+        if constexpr (LN) {
+            float s1 = s1a + s1b, s2 = s2a + s2b;
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);          // the other half of the k chunks
+            const float mean = s1 * (1.0f / 320.0f);
+            const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * (1.0f / 320.0f)), 0.f);
+            const float rs = rsqrtf(var + ln_eps);
+            if (half == 0) Ls[wave * 32 + frow] = make_float2(rs, -mean * rs);
+            s1a = s1b = s2a = s2b = 0.f;
+            ws_lds_barrier();                                    // (the next tile's statistics are written >= NSLAB barriers from here)
+        }
 #pragma unroll
         for (int pass = 0; pass < BM / ROWS_PASS; ++pass) {
             if (pass > 0) ws_lds_barrier();                       // previous pass's row walk is done with Cs
@@ -242,13 +325,23 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (i * 32 / ROWS_PASS != pass) continue;
-                    const float bch = (p.bias && wrow < p.N) ? p.bias[wrow] : 0.f;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int tl = i * 32 + 8 * g + 4 * half - pass * ROWS_PASS;       // token inside the pass
+                        float o[4];
+                        if constexpr (LN) {
+                            const float4 sa = *(const float4*)(Ls + i * 32 + 8 * g + 4 * half), sb = *(const float4*)(Ls + i * 32 + 8 * g + 4 * half + 2);
+                            o[0] = __builtin_fmaf(sa.x, acc[i][4 * g], __builtin_fmaf(sa.y, csch, bch));
+                            o[1] = __builtin_fmaf(sa.z, acc[i][4 * g + 1], __builtin_fmaf(sa.w, csch, bch));
+                            o[2] = __builtin_fmaf(sb.x, acc[i][4 * g + 2], __builtin_fmaf(sb.y, csch, bch));
+                            o[3] = __builtin_fmaf(sb.z, acc[i][4 * g + 3], __builtin_fmaf(sb.w, csch, bch));
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = acc[i][4 * g + e] + bch;
+                        }
                         uint2 ov;
-                        ov.x = pack2bf(acc[i][4 * g] + bch, acc[i][4 * g + 1] + bch);
-                        ov.y = pack2bf(acc[i][4 * g + 2] + bch, acc[i][4 * g + 3] + bch);
+                        ov.x = pack2bf(o[0], o[1]);
+                        ov.y = pack2bf(o[2], o[3]);
                         *(uint2*)(Cs + (32 * wave + frow) * CSTR_T + tl) = ov;
                     }
 #pragma unroll
@@ -291,8 +384,17 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         uint2 ov;
+                        if constexpr (LN) {
+                            const float2 st = Ls[i * 32 + frow];                                     // (rstd, -mean rstd) of this lane's row
+                            const float4 cs = *(const float4*)(Lc + ocol + 8 * g + 4 * half), bb = *(const float4*)(Lb + ocol + 8 * g + 4 * half);
+                            ov.x = pack2bf(__builtin_fmaf(st.x, acc[i][4 * g], __builtin_fmaf(st.y, cs.x, bb.x)),
+                                           __builtin_fmaf(st.x, acc[i][4 * g + 1], __builtin_fmaf(st.y, cs.y, bb.y)));
+                            ov.y = pack2bf(__builtin_fmaf(st.x, acc[i][4 * g + 2], __builtin_fmaf(st.y, cs.z, bb.z)),
+                                           __builtin_fmaf(st.x, acc[i][4 * g + 3], __builtin_fmaf(st.y, cs.w, bb.w)));
+                        } else {
                         ov.x = pack2bf(acc[i][4 * g] + bA[g].x, acc[i][4 * g + 1] + bA[g].y);
                         ov.y = pack2bf(acc[i][4 * g + 2] + bA[g].z, acc[i][4 * g + 3] + bA[g].w);
+                        }
                         *(uint2*)(Cs + ml * CSTR + ocol + 8 * g + 4 * half) = ov;
                     }
                 }
@@ -369,11 +471,12 @@ bool ws_supported(const GCParams& p) {
            (p.epi != 1 || (p.N % 64) == 0);
 }
 
-template <bool GEGLU, bool VT>
+template <bool GEGLU, bool VT, bool LN>
 static int launch_ws_one(const GCParams& p, hipStream_t st) {
     constexpr int ST = 3;
-    const size_t smem = (size_t)ST * 128 * 64 * 2 + (size_t)128 * (64 + 8) * 2;   // ring + staging (also holds 64 x 136 and the transposed 128 x 72)
-    auto kern = gemm_ws_kernel<GEGLU, ST, VT>;
+    const size_t smem = (size_t)ST * 128 * 64 * 2 + (size_t)128 * (64 + 8) * 2 +   // ring + staging (also holds 64 x 136 and the transposed 128 x 72)
+                        (LN ? 128 * sizeof(float2) + 256 * sizeof(float) : 0);      // + the tile's row statistics, W's column sums, bias
+    auto kern = gemm_ws_kernel<GEGLU, ST, VT, LN>;
     if (int rc = ensure_dyn_smem((const void*)kern, smem, "ws")) return rc;
     GCParams q = p;
     q.mt = (p.M + 127) / 128; q.nt = (p.N + 127) / 128;
@@ -387,21 +490,28 @@ static int launch_ws_one(const GCParams& p, hipStream_t st) {
     const int dbg = (int)opt(OPT_WS_DBG);
     q.dbg = dbg;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nwalk * q.nt)), dim3(256), smem, st, q);
-    return check_launch(GEGLU ? "gemm_ws_kernel<geglu>" : (VT ? "gemm_ws_kernel<vT>" : "gemm_ws_kernel<plain>"));
+    return check_launch(GEGLU ? "gemm_ws_kernel<geglu>" : LN ? (VT ? "gemm_ws_kernel<vT,ln>" : "gemm_ws_kernel<plain,ln>")
+                                                             : (VT ? "gemm_ws_kernel<vT>" : "gemm_ws_kernel<plain>"));
 }
+
+// Whether launch_gemm_ws normalises the A rows itself when p.ln_eps > 0 (else the caller must have done it: launch_gemm_conv).
+bool ws_fuses_layernorm(const GCParams& p) { return p.epi == 0 && p.ln_csum != nullptr; }
 
 int launch_gemm_ws(const GCParams& p, hipStream_t st) {
     if ((long)p.M * p.lda * 2 >= 0x7FFF0000L) return set_error(MDX_EINVAL, "gemm_ws: A exceeds the 2 GiB buffer window");
-    if (p.epi == 1) return launch_ws_one<true, false>(p, st);
-    if (!p.Vt) return launch_ws_one<false, false>(p, st);
+    const bool ln = p.ln_eps > 0.f;
+    if (ln && !ws_fuses_layernorm(p)) return set_error(MDX_EINVAL, "gemm_ws: fused LayerNorm needs a plain epilogue and ln_csum");
+    if (p.epi == 1) return launch_ws_one<true, false, false>(p, st);
+    if (!p.Vt) return ln ? launch_ws_one<false, false, true>(p, st) : launch_ws_one<false, false, false>(p, st);
     // fused q/k/v: the C columns [0, vt_from) and the transposed V columns [vt_from, N) are two launches over two row ranges of W
     GCParams c = p;
     c.N = p.vt_from; c.Vt = nullptr;
-    int rc = launch_ws_one<false, false>(c, st);
+    int rc = ln ? launch_ws_one<false, false, true>(c, st) : launch_ws_one<false, false, false>(c, st);
     if (rc != MDX_OK) return rc;
     GCParams v = p;
     v.W = p.W + (long)p.vt_from * p.ldw; v.N = p.N - p.vt_from; v.bias = p.bias ? p.bias + p.vt_from : nullptr; v.R = nullptr; v.C = nullptr;
-    return launch_ws_one<false, true>(v, st);
+    v.ln_csum = p.ln_csum ? p.ln_csum + p.vt_from : nullptr;
+    return ln ? launch_ws_one<false, true, true>(v, st) : launch_ws_one<false, true, false>(v, st);
 }
 
 }  // namespace mdx

@@ -46,7 +46,8 @@ namespace mdx {
     X(GN_REVERSE, 1, "two-stage GroupNorm: statistics pass reads the tensor back to front (Infinity-Cache reuse between producer / passes)") \
     X(GN_TWO_STAGE, 1, "streaming two-stage GroupNorm for maps >= 32768 elements") \
     X(XL_PERSIST, 1, "256x256 XL GEMMs (plain / GEGLU, optional residual) on the persistent kernel gemm_xlp_kernel") \
-    X(XL_RASTER, 2, "XL tile order: 0 row-major, 1 XCD-strided M-tiles, 2 XCD-blocked (M-group x N-group panels per XCD)")
+    X(XL_RASTER, 2, "XL tile order: 0 row-major, 1 XCD-strided M-tiles, 2 XCD-blocked (M-group x N-group panels per XCD)") \
+    X(LN_FUSE, 1, "MdxGemmDesc.ln_eps: 1 = gemm_ws.hip normalises the rows in-kernel, 0 = always normalise into ln_scratch first (A/B)")
 
 enum Opt : int {
 #define MDX_OPT_ENUM(key, dflt, doc) OPT_##key,

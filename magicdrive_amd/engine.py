@@ -78,6 +78,23 @@ class PackedNet:
         return self._get(("catlin",) + sc, keys,
                          lambda *ws: torch.cat([w.reshape(w.shape[0], -1) * f for w, f in zip(ws, sc)], 0).contiguous().to(self.dtype))
 
+    def ln_lin(self, keys: Sequence[str], ln_pre: str, scales: Sequence[float] = ()):
+        """Linear(s) that consume LayerNorm `ln_pre`'s output, with the norm's affine part folded in (MdxGemmDesc.ln_eps):
+            W' = [s_i W_i] diag(gamma)   (16-bit),   b' = [s_i W_i] beta   (fp32; diffusers' to_q / to_k / to_v carry no bias of their own),
+            csum[n] = sum_k W'[n][k]     (of the ROUNDED W': the kernel subtracts mean * csum from sum_k x_k W'[n][k]).
+        Returns (W', b', csum)."""
+        sc = tuple(scales) if scales else (1.0,) * len(keys)
+        allk = list(keys) + [ln_pre + "weight", ln_pre + "bias"]
+
+        def cat(*ts):
+            ws, g, b = ts[:-2], ts[-2].reshape(-1), ts[-1].reshape(-1)
+            return torch.cat([w.reshape(w.shape[0], -1) * f for w, f in zip(ws, sc)], 0), g, b
+
+        w = self._get(("lnw",) + sc, allk, lambda *ts: (cat(*ts)[0] * cat(*ts)[1][None, :]).contiguous().to(self.dtype))
+        b = self._get(("lnb",) + sc, allk, lambda *ts: (cat(*ts)[0] @ cat(*ts)[2]).contiguous().to(F32))
+        cs = self._get(("lncs",) + sc, allk, lambda *ts: (cat(*ts)[0] * cat(*ts)[1][None, :]).to(self.dtype).float().sum(1).contiguous())
+        return w, b, cs
+
     def cat_vec(self, keys: Sequence[str]):
         return self._get("catvec", keys, lambda *vs: torch.cat([v.reshape(-1) for v in vs]).contiguous().to(F32))
 
@@ -246,19 +263,33 @@ class Builder:
         return out
 
     # ---- transformer ------------------------------------------------------------------------
-    def self_like_attention(self, net, pre, n: torch.Tensor, B, T, C, heads, cross_view: bool, name) -> torch.Tensor:
+    @staticmethod
+    def fuses_qkv(B, T, C) -> bool:
+        """Level 0 at real batch sizes: q, k and V^T come from ONE weight-stationary launch pair (gemm_ws.hip), which can also take the
+        LayerNorm in front of it (transformer_block)."""
+        return C == 320 and T % 8 == 0 and B * T >= 8192
+
+    def self_like_attention(self, net, pre, n: torch.Tensor, B, T, C, heads, cross_view: bool, name, ln_pre: Optional[str] = None,
+                            ln_scratch: Optional[torch.Tensor] = None) -> torch.Tensor:
         """q,k fused projection + V^T projection + fused attention over the same token set (attn1) or over the
-        two neighbour views (attn4).  n: normalised tokens [B*T, C]."""
+        two neighbour views (attn4).  n: normalised tokens [B*T, C] — or, with ln_pre (only when fuses_qkv), the RAW tokens: LayerNorm
+        `ln_pre` is then applied inside the projection (ops.Gemm.ln_eps)."""
         ldv = PK.round_up(T, 8)
         vt = self.pool.get((B, C, ldv))
         qs = q_prescale(C // heads)         # softmax scale * log2(e), folded into to_q (MdxAttnDesc.q_prescaled)
-        if C == 320 and T % 8 == 0 and B * T >= 8192:
+        qkv_keys = [pre + "to_q.weight", pre + "to_k.weight", pre + "to_v.weight"]
+        if self.fuses_qkv(B, T, C):
             # level 0: ONE weight-stationary launch pair reads the tokens for q, k and v; the V columns are stored transposed
             # (gemm_ws.hip) — replaces the batched V^T GEMM (245 TFLOP/s, 2 % of the step)
             qk = self.pool.get((B * T, 2 * C))
-            self.emit(O.Gemm(n, net.cat_lin([pre + "to_q.weight", pre + "to_k.weight", pre + "to_v.weight"], (qs, 1.0, 1.0)), qk, Vt=vt, vt_from=2 * C, vt_T=T,
-                             ws=self.ws, name=name + ".qkv"))
+            if ln_pre is not None:
+                w, b, cs = net.ln_lin(qkv_keys, ln_pre, (qs, 1.0, 1.0))
+                self.emit(O.Gemm(n, w, qk, bias=b, Vt=vt, vt_from=2 * C, vt_T=T, ln_eps=1e-5, ln_csum=cs, ln_scratch=ln_scratch,
+                                 ws=self.ws, name=name + ".ln+qkv"))
+            else:
+                self.emit(O.Gemm(n, net.cat_lin(qkv_keys, (qs, 1.0, 1.0)), qk, Vt=vt, vt_from=2 * C, vt_T=T, ws=self.ws, name=name + ".qkv"))
         else:
+            assert ln_pre is None
             qk = self.gemm(n, net.cat_lin([pre + "to_q.weight", pre + "to_k.weight"], (qs, 1.0)), 2 * C, name=name + ".qk")
             self.emit(O.Gemm(net.lin(pre + "to_v.weight"), n.view(B, T, C), vt[:, :, :T], name=name + ".vT"))
         ao = self.pool.get((B * T, C))
@@ -272,15 +303,29 @@ class Builder:
 
     def transformer_block(self, net, pre, h: torch.Tensor, B, T, C, heads, ctx_kv, name) -> torch.Tensor:
         """BasicTransformerBlock / BasicMultiviewTransformerBlock.forward (magicdrive/networks/blocks.py:144-238)."""
+        # LayerNorm -> projection pairs whose GEMM has K = 320 and takes the weight-stationary route normalise inside the GEMM (gemm_ws.hip reads
+        # the whole row anyway): norm1 -> q/k/v, norm2 -> to_q, norm4 -> cross-view q/k/v.  The scratch buffer is only written by routes that cannot
+        # fuse (small M, forced routes).  norm3 -> GEGLU keeps its own pass: each of its 20 N-tiles would repeat the row sums, measured slower
+        # than the pass it saves (gemm_ws.hip).
+        fuse_ln = self.fuses_qkv(B, T, C)
         # 1. self-attention
-        n1 = self.layernorm(net, pre + "norm1.", h, name + ".norm1")
-        ao = self.self_like_attention(net, pre + "attn1.", n1, B, T, C, heads, False, name + ".attn1")
+        if fuse_ln:
+            n1 = self.pool.get(tuple(h.shape))
+            ao = self.self_like_attention(net, pre + "attn1.", h, B, T, C, heads, False, name + ".attn1", ln_pre=pre + "norm1.", ln_scratch=n1)
+        else:
+            n1 = self.layernorm(net, pre + "norm1.", h, name + ".norm1")
+            ao = self.self_like_attention(net, pre + "attn1.", n1, B, T, C, heads, False, name + ".attn1")
         self.pool.put(n1)
         h1 = self.gemm(ao, net.lin(pre + "attn1.to_out.0.weight"), C, bias=net.vec(pre + "attn1.to_out.0.bias"), R=h, name=name + ".attn1.out")
         self.pool.put(ao); self.pool.put(h)
         # 2. context cross-attention with prologue-computed K / V^T
-        n2 = self.layernorm(net, pre + "norm2.", h1, name + ".norm2")
-        q2 = self.gemm(n2, net.lin(pre + "attn2.to_q.weight", q_prescale(C // heads)), C, name=name + ".attn2.q")
+        if fuse_ln:
+            n2 = self.pool.get(tuple(h1.shape))
+            w, b, cs = net.ln_lin([pre + "attn2.to_q.weight"], pre + "norm2.", (q_prescale(C // heads),))
+            q2 = self.gemm(h1, w, C, bias=b, ln_eps=1e-5, ln_csum=cs, ln_scratch=n2, name=name + ".attn2.ln+q")
+        else:
+            n2 = self.layernorm(net, pre + "norm2.", h1, name + ".norm2")
+            q2 = self.gemm(n2, net.lin(pre + "attn2.to_q.weight", q_prescale(C // heads)), C, name=name + ".attn2.q")
         self.pool.put(n2)
         Kc, Vtc, S = ctx_kv[pre + "attn2."]
         ao2 = self.pool.get((B * T, C))
@@ -290,8 +335,12 @@ class Builder:
         self.pool.put(ao2); self.pool.put(h1)
         # 2b. cross-view attention: out = W_o (o_left + o_right) + 2 b_o ; connector ; residual (blocks.py:190-222)
         if net.has(pre + "attn4.to_q.weight"):
-            n4 = self.layernorm(net, pre + "norm4.", h2, name + ".norm4")
-            ao4 = self.self_like_attention(net, pre + "attn4.", n4, B, T, C, heads, True, name + ".attn4")
+            if fuse_ln:
+                n4 = self.pool.get(tuple(h2.shape))
+                ao4 = self.self_like_attention(net, pre + "attn4.", h2, B, T, C, heads, True, name + ".attn4", ln_pre=pre + "norm4.", ln_scratch=n4)
+            else:
+                n4 = self.layernorm(net, pre + "norm4.", h2, name + ".norm4")
+                ao4 = self.self_like_attention(net, pre + "attn4.", n4, B, T, C, heads, True, name + ".attn4")
             self.pool.put(n4)
             # connector(to_out(o_l + o_r) + 2 b_o) is one affine map: fold it at pack time,
             #   W = W_c W_o ,  b = W_c (2 b_o) + b_c     (one GEMM instead of two per block; fp32 fold, bf16 weights)

@@ -68,6 +68,11 @@ class Gemm:
     Vt: Optional[torch.Tensor] = None
     vt_from: int = 0
     vt_T: int = 0
+    # LayerNorm of the A rows fused in (include/mdx.h: MdxGemmDesc.ln_eps): A = raw rows, W / bias carry gamma / beta (engine.PackedNet.ln_lin),
+    # ln_csum fp32 [N] = row sums of W, ln_scratch [M, K] = where routes that cannot fuse put the normalised rows
+    ln_eps: float = 0.0
+    ln_csum: Optional[torch.Tensor] = None
+    ln_scratch: Optional[torch.Tensor] = None
     opcode = L.OP_GEMM
 
     def lower(self):
@@ -125,6 +130,11 @@ class Gemm:
         if self.Vt is not None:
             d.Vt = _p(self.Vt)
             d.vt_from, d.vt_T, d.vt_ld, d.vt_stride = self.vt_from, self.vt_T, self.Vt.stride(1), self.Vt.stride(0)
+        if self.ln_eps > 0:
+            _chk(batch == 1 and self.ln_csum is not None and self.ln_csum.dtype == F32 and self.ln_csum.numel() == N, f"gemm {self.name}: ln_csum")
+            _chk(self.ln_scratch is None or (self.ln_scratch.dtype == A.dtype and self.ln_scratch.is_contiguous() and self.ln_scratch.numel() >= M * lda),
+                 f"gemm {self.name}: ln_scratch must be a contiguous [M, lda] buffer of the operand type")
+            d.ln_eps, d.ln_csum, d.ln_scratch = float(self.ln_eps), _p(self.ln_csum), _p(self.ln_scratch)
         return self.opcode, d
 
 

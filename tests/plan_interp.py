@@ -29,7 +29,12 @@ def _temb_rows(op, n_rows_b, width, col0=0):
 
 def run_gemm(op: O.Gemm):
     A, W, C = op.A.float(), op.W.float(), op.C
-    raw = A @ W.transpose(-1, -2)
+    if op.ln_eps > 0:                         # fused LayerNorm, exactly as include/mdx.h states it: rstd (A W'^T - mean csum) + bias
+        mean = A.mean(-1, keepdim=True)
+        rstd = (A.var(-1, unbiased=False, keepdim=True) + op.ln_eps).rsqrt()
+        raw = rstd * (A @ W.transpose(-1, -2) - mean * op.ln_csum.float())
+    else:
+        raw = A @ W.transpose(-1, -2)
     N = W.shape[-2]
     if op.bias is not None:
         raw = raw + op.bias.float()

@@ -63,6 +63,9 @@ def test_fp16_gemm_conv_norm_kernels(dev):
             TR.gemm_case(8736, 1280, 1280, res=True, expect="gemm_conv_kernel<128,128,64")
         TK.test_groupnorm(dev, 2, 1400, 320, 32, True, 1e-5)
         TK.test_groupnorm(dev, 3, 91, 1280, 32, False, 1e-6)
+        TK.test_gemm_fused_layernorm(dev, 9001, 640, True, "ws")          # LayerNorm inside the weight-stationary GEMM
+        TK.test_gemm_fused_layernorm(dev, 8400, 320, True, "no_ws")       # ... and through ln_scratch
+        TK.test_gemm_fused_layernorm_qkv_transposed_v(dev, 7, 1176)
         TK.test_layernorm(dev, 8403, 320)
         TK.test_layernorm(dev, 546, 1280)
 

@@ -93,6 +93,93 @@ def test_gemm_fused_qkv_transposed_v(dev, Bv, T):
         O.run_ops([O.Gemm(rnd(M, 640, seed=3), rnd(3 * Cc, 640, seed=4), qk, Vt=Vt, vt_from=2 * Cc, vt_T=T)])
 
 
+def ln_fold(W, gamma, beta, dtype):
+    """LayerNorm affine folded into the Linear that follows it (engine.PackedNet.ln_lin): W' (16-bit), b' = W beta, column sums of W'."""
+    Wp = (W * gamma[None, :]).to(dtype)
+    return Wp, (W @ beta).float(), Wp.float().sum(1)
+
+
+def ln_ref(x, Wp, b, eps=1e-5, stored=False):
+    """stored: the route under test keeps a 16-bit normalised copy (ln_scratch) — the reference rounds it too, as for any LayerNorm -> GEMM pair."""
+    xf = x.float().cpu()
+    xh = (xf - xf.mean(-1, keepdim=True)) * (xf.var(-1, unbiased=False, keepdim=True) + eps).rsqrt()
+    if stored: xh = xh.to(x.dtype).float()
+    return xh @ Wp.float().cpu().T + b.cpu()
+
+
+@pytest.mark.parametrize("M,N,res,route", [(8400, 320, False, "ws"), (9001, 640, True, "ws"), (8333, 328, False, "ws"), (16384, 960, False, "ws"),
+                                           (2100, 320, False, "small"), (8400, 320, True, "no_ws"), (8400, 640, False, "xl")])
+def test_gemm_fused_layernorm(dev, M, N, res, route):
+    """LayerNorm fused into the K = 320 projection (MdxGemmDesc.ln_eps): raw rows in, statistics taken inside gemm_ws.hip from the slabs it
+    streams, rstd (acc - mean csum) + bias in the epilogue — against LayerNorm -> Linear in fp32 on the same 16-bit W'.  Rows with a large
+    common offset exercise the one-pass variance; every route that cannot fuse (small M, weight-stationary kernel off, XL forced) must give
+    the same result through ln_scratch."""
+    K = 320
+    x = rnd(M, K, scale=1.5, seed=1).float() + 0.7
+    x[::7] += 12.0                                                   # |mean| = 8 sigma on every 7th row
+    x = x.to(BF)
+    W = rnd(N, K, scale=K ** -0.5, seed=2, dtype=torch.float32); gamma = 1.0 + rnd(K, scale=0.3, seed=5, dtype=torch.float32)
+    beta = rnd(K, scale=0.3, seed=6, dtype=torch.float32)
+    Wp, b, cs = ln_fold(W, gamma, beta, BF)
+    R = rnd(M, N, seed=4) if res else None
+    C = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+    scratch = torch.full((M, K), float("nan"), dtype=BF, device=dev)
+    opts = {"ws": {}, "small": {}, "no_ws": {"GEMM_WS": 0}, "xl": {"GEMM_XL": 2, "XL_K320": 1}}[route]
+    with L.options(**opts):
+        O.run_ops([O.Gemm(x, Wp, C, bias=b, R=R, ln_eps=1e-5, ln_csum=cs, ln_scratch=scratch, ws=ws_buf(dev))])
+        kern = (L.lib().mdx_last_kernel() or b"").decode()
+    torch.cuda.synchronize()
+    fused = route == "ws"
+    assert (kern == "gemm_ws_kernel<plain,ln>") == fused, kern
+    assert torch.isnan(scratch.float()).all() == fused, "the fused route must not touch ln_scratch; the others must fill it"
+    ref = ln_ref(x, Wp, b, stored=not fused)
+    if res: ref += R.float().cpu()
+    close(C, ref, name=f"ln+gemm {M}x{N} {route}")
+    if not fused:
+        with pytest.raises(L.MdxError):                              # no scratch, no silent un-normalised product
+            with L.options(**opts):
+                O.run_ops([O.Gemm(x, Wp, C, bias=b, R=R, ln_eps=1e-5, ln_csum=cs, ws=ws_buf(dev))])
+
+
+@pytest.mark.parametrize("Bv,T", [(6, 1400), (7, 1176)])
+def test_gemm_fused_layernorm_qkv_transposed_v(dev, Bv, T):
+    """norm1 -> to_q / to_k / to_v as the engine emits it at level 0: LayerNorm fused, q/k row-major, V transposed, bias = W beta on all three."""
+    Cc = 320
+    M = Bv * T
+    x = (rnd(M, Cc, scale=1.3, seed=1).float() - 0.4).to(BF)
+    W = rnd(3 * Cc, Cc, scale=Cc ** -0.5, seed=2, dtype=torch.float32); gamma = 1.0 + rnd(Cc, scale=0.3, seed=5, dtype=torch.float32)
+    beta = rnd(Cc, scale=0.3, seed=6, dtype=torch.float32)
+    Wp, b, cs = ln_fold(W, gamma, beta, BF)
+    qk = torch.full((M, 2 * Cc), float("nan"), dtype=BF, device=dev)
+    Vt = torch.full((Bv, Cc, T), float("nan"), dtype=BF, device=dev)
+    O.run_ops([O.Gemm(x, Wp, qk, bias=b, Vt=Vt, vt_from=2 * Cc, vt_T=T, ln_eps=1e-5, ln_csum=cs)])
+    kern = (L.lib().mdx_last_kernel() or b"").decode()
+    torch.cuda.synchronize()
+    assert kern == "gemm_ws_kernel<vT,ln>", kern
+    ref = ln_ref(x, Wp, b)
+    close(qk, ref[:, :2 * Cc], name="ln + fused qk")
+    close(Vt, ref[:, 2 * Cc:].reshape(Bv, T, Cc).transpose(1, 2), name="ln + fused V^T")
+
+
+def test_gemm_fused_layernorm_geglu_goes_through_scratch(dev):
+    """ln_eps on a GEGLU projection (norm3 -> ff.net.0) is accepted by the C-ABI but never fused (gemm_ws.hip: measured slower than the
+    LayerNorm pass): the rows are normalised into ln_scratch, then the ordinary GEGLU kernel runs on the folded weights."""
+    M, F_, K = 8250, 320, 320
+    x = (rnd(M, K, scale=1.4, seed=1).float() + 0.5).to(BF)
+    W = rnd(2 * F_, K, scale=K ** -0.5, seed=2, dtype=torch.float32, dev="cpu"); b = rnd(2 * F_, seed=3, dtype=torch.float32, dev="cpu")
+    gamma = 1.0 + rnd(K, scale=0.3, seed=5, dtype=torch.float32, dev="cpu"); beta = rnd(K, scale=0.3, seed=6, dtype=torch.float32, dev="cpu")
+    Wf, bf_ = W * gamma[None, :], b + W @ beta
+    Wp, bp = PK.pack_geglu(Wf, bf_, BF)
+    C = torch.zeros(M, F_, dtype=BF, device=dev)
+    scratch = torch.full((M, K), float("nan"), dtype=BF, device=dev)
+    O.run_ops([O.Gemm(x, Wp.to(dev), C, bias=bp.to(dev), epilogue=L.EPI_GEGLU, ln_eps=1e-5, ln_csum=Wp.float().sum(1).to(dev), ln_scratch=scratch, ws=ws_buf(dev))])
+    kern = (L.lib().mdx_last_kernel() or b"").decode()
+    torch.cuda.synchronize()
+    assert kern == "gemm_ws_kernel<geglu>" and not torch.isnan(scratch.float()).any(), kern
+    h, g = ln_ref(x, Wf.to(BF), bf_, stored=True).chunk(2, dim=-1)
+    close(C, h * F.gelu(g), name="ln(scratch)+geglu")
+
+
 def test_gemm_weight_stationary_geglu_ragged(dev):
     M, F_, K = 8250, 320, 320
     A = rnd(M, K, seed=1); W = rnd(2 * F_, K, scale=K ** -0.5, seed=2, dtype=torch.float32, dev="cpu")

@@ -245,3 +245,43 @@ def test_fp16_sampler_plan_matches_golden_pipeline():
     e = rel_l2(sp.latents(), G["latents_cfg"])
     assert e < 2e-2, e            # fp16 activations (11-bit mantissa): measured ~0.2 %
     print(f"[fp16 plan, CPU interpreter vs reference golden] {e:.4f}")
+
+
+@pytest.mark.parametrize("dtype,limit", [(torch.bfloat16, 6e-3), (torch.float16, 8e-4)])
+def test_fused_layernorm_block_equals_separate_layernorm(monkeypatch, dtype, limit):
+    """Level-0 transformer block (C = 320, 6 views x 1400 tokens): the emission with LayerNorm folded into the q/k/v and to_q projections
+    (engine.PackedNet.ln_lin + ops.Gemm.ln_eps: raw tokens in, W diag(gamma), W beta, column sums) against the plain LayerNorm -> Linear
+    emission of the same block, both through the CPU interpreter.  The two differ only in where the 16-bit rounding falls (W' vs x_hat):
+    measured 4.1e-3 in bf16 (2^-9 steps), 8x less in fp16 — an algebra or packing error would show at the same size in both."""
+    from magicdrive_amd import engine as E, ops as O
+    g = torch.Generator().manual_seed(3)
+    B, T, C, heads, S = 6, 1400, 320, 8, 20
+    pre = "blk."
+    sd = {}
+    rn = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    for n in ("norm1", "norm2", "norm3", "norm4"):
+        sd[pre + n + ".weight"] = 1.0 + rn(C, sc=0.3); sd[pre + n + ".bias"] = rn(C, sc=0.3)
+    for a in ("attn1", "attn2", "attn4"):
+        for k in ("to_q", "to_k", "to_v"):
+            sd[f"{pre}{a}.{k}.weight"] = rn(C, C, sc=C ** -0.5)
+        sd[f"{pre}{a}.to_out.0.weight"] = rn(C, C, sc=C ** -0.5); sd[f"{pre}{a}.to_out.0.bias"] = rn(C, sc=0.1)
+    sd[pre + "connector.weight"] = rn(C, C, sc=C ** -0.5); sd[pre + "connector.bias"] = rn(C, sc=0.1)
+    sd[pre + "ff.net.0.proj.weight"] = rn(8 * C, C, sc=C ** -0.5); sd[pre + "ff.net.0.proj.bias"] = rn(8 * C, sc=0.1)
+    sd[pre + "ff.net.2.weight"] = rn(C, 4 * C, sc=(4 * C) ** -0.5); sd[pre + "ff.net.2.bias"] = rn(C, sc=0.1)
+    x = (rn(B * T, C) * 1.5 + 0.7).to(dtype)          # a non-zero mean: the mean * csum term matters
+    Kc = rn(B, S, C).to(dtype); Vtc = torch.zeros(B, C, 24, dtype=dtype); Vtc[:, :, :S] = rn(B, C, S).to(dtype)
+
+    def run(fused):
+        monkeypatch.setattr(E.Builder, "fuses_qkv", staticmethod((lambda B_, T_, C_: True) if fused else (lambda B_, T_, C_: False)))
+        net = PackedNet(sd, CPU, dtype)
+        b = E.Builder(spec.SD15_CONFIG, CPU, B, 6, ws_mb=1, dtype=dtype)
+        h = b.pool.get((B * T, C)); h.copy_(x)
+        out = b.transformer_block(net, pre, h, B, T, C, heads, {pre + "attn2.": (Kc, Vtc, S)}, "blk")
+        kinds = [type(o).__name__ + (":ln" if getattr(o, "ln_eps", 0) > 0 else "") for o in b.ops]
+        plan_interp.run(b.ops)
+        return out.float().clone(), kinds
+    y1, k1 = run(True)
+    y0, k0 = run(False)
+    assert k1.count("Gemm:ln") == 3 and k1.count("LayerNorm") == 1          # norm3 -> GEGLU keeps its own pass
+    assert k0.count("Gemm:ln") == 0 and k0.count("LayerNorm") == 4
+    assert rel_l2(y1, y0) < limit, rel_l2(y1, y0)
