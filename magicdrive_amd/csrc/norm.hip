@@ -299,7 +299,9 @@ struct LNParams {
 
 // RPW rows per wave, processed together so that RPW * MAXV 16-byte loads per lane are in flight (one row per wave leaves the kernel
 // latency-bound at ~60 % of the streaming rate); C % 8 == 0, C <= 8 * 64 * MAXV.  Two-pass statistics in registers, shuffle reductions.
-template <int MAXV, int RPW>
+// AFFINE = false: plain normalisation, gamma / beta not read (launch_layernorm_plain).  A compile-time switch: as a run-time test on
+// p.gamma every gamma / beta load became its own branch with a full wait and the kernel ran 2-3 x slower at C = 640 / 1280 (round 3).
+template <int MAXV, int RPW, bool AFFINE>
 __global__ __launch_bounds__(256) void layernorm_kernel(LNParams p) {
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
@@ -324,10 +326,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LNParams p) {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + 64 * i, cl = c < nv ? c : 0;
-        // gamma == null: plain normalisation (the affine part lives in the consumer's weights: launch_layernorm_plain below)
-        const float4 one4 = make_float4(1.f, 1.f, 1.f, 1.f), zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 g0 = p.gamma ? *(const float4*)(p.gamma + cl * 8) : one4, g1 = p.gamma ? *(const float4*)(p.gamma + cl * 8 + 4) : one4;
-        const float4 b0 = p.gamma ? *(const float4*)(p.beta + cl * 8) : zero4, b1 = p.gamma ? *(const float4*)(p.beta + cl * 8 + 4) : zero4;
+        float4 g0, g1, b0, b1;
+        if constexpr (AFFINE) {
+            g0 = *(const float4*)(p.gamma + cl * 8); g1 = *(const float4*)(p.gamma + cl * 8 + 4);
+            b0 = *(const float4*)(p.beta + cl * 8); b1 = *(const float4*)(p.beta + cl * 8 + 4);
+        } else {
+            g0 = g1 = make_float4(1.f, 1.f, 1.f, 1.f); b0 = b1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         g[i][0] = g0.x; g[i][1] = g0.y; g[i][2] = g0.z; g[i][3] = g0.w; g[i][4] = g1.x; g[i][5] = g1.y; g[i][6] = g1.z; g[i][7] = g1.w;
         bt[i][0] = b0.x; bt[i][1] = b0.y; bt[i][2] = b0.z; bt[i][3] = b0.w; bt[i][4] = b1.x; bt[i][5] = b1.y; bt[i][6] = b1.z; bt[i][7] = b1.w;
     }
@@ -480,12 +485,13 @@ extern "C" int mdx_softmax_rows(const MdxSoftmaxDesc* d, void* stream) {
 }
 
 namespace mdx {
+template <bool AFFINE>
 static int launch_layernorm(const LNParams& p, hipStream_t st) {
     const int rpw = p.C <= 512 ? 4 : (p.C <= 1024 ? 2 : 1);
     dim3 grid((p.M + 4 * rpw - 1) / (4 * rpw));
-    if (p.C <= 512) hipLaunchKernelGGL((layernorm_kernel<1, 4>), grid, dim3(256), 0, st, p);
-    else if (p.C <= 1024) hipLaunchKernelGGL((layernorm_kernel<2, 2>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((layernorm_kernel<4, 1>), grid, dim3(256), 0, st, p);
+    if (p.C <= 512) hipLaunchKernelGGL((layernorm_kernel<1, 4, AFFINE>), grid, dim3(256), 0, st, p);
+    else if (p.C <= 1024) hipLaunchKernelGGL((layernorm_kernel<2, 2, AFFINE>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((layernorm_kernel<4, 1, AFFINE>), grid, dim3(256), 0, st, p);
     return check_launch("layernorm_kernel");
 }
 // (x - mean) * rstd without the affine part, for GEMM routes that cannot normalise their A rows in-kernel (MdxGemmDesc.ln_eps:
@@ -496,7 +502,7 @@ int launch_layernorm_plain(const bf16_t* X, bf16_t* Y, int M, int C, long ldx, l
     if (M <= 0) return MDX_OK;
     LNParams p;
     p.X = X; p.Y = Y; p.gamma = nullptr; p.beta = nullptr; p.M = M; p.C = C; p.ldx = ldx; p.ldy = ldy; p.eps = eps;
-    return launch_layernorm(p, st);
+    return launch_layernorm<false>(p, st);
 }
 }  // namespace mdx
 
@@ -509,5 +515,5 @@ extern "C" int mdx_layernorm_bf16(const MdxLayerNormDesc* d, void* stream) {
     LNParams p;
     p.X = (const bf16_t*)d->X; p.Y = (bf16_t*)d->Y; p.gamma = d->gamma; p.beta = d->beta;
     p.M = (int)d->M; p.C = (int)d->C; p.ldx = d->ldx; p.ldy = d->ldy; p.eps = (float)d->eps;
-    return launch_layernorm(p, (hipStream_t)stream);
+    return launch_layernorm<true>(p, (hipStream_t)stream);
 }
