@@ -1,17 +1,17 @@
 #!/bin/bash
-# Round-3 final evidence: GPU suite, the driver's bench command, kernel statistics of the bench command (eager launches).
+# One gpurun call's worth of round evidence (≈ 13 GPU-minutes): GPU suite, the driver's bench command, kernel statistics of the bench command (eager launches).
 set -u
 cd "$(dirname "$0")/.."
-OUT=gpurun_out/r3c16; mkdir -p $OUT
+OUT=${1:-gpurun_out/evidence}; mkdir -p $OUT
 REPO=$PWD
 export MDX_PARITY_LOG=$PWD/$OUT/parity_measured.jsonl
 rm -f $MDX_PARITY_LOG
 (timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log)
 grep -E "passed|failed|error|rc=" $OUT/pytest_gpu.log | tail -4; grep -E "^FAILED|^ERROR" $OUT/pytest_gpu.log | head -20
 unset MDX_PARITY_LOG
-timeout 900 python bench.py --ops-json $OUT/ops_b128.json > $OUT/bench_b128.json 2> $OUT/bench_b128.err; tail -c 600 $OUT/bench_b128.err; python - <<'PY'
-import json
-d=json.load(open('gpurun_out/r3c16/bench_b128.json'))
+timeout 900 python bench.py --ops-json $OUT/ops_b128.json > $OUT/bench_b128.json 2> $OUT/bench_b128.err; tail -c 600 $OUT/bench_b128.err; OUT=$OUT python - <<'PY'
+import json, os
+d=json.load(open(os.environ['OUT']+'/bench_b128.json'))
 print({k:v for k,v in d.items() if k not in ('roofline','config','cpu_baseline')}); print(d['cpu_baseline']); print({k:v for k,v in d['config'].items() if k!='workload'})
 r=d['roofline']; print({k:v for k,v in r.items() if k not in ('per_kernel','per_family','traffic')})
 for k,v in r['per_kernel'].items(): print('   %-48s %8.3f ms %5d launches %8.1f us %s TF  mfma_util=%s hbm=%s'%(k, v['ms_per_step'], v['launches'], v['avg_launch_us'], v['tflops'], v.get('mfma_util'), v.get('hbm_gbps')))
