@@ -65,21 +65,29 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
 }
 
 
-template <int BK, int NSTG, bool STORE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+// NW = 4: 2 x 2 waves of 128 x 128 (one wave per SIMD).  NW = 8: 2 x 4 waves of 128 x 64 (two waves per SIMD, 128 accumulators each) —
+// the "plain" 8-wave form of the same loop, for comparison with gemm_xl.hip's staggered quadrant phases.
+// ABL (ablations; results are wrong, timing only): 1 = no DMA inside the loop (the stages keep the first units), 2 = no barrier,
+// 4 = no fragment reads inside the loop (MFMA stream only).
+template <int NW, int BK, int NSTG, bool STORE, int ABL>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
 void gemm4w_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* __restrict__ C, int M, int N, int K, int nt) {
     constexpr int ROWB = BK * 2;                 // bytes per LDS row (128 / 64)
     constexpr int CPR = BK / 8;                  // 16-byte chunks per row (8 / 4)
     constexpr int RPP = 1024 / ROWB;             // rows per DMA piece (8 / 16)
     constexpr int REG = 256 * ROWB;              // bytes of the A (or W) half of a unit
     constexpr int UNIT = 2 * REG;                // 64 KB / 32 KB
-    constexpr int PPW = UNIT / 1024 / 4;         // pieces per wave per unit (16 / 8)
+    constexpr int PPW = UNIT / 1024 / NW;        // pieces per wave per unit (4 waves: 16 / 8)
     constexpr int KS = BK / 16;                  // MFMA k-steps per unit (4 / 2)
+    constexpr int WNC = NW / 2;                  // waves along N
+    constexpr int NN = 4 / (NW / 4);             // 32-column accumulator tiles per wave along N (4 / 2)
+    constexpr int SLOTS = KS * 4;                // {NN MFMAs} groups per unit; one DMA piece behind every SLOTS / PPW-th group
+    static_assert(SLOTS % PPW == 0, "pieces spread evenly over the MFMA groups");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WNC, wn = wave % WNC;
     const int frow = lane & 31, half = lane >> 5;
     // XCD-aware order: workgroup b runs on XCD b % 8; an XCD walks the N-tiles of consecutive M-tiles
     const int nblk = gridDim.x;
@@ -88,7 +96,7 @@ void gemm4w_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, b
     const int tm = bid / nt, tn = bid - tm * nt;
     const int m0 = tm * 256, n0 = tn * 256;
 
-    const bool loadsA = wave < 2;                                          // waves 0, 1 load the A rows, waves 2, 3 the W rows
+    const bool loadsA = wave < NW / 2;                                     // the first half of the waves loads the A rows, the second the W rows
     rsrc_t rs = make_rsrc(loadsA ? (const void*)A : (const void*)W);
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
     // swizzle of the 16-byte chunk index by the row: 128-byte rows (row >> 1) & 7, 64-byte rows (row >> 2) & 3
@@ -98,14 +106,14 @@ void gemm4w_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, b
     unsigned src_off[PPW];                       // byte offset of this lane's source chunk at k = 0
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-        const int piece = (wave & 1) * PPW + j;                  // piece within the A (or W) region
+        const int piece = (wave % (NW / 2)) * PPW + j;           // piece within the A (or W) region
         const int row = piece * RPP + lane / CPR;                // 0..255
         const int cp = lane % CPR;
         const int c = cp ^ swz(row);
         const long grow = (loadsA ? m0 : n0) + row;
         src_off[j] = (unsigned)(grow * (long)K * 2 + c * 16);    // operands < 4 GiB (host checks)
     }
-    const unsigned dst_reg = (loadsA ? 0 : REG) + (wave & 1) * PPW * 1024;
+    const unsigned dst_reg = (loadsA ? 0 : REG) + (wave % (NW / 2)) * PPW * 1024;
     const int T = K / BK;
     // piece j of unit t (past-the-end units: num_records = 0 -> the DMA writes zeros; the vmcnt bookkeeping stays uniform)
     auto issue_piece = [&](int t, int j) {
@@ -114,55 +122,65 @@ void gemm4w_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, b
         glds(r, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(t % NSTG) * UNIT + dst_reg + j * 1024), src_off[j], (unsigned)t * ROWB);
     };
 
-    f32x16_t acc[4][4];
+    f32x16_t acc[4][NN];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < NN; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
 
 #pragma unroll
-    for (int t = 0; t < NSTG - 1; ++t)
+    for (int t = 0; t < NSTG - 1 + (ABL & 1); ++t)
 #pragma unroll
         for (int j = 0; j < PPW; ++j) issue_piece(t, j);
+    if (ABL & 1) { wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); }
 
     const int x0 = half ^ swz(frow);                                       // physical chunk of k-step 0; k-step j: x0 ^ (j << 1)
     const unsigned a_rd = (unsigned)((wm * 128 + frow) * ROWB);            // + i * 32 * ROWB
-    const unsigned w_rd = (unsigned)(REG + (wn * 128 + frow) * ROWB);
+    const unsigned w_rd = (unsigned)(REG + (wn * 32 * NN + frow) * ROWB);
+    Frag8 af[2][4], wf[2][NN];
+    if (ABL & 4) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[b][i].u = *(const uint4*)(smem + a_rd + i * 32 * ROWB + (x0 << 4));
+#pragma unroll
+            for (int n = 0; n < NN; ++n) wf[b][n].u = *(const uint4*)(smem + w_rd + n * 32 * ROWB + (x0 << 4));
+        }
+    }
 
     for (int t = 0; t < T; ++t) {
         __builtin_amdgcn_sched_barrier(0);
-        wait_vmcnt<(NSTG - 2) * PPW>();                                    // unit t's pieces of this wave have landed
-        __builtin_amdgcn_s_barrier();                                      // ... everyone's; and everyone is done reading unit t - 1
+        if (!(ABL & 1)) wait_vmcnt<(NSTG - 2) * PPW>();                    // unit t's pieces of this wave have landed
+        if (!(ABL & 2)) __builtin_amdgcn_s_barrier();                      // ... everyone's; and everyone is done reading unit t - 1
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* ub = smem + (t % NSTG) * UNIT;
-        Frag8 af[2][4], wf[2][4];
+        if (!(ABL & 4)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            af[0][i].u = *(const uint4*)(ub + a_rd + i * 32 * ROWB + (x0 << 4));
-            wf[0][i].u = *(const uint4*)(ub + w_rd + i * 32 * ROWB + (x0 << 4));
+            for (int i = 0; i < 4; ++i) af[0][i].u = *(const uint4*)(ub + a_rd + i * 32 * ROWB + (x0 << 4));
+#pragma unroll
+            for (int n = 0; n < NN; ++n) wf[0][n].u = *(const uint4*)(ub + w_rd + n * 32 * ROWB + (x0 << 4));
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 1 < KS) {                                             // fragment reads one k-step ahead (second register set)
+            if (ks + 1 < KS && !(ABL & 4)) {                               // fragment reads one k-step ahead (second register set)
                 const int co = (x0 ^ ((ks + 1) << 1)) << 4;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    af[(ks + 1) & 1][i].u = *(const uint4*)(ub + a_rd + i * 32 * ROWB + co);
-                    wf[(ks + 1) & 1][i].u = *(const uint4*)(ub + w_rd + i * 32 * ROWB + co);
-                }
+                for (int i = 0; i < 4; ++i) af[(ks + 1) & 1][i].u = *(const uint4*)(ub + a_rd + i * 32 * ROWB + co);
+#pragma unroll
+                for (int n = 0; n < NN; ++n) wf[(ks + 1) & 1][n].u = *(const uint4*)(ub + w_rd + n * 32 * ROWB + co);
             }
             asm volatile("" ::: "memory");                                 // the reads above stay above this k-step's MFMAs
             // D[n'][m'] orientation (W fragment as the A operand): lane = token row m', registers = 4-column groups of n' -> 8-byte row stores.
-            // One DMA piece of unit t + NSTG - 1 (it refills the stage unit t - 1 occupied) behind every 4 MFMAs: KS * 4 == PPW.
-            static_assert(KS * 4 == PPW, "one piece per four MFMAs");
+            // The DMA pieces of unit t + NSTG - 1 (it refills the stage unit t - 1 occupied) are spread over the unit's MFMA groups.
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int n = 0; n < 4; ++n) MFMA_32x32x16(acc[i][n], wf[ks & 1][n].v, af[ks & 1][i].v);
-                issue_piece(t + NSTG - 1, ks * 4 + i);
+                for (int n = 0; n < NN; ++n) MFMA_32x32x16(acc[i][n], wf[ks & 1][n].v, af[ks & 1][i].v);
+                const int slot = ks * 4 + i;
+                if (!(ABL & 1) && slot % (SLOTS / PPW) == 0) issue_piece(t + NSTG - 1, slot / (SLOTS / PPW));
             }
         }
     }
@@ -173,8 +191,8 @@ void gemm4w_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, b
         for (int i = 0; i < 4; ++i) {
             const long m = m0 + wm * 128 + i * 32 + frow;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                bf16_t* crow = C + m * (long)N + n0 + wn * 128 + n * 32 + 4 * half;
+            for (int n = 0; n < NN; ++n) {
+                bf16_t* crow = C + m * (long)N + n0 + wn * 32 * NN + n * 32 + 4 * half;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     uint2 o;
@@ -190,7 +208,7 @@ void gemm4w_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, b
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) s += acc[i][n][0] + acc[i][n][15];
+            for (int n = 0; n < NN; ++n) s += acc[i][n][0] + acc[i][n][15];
         if (s == 12345.678f) C[threadIdx.x] = 1;
     }
 }
@@ -198,17 +216,17 @@ void gemm4w_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, b
 static float bf2f(bf16_t v) { unsigned u = (unsigned)v << 16; float f; memcpy(&f, &u, 4); return f; }
 static bf16_t f2bf(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (bf16_t)(u >> 16); }
 
-template <int BK, int NSTG, bool STORE>
+template <int NW, int BK, int NSTG, bool STORE, int ABL = 0>
 static double run(const bf16_t* dA, const bf16_t* dW, bf16_t* dC, int M, int N, int K, int reps) {
     const int mt = M / 256, nt = N / 256, nblk = mt * nt;
     const size_t smem = (size_t)NSTG * 2 * 256 * BK * 2;
-    auto kern = gemm4w_kernel<BK, NSTG, STORE>;
+    auto kern = gemm4w_kernel<NW, BK, NSTG, STORE, ABL>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), smem, 0, dA, dW, dC, M, N, K, nt);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, 0, dA, dW, dC, M, N, K, nt);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), smem, 0, dA, dW, dC, M, N, K, nt);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, 0, dA, dW, dC, M, N, K, nt);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
     hipError_t e = hipGetLastError();
@@ -219,8 +237,7 @@ static double run(const bf16_t* dA, const bf16_t* dW, bf16_t* dC, int M, int N, 
 int main() {
     struct Shape { int M, N, K; const char* what; };
     const Shape shapes[] = {
-        {268800, 1280, 640, "qk L1 (768 views)"},       {268800, 5120, 640, "GEGLU L1 (raw N)"}, {69888, 2560, 1280, "qk L2"},
-        {69888, 1280, 5120, "ff.out L2"},               {8192, 8192, 8192, "square 8k"},
+        {268800, 1280, 640, "qk L1 (768 views)"}, {69888, 2560, 1280, "qk L2"}, {69888, 1280, 5120, "ff.out L2"}, {8192, 8192, 8192, "square 8k"},
     };
     size_t maxA = 0, maxW = 0, maxC = 0;
     for (auto& s : shapes) {
@@ -237,13 +254,16 @@ int main() {
     (void)hipMemcpy(dA, hA.data(), maxA * 2, hipMemcpyHostToDevice); (void)hipMemcpy(dW, hW.data(), maxW * 2, hipMemcpyHostToDevice);
     std::vector<bf16_t> hC(4096);
     for (auto& s : shapes) {
-        const int reps = 5;
-        // correctness of both variants on sampled outputs (the operands are the leading M x K / N x K elements of the same buffers)
-        for (int variant = 0; variant < 2; ++variant) {
+        const int reps = 4;
+        // correctness of the four complete variants on sampled outputs (the operands are the leading M x K / N x K elements of the buffers)
+        for (int variant = 0; variant < 4; ++variant) {
             (void)hipMemset(dC, 0xff, (size_t)s.M * s.N * 2);
-            if (variant == 0) run<64, 2, true>(dA, dW, dC, s.M, s.N, s.K, 1); else run<32, 4, true>(dA, dW, dC, s.M, s.N, s.K, 1);
+            if (variant == 0) run<4, 64, 2, true>(dA, dW, dC, s.M, s.N, s.K, 1);
+            else if (variant == 1) run<4, 32, 4, true>(dA, dW, dC, s.M, s.N, s.K, 1);
+            else if (variant == 2) run<8, 64, 2, true>(dA, dW, dC, s.M, s.N, s.K, 1);
+            else run<8, 32, 4, true>(dA, dW, dC, s.M, s.N, s.K, 1);
             double worst = 0;
-            for (int q = 0; q < 64; ++q) {
+            for (int q = 0; q < 48; ++q) {
                 const long m = ((long)q * 7919 + (q % 3 == 0 ? s.M - 1 - q : 0)) % s.M, n = ((long)q * 104729 + (q % 5 == 0 ? s.N - 1 : 0)) % s.N;
                 bf16_t got; (void)hipMemcpy(&got, dC + m * (long)s.N + n, 2, hipMemcpyDeviceToHost);
                 double ref = 0;
@@ -251,11 +271,16 @@ int main() {
                 const double err = fabs(bf2f(got) - ref) / (fabs(ref) + 0.05 * sqrt((double)s.K) * 0.07);
                 worst = std::max(worst, err);
             }
-            printf("%-28s variant %c check: worst sampled relative error %.4f %s\n", s.what, variant ? 'B' : 'A', worst, worst < 2e-2 ? "ok" : "MISMATCH");
+            printf("%-20s %d waves, %s: worst sampled relative error %.4f %s\n", s.what, variant < 2 ? 4 : 8, variant & 1 ? "BK 32 x 4" : "BK 64 x 2", worst, worst < 2e-2 ? "ok" : "MISMATCH");
         }
-        const double a1 = run<64, 2, true>(dA, dW, dC, s.M, s.N, s.K, reps), a0 = run<64, 2, false>(dA, dW, dC, s.M, s.N, s.K, reps);
-        const double b1 = run<32, 4, true>(dA, dW, dC, s.M, s.N, s.K, reps), b0 = run<32, 4, false>(dA, dW, dC, s.M, s.N, s.K, reps);
-        printf("%-28s M=%6d N=%5d K=%5d   A (BK 64 x 2): %7.1f TF/s (main loop only %7.1f)   B (BK 32 x 4): %7.1f (%7.1f)\n", s.what, s.M, s.N, s.K, a1, a0, b1, b0);
+        printf("%-20s M=%6d N=%5d K=%5d  TFLOP/s: full | no stores | + no DMA in loop | + no barrier | MFMA stream only\n", s.what, s.M, s.N, s.K);
+#define ROW(NW_, BK_, NS_)                                                                                                               \
+        printf("    %d waves, BK %2d x %d :  %7.1f | %7.1f | %7.1f | %7.1f | %7.1f\n", NW_, BK_, NS_,                                      \
+               run<NW_, BK_, NS_, true, 0>(dA, dW, dC, s.M, s.N, s.K, reps), run<NW_, BK_, NS_, false, 0>(dA, dW, dC, s.M, s.N, s.K, reps), \
+               run<NW_, BK_, NS_, false, 1>(dA, dW, dC, s.M, s.N, s.K, reps), run<NW_, BK_, NS_, false, 3>(dA, dW, dC, s.M, s.N, s.K, reps), \
+               run<NW_, BK_, NS_, false, 7>(dA, dW, dC, s.M, s.N, s.K, reps));
+        ROW(4, 64, 2) ROW(4, 32, 4) ROW(8, 64, 2) ROW(8, 32, 4)
+#undef ROW
     }
     return 0;
 }
