@@ -280,6 +280,12 @@ int main() {
                run<NW_, BK_, NS_, false, 1>(dA, dW, dC, s.M, s.N, s.K, reps), run<NW_, BK_, NS_, false, 3>(dA, dW, dC, s.M, s.N, s.K, reps), \
                run<NW_, BK_, NS_, false, 7>(dA, dW, dC, s.M, s.N, s.K, reps));
         ROW(4, 64, 2) ROW(4, 32, 4) ROW(8, 64, 2) ROW(8, 32, 4)
+        if (&s == &shapes[sizeof(shapes) / sizeof(shapes[0]) - 1]) {
+            // the same loops on ALL-ZERO operands: the matrix pipe's power draw depends on the data, and the clock on the power
+            (void)hipMemset(dA, 0, maxA * 2); (void)hipMemset(dW, 0, maxW * 2);
+            printf("%-20s ... on all-zero operands (power, not the schedule, sets the random-data rates above if these are higher)\n", s.what);
+            ROW(4, 64, 2) ROW(8, 64, 2)
+        }
 #undef ROW
     }
     return 0;
