@@ -42,7 +42,7 @@ extern "C" {
 #define MDX_ELAUNCH (-2)     /* hip launch / runtime error */
 #define MDX_EUNSUPPORTED (-3)
 
-#define MDX_ABI_VERSION 7
+#define MDX_ABI_VERSION 8
 
 /* ---- epilogue flags shared by GEMM / conv ------------------------------- */
 #define MDX_EPI_NONE 0
@@ -294,15 +294,23 @@ int mdx_cfg_ddim_step(const MdxDdimDesc* d, void* stream);
  *   x_c = corr ? cl x_last + c1 m1 + c2 m2 + ct m_t : x   (UniC with the previous step's order)
  *   x  <- px x_c + pt m_t + p1 m1                      (UniP with this step's order)
  *   x_last <- x_c ; m2 <- m1 ; m1 <- m_t
- * coef: fp32 [n_steps][12] = {a, b, corr, cl, c1, c2, ct, px, pt, p1, 0, 0}; row = *step_ptr, incremented after.
+ * coef: fp32 [n_steps][12] = {a, b, corr, cl, c1, c2, ct, px, pt, p1, an, sn}; row = *step_ptr, incremented after.
  * x_last, m1, m2: fp32 state buffers of n elements (zeroed by the caller before the first step).
  * x_in / xin_c / xin_ld as in MdxDdimDesc.
+ * gv_* (ABI 8): given views exactly as in MdxDdimDesc — what demo/run_cond_on_view.py runs (its pipe comes from build_pipe, which
+ * installs UniPC: magicdrive/misc/test_utils.py:129).  Re-noising is scheduler-independent (scheduling_unipc_multistep.py add_noise:
+ * x = sqrt(acp_t) cond + sqrt(1 - acp_t) noise), so gv_mode 1 replaces a given view's PREDICTOR output of step s < gv_last_step by
+ * an * cond + sn * noise with (an, sn) = coef[s][10..11] = (alpha, sigma) of the NEXT timestep; the multistep history (x_last, m1,
+ * m2) keeps the values computed from the overwritten samples, as the reference's scheduler state does.  gv_mode 2 replaces the
+ * combined noise prediction by gv_noise.
  */
 typedef struct MdxUniPCDesc {
     float* x; const float* eps; const float* coef; int32_t* step_ptr; void* x_in; float* x_last; float* m1; float* m2;
     int64_t n, cfg;
     double guidance;
     int64_t xin_c, xin_ld;
+    const float* gv_cond; const float* gv_noise; const uint8_t* gv_mask;
+    int64_t gv_mode, gv_view_elems, gv_last_step;
 } MdxUniPCDesc;
 int mdx_cfg_unipc_step(const MdxUniPCDesc* d, void* stream);
 
@@ -362,6 +370,9 @@ int mdx_graph_launch(void* graph, void* stream);
 int mdx_graph_destroy(void* graph);
 
 int mdx_abi_version(void);
+/* Hash of the kernel sources this library was built from (csrc/Makefile: sha256 over every .hip / .h, first 16 hex digits).  Counter
+ * summaries under profiles/ record it; bench.py drops counters whose build differs from the library it is timing. */
+const char* mdx_build_id(void);
 const char* mdx_last_error(void);
 /* Name of the kernel the calling thread's last op launched (the one doing the op's work; which GEMM / conv main loop a
  * descriptor is routed to is decided inside the library by shape).  Measurement aid: bench.py groups its per-launch HIP-event

@@ -13,7 +13,7 @@ from typing import Dict, List, Tuple
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDX_LIB_PATH") or os.path.join(_HERE, "libmdx.so")      # MDX_LIB_PATH: A/B a second build (tools only)
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # opcodes (mdx.h)
 OP_GEMM, OP_CONV, OP_CONV_DIRECT, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM = 1, 2, 3, 4, 5, 6
@@ -51,7 +51,8 @@ MdxGatherDesc = _struct("MdxGatherDesc", _f(P, "T Y idx mask null_row reserved_p
 MdxTimeEmbDesc = _struct("MdxTimeEmbDesc", _f(P, "t Y") + _f(I, "n dim flip_sin_to_cos ldy") + _f(D, "freq_shift max_period"))
 MdxDdimDesc = _struct("MdxDdimDesc", _f(P, "x eps coef step_ptr x_in reserved_p") + _f(I, "n cfg") + _f(D, "guidance") + _f(I, "xin_c xin_ld")
                       + _f(P, "gv_cond gv_noise gv_mask") + _f(I, "gv_mode gv_view_elems gv_last_step"))
-MdxUniPCDesc = _struct("MdxUniPCDesc", _f(P, "x eps coef step_ptr x_in x_last m1 m2") + _f(I, "n cfg") + _f(D, "guidance") + _f(I, "xin_c xin_ld"))
+MdxUniPCDesc = _struct("MdxUniPCDesc", _f(P, "x eps coef step_ptr x_in x_last m1 m2") + _f(I, "n cfg") + _f(D, "guidance") + _f(I, "xin_c xin_ld")
+                       + _f(P, "gv_cond gv_noise gv_mask") + _f(I, "gv_mode gv_view_elems gv_last_step"))
 
 MdxSoftmaxDesc = _struct("MdxSoftmaxDesc", _f(P, "X Y") + _f(I, "rows T ldx ldy") + _f(D, "scale") + _f(I, "reserved0"))
 DESC_OF_OP = {
@@ -77,7 +78,7 @@ def entry_name(opcode: int, dtype: int = DTYPE_BF16) -> str:
 # every symbol include/mdx.h declares
 EXPORTS = sorted(set(ENTRY_OF_OP.values()) | {entry_name(o, DTYPE_F16) for o in ENTRY_OF_OP} | {
     "mdx_program_run", "mdx_graph_create", "mdx_graph_launch", "mdx_graph_destroy",
-    "mdx_abi_version", "mdx_last_error", "mdx_last_kernel", "mdx_device_info", "mdx_set_option", "mdx_get_option", "mdx_option_name"})
+    "mdx_abi_version", "mdx_build_id", "mdx_last_error", "mdx_last_kernel", "mdx_device_info", "mdx_set_option", "mdx_get_option", "mdx_option_name"})
 
 
 class MdxOp(C.Structure):
@@ -123,6 +124,7 @@ def lib() -> C.CDLL:
     l.mdx_graph_destroy.argtypes = [C.c_void_p]
     l.mdx_abi_version.restype = C.c_int
     l.mdx_last_error.restype = C.c_char_p
+    l.mdx_build_id.restype = C.c_char_p
     l.mdx_last_kernel.restype = C.c_char_p
     l.mdx_device_info.restype = C.c_int
     l.mdx_device_info.argtypes = [C.POINTER(C.c_int64)]
@@ -226,6 +228,11 @@ class options:
         for k, v in self.prev.items():
             set_option(k, v)
         return False
+
+
+def build_id() -> str:
+    """Source hash of the loaded libmdx.so (mdx_build_id)."""
+    return (lib().mdx_build_id() or b"unknown").decode()
 
 
 def device_info() -> Dict[str, int]:

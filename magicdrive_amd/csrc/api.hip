@@ -187,6 +187,10 @@ extern "C" int mdx_graph_destroy(void* graph) {
 }
 
 extern "C" int mdx_abi_version(void) { return MDX_ABI_VERSION; }
+#ifndef MDX_BUILD_ID
+#define MDX_BUILD_ID "unknown"
+#endif
+extern "C" const char* mdx_build_id(void) { return MDX_BUILD_ID; }
 extern "C" const char* mdx_last_error(void) { return error_buffer(); }
 
 extern "C" const char* mdx_last_kernel(void) { return kernel_tag_buffer(); }

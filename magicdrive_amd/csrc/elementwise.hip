@@ -306,6 +306,10 @@ struct DdimParams { float* x; const float* eps; const float* coef; int* step; vo
 __global__ __launch_bounds__(256) void ddim_kernel(DdimParams p) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     const int step = *p.step;
+    if (i < p.n && step < 0) {          // a row index of -1 = "timestep not in the scheduler's list" (DDIMScheduler.step with a device timestep):
+        p.x[i] = __builtin_nanf("");     // poison the result instead of silently using row 0
+        return;
+    }
     if (i < p.n) {
         const float* c = p.coef + 4 * step;
         float e;
@@ -339,7 +343,8 @@ __global__ __launch_bounds__(256) void ddim_kernel(DdimParams p) {
         }
     }
 }
-struct UniPCParams { float* x; const float* eps; const float* coef; int* step; void* x_in; float* x_last; float* m1; float* m2; long n; int cfg; float g; int xin_c, xin_ld; };
+struct UniPCParams { float* x; const float* eps; const float* coef; int* step; void* x_in; float* x_last; float* m1; float* m2; long n; int cfg; float g; int xin_c, xin_ld;
+                     const float* gv_cond; const float* gv_noise; const unsigned char* gv_mask; int gv_mode; long gv_view; int gv_last; };
 
 __global__ __launch_bounds__(256) void unipc_kernel(UniPCParams p) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -353,12 +358,16 @@ __global__ __launch_bounds__(256) void unipc_kernel(UniPCParams p) {
     } else {
         e = p.eps[i];
     }
+    // given views (pipeline_bev_controlnet_given_view.py:263-291, 380-390 under the scheduler build_pipe installs; MdxUniPCDesc.gv_*)
+    const bool given = p.gv_mode != 0 && p.gv_mask[i / p.gv_view] != 0;
+    if (given && p.gv_mode == 2) e = p.gv_noise[i];
     const float x = p.x[i];
     const float m1 = p.m1[i], m2 = p.m2[i];
     const float mt = c[0] * x + c[1] * e;
     float xc = x;
     if (c[2] != 0.f) xc = c[3] * p.x_last[i] + c[4] * m1 + c[5] * m2 + c[6] * mt;
-    const float xn = c[7] * xc + c[8] * mt + c[9] * m1;
+    float xn = c[7] * xc + c[8] * mt + c[9] * m1;
+    if (given && p.gv_mode == 1 && step < p.gv_last) xn = c[10] * p.gv_cond[i] + c[11] * p.gv_noise[i];
     p.x[i] = xn; p.x_last[i] = xc; p.m2[i] = m1; p.m1[i] = mt;
     if (p.x_in) {
         if (p.xin_ld > 0) {
@@ -492,8 +501,11 @@ extern "C" int mdx_cfg_ddim_step(const MdxDdimDesc* d, void* stream) {
 extern "C" int mdx_cfg_unipc_step(const MdxUniPCDesc* d, void* stream) {
     if (!d || !d->x || !d->eps || !d->coef || !d->step_ptr || !d->x_last || !d->m1 || !d->m2)
         return set_error(MDX_EINVAL, "mdx_cfg_unipc_step: null operand");
-    UniPCParams p{d->x, d->eps, d->coef, d->step_ptr, d->x_in, d->x_last, d->m1, d->m2, d->n, (int)d->cfg, (float)d->guidance, (int)d->xin_c, (int)d->xin_ld};
+    UniPCParams p{d->x, d->eps, d->coef, d->step_ptr, d->x_in, d->x_last, d->m1, d->m2, d->n, (int)d->cfg, (float)d->guidance, (int)d->xin_c, (int)d->xin_ld,
+                  d->gv_cond, d->gv_noise, d->gv_mask, d->gv_mask ? (int)d->gv_mode : 0, d->gv_view_elems, (int)d->gv_last_step};
     if (p.xin_ld > 0 && (p.xin_c <= 0 || p.xin_ld < p.xin_c || p.n % p.xin_c)) return set_error(MDX_EINVAL, "unipc: bad x_in channel layout");
+    if (p.gv_mode != 0 && (p.gv_mode < 0 || p.gv_mode > 2 || !p.gv_noise || (p.gv_mode == 1 && !p.gv_cond) || p.gv_view <= 0 || p.n % p.gv_view))
+        return set_error(MDX_EINVAL, "unipc: given-view mode %d needs gv_noise (+ gv_cond for mode 1) and gv_view_elems dividing n", p.gv_mode);
     if (p.n <= 0) return MDX_OK;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(unipc_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);

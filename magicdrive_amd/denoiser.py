@@ -49,12 +49,12 @@ class PlanCache:
     """Small LRU of plans keyed by batch geometry.  A plan owns a 64 MB workspace, its activation pool, K/V and temb tables and a
     captured hipGraph; the reference's validation flow changes the padded box count (and with it the plan key) almost every batch,
     so an unbounded dict would accumulate ~100 plans per batch size.  Evicted plans release their graph and device buffers.
-    Size: MDX_PLAN_CACHE (default 4)."""
+    Size: MDX_PLAN_CACHE (default 6: a multi-stream call holds one plan per scene chunk)."""
 
     def __init__(self, maxsize: Optional[int] = None):
         import os
         from collections import OrderedDict
-        self.maxsize = maxsize if maxsize is not None else max(1, int(os.environ.get("MDX_PLAN_CACHE", "4")))
+        self.maxsize = maxsize if maxsize is not None else max(1, int(os.environ.get("MDX_PLAN_CACHE", "6")))
         self._d = OrderedDict()
 
     def get(self, key):
@@ -261,7 +261,7 @@ class SamplerPlan:
                  scheduler_kind: str = "ddim", given_view_mode: int = 0):
         self.cfg, self.device = cfg, device
         assert scheduler_kind in ("ddim", "unipc")
-        assert given_view_mode in (0, 1, 2) and (given_view_mode == 0 or scheduler_kind == "ddim"), "given views: fused for DDIM only"
+        assert given_view_mode in (0, 1, 2)
         self.scheduler_kind = scheduler_kind
         self.given_view_mode = given_view_mode
         n_cam = len(cfg["neighboring_view_pair"])
@@ -329,8 +329,12 @@ class SamplerPlan:
             bld.emit(O.DdimStep(self.x.view(-1), self.eps.view(-1), self.coef, self.step_ctr, x_in=self.x_in.view(-1, CIN_PAD), cfg=do_cfg,
                                 guidance=guidance_scale, xin_c=Cl, name="cfg+ddim", **gv))
         else:
+            gv = {}
+            if given_view_mode:
+                gv = dict(gv_mask=self.gv_mask, gv_cond=self.gv_cond.view(-1), gv_noise=self.gv_noise.view(-1), gv_mode=given_view_mode,
+                          gv_last_step=num_steps - 1)
             bld.emit(O.UniPCStep(self.x.view(-1), self.eps.view(-1), self.coef, self.step_ctr, self.x_last.view(-1), self.m1.view(-1),
-                                 self.m2.view(-1), x_in=self.x_in.view(-1, CIN_PAD), cfg=do_cfg, guidance=guidance_scale, xin_c=Cl, name="cfg+unipc"))
+                                 self.m2.view(-1), x_in=self.x_in.view(-1, CIN_PAD), cfg=do_cfg, guidance=guidance_scale, xin_c=Cl, name="cfg+unipc", **gv))
         self.step_ops = bld.ops
         bld.ops = []
         self.prologue: Optional[L.Program] = None
@@ -369,7 +373,11 @@ class SamplerPlan:
             self.gv_noise.copy_(xl)                                                  # original_noise (:263)
             self.gv_cond.copy_(given_latents.to(self.device, F32).reshape(b * nc, *latents.shape[2:]).permute(0, 2, 3, 1))
             c0 = coef[0].to(self.device, F32)                                        # add_noise at the first timestep (:265-275, :284-291)
-            xl = torch.where(gm.view(-1, 1, 1, 1), c0[0] * self.gv_cond + c0[1] * self.gv_noise, xl)
+            if self.scheduler_kind == "ddim":
+                a0, s0 = c0[0], c0[1]                                                # DDIM row: sqrt(acp_t), sqrt(1 - acp_t), ...
+            else:
+                a0, s0 = 1.0 / c0[0], -c0[1] / c0[0]                                 # UniPC row: a = 1 / alpha_t, b = -sigma_t / alpha_t
+            xl = torch.where(gm.view(-1, 1, 1, 1), a0 * self.gv_cond + s0 * self.gv_noise, xl)
         else:
             assert given_mask is None, "this plan was built without given views"
         self.x.copy_(xl)
@@ -398,6 +406,11 @@ class SamplerPlan:
 
     def latents(self) -> torch.Tensor:
         return self.x.view(self.b, self.n_cam, self.h, self.w, -1).permute(0, 1, 4, 2, 3).contiguous()
+
+    def latents_on(self, stream) -> torch.Tensor:
+        """latents() as a copy made on `stream` (a torch stream that already waits for this plan's last replay)."""
+        with torch.cuda.stream(stream):
+            return self.latents()
 
 
 class ControlNetPlan:

@@ -57,25 +57,40 @@ def gather_scene_results(local: torch.Tensor, n_scenes: int, rank: int, world: i
 
 
 def device_identity(device) -> str:
-    """A string that differs between physical GPUs of the node (uuid when the runtime reports one, else PCI ids + index)."""
+    """The PHYSICAL identity of a GPU: its PCI location (domain:bus:device), else its uuid; "" when the runtime reports neither.
+    No launcher-assigned index in it: under per-rank HIP_VISIBLE_DEVICES isolation every rank sees index 0, and an index is not a
+    physical identity anyway."""
     pr = torch.cuda.get_device_properties(device)
-    parts = [str(getattr(pr, "uuid", "")), str(getattr(pr, "pci_bus_id", "")), str(getattr(pr, "pci_device_id", "")), str(getattr(pr, "pci_domain_id", ""))]
-    ident = "/".join(parts)
-    if ident.strip("/") == "":
-        ident = f"index{torch.device(device).index}"
-    return ident + f"#{torch.device(device).index}"
+    bus = getattr(pr, "pci_bus_id", None)
+    if bus is not None and str(bus) != "":
+        return f"pci:{getattr(pr, 'pci_domain_id', 0)}:{bus}:{getattr(pr, 'pci_device_id', 0)}"
+    uuid = str(getattr(pr, "uuid", "") or "")
+    return f"uuid:{uuid}" if uuid.strip("0-") else ""
 
 
 def assert_distinct_devices(device, rank: int, world: int) -> int:
     """Every rank must drive its own GPU: gathers device_identity() over the group and returns the number of distinct devices
-    (== world, asserted).  A launcher that put two ranks on one GPU would otherwise print a whole-job number for hardware it did not use."""
+    (== world, asserted).  A launcher that put two ranks on one GPU would otherwise print a whole-job number for hardware it did not use.
+    When the runtime exposes no physical identity at all the check cannot be made: warn and trust the launcher."""
     if world == 1:
         return 1
     ids: List[str] = [None] * world           # type: ignore[list-item]
     dist.all_gather_object(ids, device_identity(device))
+    if any(i == "" for i in ids):
+        import warnings
+        warnings.warn(f"no PCI id / uuid reported for some devices ({ids}): distinct-device check skipped")
+        return world
     n = len(set(ids))
     assert n == world, f"{world} ranks on {n} distinct GPUs: {ids}"
     return n
+
+
+def shutdown():
+    """Leave the process group on EVERY rank at the same point: barrier, then destroy (val_set_gen.py:149-160 ends its distributed part
+    the same way before rank 0 writes results).  No-op for a single process."""
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def barrier():

@@ -71,10 +71,12 @@ def arch_config_from_json(js: Dict, base: Optional[Dict] = None) -> Dict:
         # false (configs/model/SDv1.5mv_rawbox.yaml:56).  A config that omits the key means the class default.
         cn["bbox"]["minmax_normalize"] = bool(bp.get("minmax_normalize", True))
         # the class default is mode='cxyz' (4 points, bbox_embedder.py:41); the shipped config sets all-xyz (8 corners,
-        # configs/model/SDv1.5mv_rawbox.yaml:54), which is what the plan, the conditioning buffers and the input marshalling build
+        # configs/model/SDv1.5mv_rawbox.yaml:54); both are the same prologue ops with a different point count (bbox_embedder.py:52-57)
         mode = bp.get("mode", "cxyz")
-        if mode != "all-xyz":
-            raise NotImplementedError(f"bbox_embedder mode={mode!r}: only 'all-xyz' (8 corners) is built; 'cxyz' checkpoints would fail later on a shape mismatch")
+        if mode not in ("all-xyz", "cxyz"):
+            raise NotImplementedError(f"bbox_embedder mode={mode!r}")        # 'owhr' raises in the reference too (bbox_embedder.py:58-59)
+        cn["bbox"]["mode"] = mode
+        cn["bbox"]["n_corners"] = 8 if mode == "all-xyz" else 4
     # classifier-free-guidance map substitution (unet_addon_rawbox.py:188-202, 674-677): an `uncond_map` buffer exists in the
     # checkpoint only when use_uncond_map is set AND drop_cond_ratio > 0
     um, dr = js.get("use_uncond_map"), js.get("drop_cond_ratio", 0.0) or 0.0

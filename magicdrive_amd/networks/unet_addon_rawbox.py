@@ -41,7 +41,8 @@ class BEVControlNetModel(MdxModel):
                   cam_embedder_param=dict(input_dims=3, num_freqs=cn["cam_embedder_num_freqs"], include_input=True, log_sampling=True),
                   bbox_embedder_param=dict(n_classes=cn["bbox"]["n_classes"], class_token_dim=cn["bbox"]["class_token_dim"],
                                            embedder_num_freq=cn["bbox"]["embedder_num_freq"], proj_dims=list(cn["bbox"]["proj_dims"]),
-                                           minmax_normalize=bool(cn["bbox"].get("minmax_normalize", False)), mode="all-xyz"))
+                                           minmax_normalize=bool(cn["bbox"].get("minmax_normalize", False)),
+                                           mode=cn["bbox"].get("mode", "all-xyz")))
         if cn.get("use_uncond_map"):
             js.update(use_uncond_map=cn["use_uncond_map"], drop_cond_ratio=float(cn.get("drop_cond_ratio") or 0.25))
         if cn.get("map_embedder_cls"):
@@ -71,7 +72,7 @@ class BEVControlNetModel(MdxModel):
             if max_len is not None:
                 dev = camera_param.device
                 ret["bboxes_3d_data"] = {
-                    "bboxes": torch.zeros([batch_size * 2, n_cam, max_len, 8, 3], device=dev),
+                    "bboxes": torch.zeros([batch_size * 2, n_cam, max_len, self.cfg["controlnet"]["bbox"].get("n_corners", 8), 3], device=dev),
                     "classes": torch.zeros([batch_size * 2, n_cam, max_len], device=dev, dtype=torch.long),
                     "masks": torch.zeros([batch_size * 2, n_cam, max_len], device=dev, dtype=torch.bool)}
             else:

@@ -503,6 +503,12 @@ class UniPCStep:
     guidance: float = 1.0
     xin_c: int = 0
     name: str = ""
+    # given views (MdxUniPCDesc.gv_*): as in DdimStep
+    gv_mask: Optional[torch.Tensor] = None
+    gv_cond: Optional[torch.Tensor] = None
+    gv_noise: Optional[torch.Tensor] = None
+    gv_mode: int = 0
+    gv_last_step: int = 0
     opcode = L.OP_UNIPC
 
     def lower(self):
@@ -519,6 +525,14 @@ class UniPCStep:
                 _chk(self.x_in.dtype in H16 and self.x_in.dim() == 2 and self.xin_c > 0 and self.x_in.shape[0] * self.xin_c == self.eps.numel(), "unipc: bf16 x_in")
                 d.xin_c, d.xin_ld = self.xin_c, self.x_in.shape[1]
         d.n, d.cfg, d.guidance = n, int(self.cfg), float(self.guidance)
+        if self.gv_mode:
+            _chk(self.gv_mode in (1, 2) and self.gv_mask is not None and self.gv_mask.dtype == torch.uint8 and self.gv_mask.is_contiguous()
+                 and n % self.gv_mask.numel() == 0, "unipc: given-view mask")
+            _chk(self.gv_noise is not None and self.gv_noise.dtype == F32 and self.gv_noise.is_contiguous() and self.gv_noise.numel() == n, "unipc: gv_noise")
+            _chk(self.gv_mode == 2 or (self.gv_cond is not None and self.gv_cond.dtype == F32 and self.gv_cond.is_contiguous()
+                                       and self.gv_cond.numel() == n), "unipc: gv_cond")
+            d.gv_mask, d.gv_noise, d.gv_cond = _p(self.gv_mask), _p(self.gv_noise), _p(self.gv_cond)
+            d.gv_mode, d.gv_view_elems, d.gv_last_step = self.gv_mode, n // self.gv_mask.numel(), self.gv_last_step
         return self.opcode, d
 
 

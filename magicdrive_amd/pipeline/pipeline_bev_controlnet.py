@@ -59,6 +59,11 @@ class StableDiffusionBEVControlNetPipeline:
         # the cache is a small LRU and an evicted plan releases its graph and buffers.
         self._plans = PlanCache()
         self.use_graph = True
+        # Scene chunks replayed concurrently on separate HIP streams (see __call__): MDX_STREAMS overrides; chunks hold at least
+        # `min_scenes_per_stream` scenes (below that a launch has too few tiles to fill the chip even alone).
+        self.streams = max(1, int(os.environ.get("MDX_STREAMS", "1")))
+        self.min_scenes_per_stream = 16
+        self._side: Dict[Any, List[Any]] = {}
 
     # ---- construction / housekeeping the reference's callers use (misc/test_utils.py:94-138) ----
     @classmethod
@@ -99,6 +104,13 @@ class StableDiffusionBEVControlNetPipeline:
                 m.to(self._device)
         self._plans.clear()
         return self
+
+    def _side_streams(self, device, n: int):
+        """`n` extra HIP streams on `device`, created once per pipeline."""
+        have = self._side.setdefault(str(device), [])
+        while len(have) < n:
+            have.append(torch.cuda.Stream(device=device))
+        return have[:n]
 
     @property
     def device(self):
@@ -212,6 +224,8 @@ class StableDiffusionBEVControlNetPipeline:
         """`_given_view` = (conditional_latents, change_every_input) is how StableDiffusionBEVControlNetGivenViewPipeline reuses
         this body; not part of the reference signature."""
         if guess_mode:
+            # the reference's own guess path cannot run either: under CFG it feeds the ControlNet 5-D `latents` with a 2x-batched camera_param
+            # and the un-repeated prompt (pipeline_bev_controlnet.py:366-373) — refused rather than guessed at
             raise NotImplementedError("guess_mode is outside the built hot path")
         if cross_attention_kwargs:
             # the reference forwards these to the UNet's attention processors (:420); the fused attention has no such hooks — refuse,
@@ -266,16 +280,14 @@ class StableDiffusionBEVControlNetPipeline:
             uncond_image = torch.zeros_like(image) if use_zero_map_as_unconditional else kw["image"]
             image = torch.cat([uncond_image, image])
             text = torch.cat([negative_prompt_embeds.to(device), prompt_embeds.to(device)])
-        elif boxes is not None and bbox_max_length is not None and boxes["bboxes"].shape[2] < bbox_max_length:
-            raise NotImplementedError("bbox_max_length padding without CFG")
+        # without CFG the reference never looks at bbox_max_length: the padding lives inside add_uncond_to_kwargs, which only the CFG branch
+        # calls (pipeline_bev_controlnet.py:330-343) — ignored here too
         L_box = 0 if boxes is None else int(boxes["bboxes"].shape[2])
         h, w = latents.shape[-2:]
         n_steps = len(timesteps)
         gv_mode, gv_mask, gv_lat = 0, None, None
         if _given_view is not None:
             cond_lat, every_input = _given_view
-            if sched_kind != "ddim":
-                raise NotImplementedError("given views are fused into the DDIM step only")
             assert len(cond_lat) == b and all(len(r) == n_cam for r in cond_lat), "conditional_latents must be a B x N_cam list"
             gv_mode = 1 if every_input else 2
             gv_mask = torch.tensor([[v is not None for v in r] for r in cond_lat], dtype=torch.bool)
@@ -284,35 +296,75 @@ class StableDiffusionBEVControlNetPipeline:
                 for j, v in enumerate(r):
                     if v is not None:
                         gv_lat[i, j] = v.to(device, torch.float32)
-        key = (b, do_cfg, L_box, h, w, n_steps, float(guidance_scale), float(controlnet_conditioning_scale), text.shape[1], sched_kind, gv_mode)
-        plan = self._plans.get(key)
-        if plan is None:
-            with torch.cuda.device(device):
-                # the UNet's config.json knows nothing about the conditioning encoders: their geometry (box MLP widths, map embedder
-                # class / size, camera frequencies) is the ControlNet checkpoint's (a tiny or a 272x736 `...Plus` checkpoint loaded with
-                # from_pretrained would otherwise be planned with the SD-1.5 defaults)
-                plan_cfg = self._plan_config()
-                plan = SamplerPlan(plan_cfg, self.unet.packed(), self.controlnet.packed(), device, b, do_cfg, L_box, (h, w),
-                                   num_steps=n_steps, guidance_scale=guidance_scale,
-                                   conditioning_scale=float(controlnet_conditioning_scale), n_text=text.shape[1], scheduler_kind=sched_kind,
-                                   given_view_mode=gv_mode)
-                plan.compile()
-            self._plans.put(key, plan)
-        plan.load_inputs(latents, camera_param, text, image, boxes, timesteps, self.scheduler.coefficient_table(),
-                         given_mask=gv_mask, given_latents=gv_lat)
+        # ---- scene chunks: `self.streams` HIP streams, each replaying its own plan over a contiguous share of the scenes -------------
+        # Scenes are independent (cross-view attention couples only the cameras of one scene, the CFG halves of a scene stay together),
+        # and every kernel of a step owns whole CUs: on ONE stream the tail of each launch (the last partial round of tiles) and the
+        # boundary between two launches leave CUs idle ~620 times per step.  Two half-batch graph replays in flight on two streams
+        # fill those gaps with the other half's kernels (profiles/r04_streams_ab.log).  Callbacks need the whole
+        # batch at a step boundary, so they keep the single-stream path.
+        n_chunk = 1
+        if self.streams > 1 and callback is None and b >= 2 * self.min_scenes_per_stream:
+            n_chunk = min(int(self.streams), b // self.min_scenes_per_stream)
+        bounds = [(b * i) // n_chunk for i in range(n_chunk + 1)]
+        c_halves = 2 if do_cfg else 1
+
+        def rows(t, s0, s1):      # rows of scenes [s0, s1) of a tensor that holds the [uncond | cond] halves when CFG is on
+            if t is None or n_chunk == 1:
+                return t
+            return torch.cat([t[hf * b + s0:hf * b + s1] for hf in range(c_halves)]) if c_halves == 2 else t[s0:s1]
+
+        pdt = self.unet.packed().dtype
+        plans = []
+        for ci in range(n_chunk):
+            s0, s1 = bounds[ci], bounds[ci + 1]
+            # the packed nets' identity and 16-bit type are part of the key: `pipe.unet.to(torch.float16)` re-packs the weights, and a plan
+            # built on the old PackedNet would keep running (and keep alive) the old ones
+            key = (s1 - s0, ci, do_cfg, L_box, h, w, n_steps, float(guidance_scale), float(controlnet_conditioning_scale), text.shape[1], sched_kind,
+                   gv_mode, pdt, id(self.unet.packed()), id(self.controlnet.packed()))
+            plan = self._plans.get(key)
+            if plan is None:
+                with torch.cuda.device(device):
+                    # the UNet's config.json knows nothing about the conditioning encoders: their geometry (box MLP widths, map embedder
+                    # class / size, camera frequencies) is the ControlNet checkpoint's (a tiny or a 272x736 `...Plus` checkpoint loaded with
+                    # from_pretrained would otherwise be planned with the SD-1.5 defaults)
+                    plan_cfg = self._plan_config()
+                    plan = SamplerPlan(plan_cfg, self.unet.packed(), self.controlnet.packed(), device, s1 - s0, do_cfg, L_box, (h, w),
+                                       num_steps=n_steps, guidance_scale=guidance_scale,
+                                       conditioning_scale=float(controlnet_conditioning_scale), n_text=text.shape[1], scheduler_kind=sched_kind,
+                                       given_view_mode=gv_mode)
+                    plan.compile()
+                self._plans.put(key, plan)
+            plan.load_inputs(latents[s0:s1], rows(camera_param, s0, s1), rows(text, s0, s1), rows(image, s0, s1),
+                             None if boxes is None else {k: rows(v, s0, s1) for k, v in boxes.items()}, timesteps,
+                             self.scheduler.coefficient_table(), given_mask=None if gv_mask is None else gv_mask[s0:s1],
+                             given_latents=None if gv_lat is None else gv_lat[s0:s1])
+            plans.append(plan)
         with torch.cuda.device(device):                       # launches, graph replays and torch copies all target the pipeline's device
-            st = device_stream(device)
-            plan.prologue.run(st)
+            main = torch.cuda.current_stream(device)
+            side = self._side_streams(device, n_chunk - 1)
+            if side:
+                ready = torch.cuda.Event()
+                ready.record(main)                            # the inputs were loaded on the caller's stream
+                for s_ in side:
+                    s_.wait_event(ready)
+            sts = [main.cuda_stream] + [s_.cuda_stream for s_ in side]
+            for plan, st in zip(plans, sts):
+                plan.prologue.run(st)
             with self.progress_bar(total=num_inference_steps) as bar:
                 for i, t in enumerate(timesteps):
-                    if self.use_graph:
-                        plan.step.launch(st)
-                    else:
-                        plan.step.run(st)
+                    for plan, st in zip(plans, sts):
+                        if self.use_graph:
+                            plan.step.launch(st)
+                        else:
+                            plan.step.run(st)
                     bar.update()
                     if callback is not None and i % callback_steps == 0:
-                        callback(i, t, plan.latents().to(prompt_embeds.dtype))
-            latents = plan.latents().to(prompt_embeds.dtype)
+                        callback(i, t, plans[0].latents().to(prompt_embeds.dtype))
+            for s_ in side:                                   # the caller's stream owns the result: join the side streams into it
+                done = torch.cuda.Event()
+                done.record(s_)
+                main.wait_event(done)
+            latents = (plans[0].latents() if n_chunk == 1 else torch.cat([pl.latents_on(main) for pl in plans])).to(prompt_embeds.dtype)
         if output_type == "latent":
             out, nsfw = latents, None
         else:

@@ -126,12 +126,13 @@ class DDIMScheduler:
         if coef is None:
             coef = self._table_dev[dev] = tab.to(dev)
         if isinstance(timestep, torch.Tensor) and timestep.is_cuda:
-            # no host round trip: the row index is computed on the device (argmax of the match mask; a timestep that is not in the list
-            # cannot be detected without a sync and selects row 0 — host timesteps below are validated)
+            # no host round trip: the row index is computed on the device (argmax of the match mask).  A timestep that is not in the list
+            # cannot raise without a sync: its row index becomes -1 and the kernel writes NaN (a loud miss; host timesteps below raise)
             ts_dev = self._table_dev.get(("timesteps", dev))
             if ts_dev is None:
                 ts_dev = self._table_dev[("timesteps", dev)] = self.timesteps.to(dev, torch.int64)
-            step = (ts_dev == timestep.reshape(-1)[0].to(torch.int64)).to(torch.int32).argmax().reshape(1).to(torch.int32)
+            hit = ts_dev == timestep.reshape(-1)[0].to(torch.int64)
+            step = torch.where(hit.any(), hit.to(torch.int32).argmax(), torch.full((), -1, device=dev, dtype=torch.int64)).reshape(1).to(torch.int32)
         else:
             hits = (self.timesteps == int(timestep)).nonzero()
             if hits.numel() == 0:
@@ -245,7 +246,9 @@ class UniPCMultistepScheduler:
         return h_phi_1, B_h, rks[:-1], rhos
 
     def coefficient_table(self) -> torch.Tensor:
-        """fp32 [n_steps, 12] = {a, b, corr, cl, c1, c2, ct, px, pt, p1, 0, 0} (see mdx_cfg_unipc_step in include/mdx.h)."""
+        """fp32 [n_steps, 12] = {a, b, corr, cl, c1, c2, ct, px, pt, p1, an, sn} (see mdx_cfg_unipc_step in include/mdx.h); (an, sn) =
+        (alpha, sigma) of the NEXT timestep: add_noise(cond, noise, t) = alpha_t cond + sigma_t noise (scheduling_unipc_multistep.py
+        add_noise), what the given-view pipeline re-noises its known views with at the top of the next iteration."""
         ts = [int(t) for t in self.timesteps.tolist()]
         n = len(ts)
         al, sg = self.alpha_t, self.sigma_t
@@ -274,11 +277,20 @@ class UniPCMultistepScheduler:
             px = float(sg[prev_t]) / float(sg[t])
             p1 = -ap * B_h * rhos[0] / rks[0] if this_order == 2 else 0.0
             pt = -ap * h_phi_1 - p1
-            rows.append([a, bcoef, 1.0 if corr else 0.0, cl, c1, c2, ct, px, pt, p1, 0.0, 0.0])
+            an, sn = (float(al[ts[i + 1]]), float(sg[ts[i + 1]])) if i + 1 < n else (0.0, 0.0)
+            rows.append([a, bcoef, 1.0 if corr else 0.0, cl, c1, c2, ct, px, pt, p1, an, sn])
             prev_order = this_order
             if lower_order_nums < self.solver_order:
                 lower_order_nums += 1
         return torch.tensor(rows, dtype=torch.float64).to(torch.float32)
+
+    def add_noise(self, original_samples: torch.Tensor, noise: torch.Tensor, timesteps) -> torch.Tensor:
+        """scheduling_unipc_multistep.py add_noise: sqrt(acp_t) x0 + sqrt(1 - acp_t) noise (torch arithmetic on the caller's tensors)."""
+        t = torch.as_tensor(timesteps).reshape(-1).long().cpu()
+        shape = (-1,) + (1,) * (original_samples.dim() - 1)
+        a = self.alpha_t[t].to(original_samples.device, original_samples.dtype).reshape(shape)
+        sg = self.sigma_t[t].to(original_samples.device, original_samples.dtype).reshape(shape)
+        return a * original_samples + sg * noise
 
     def step(self, model_output, timestep, sample, return_dict: bool = True):
         raise NotImplementedError("UniPC keeps multistep state on the device: it runs inside StableDiffusionBEVControlNetPipeline.__call__ "

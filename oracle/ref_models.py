@@ -33,7 +33,8 @@ def build_reference(cfg, unet_sd, cn_sd, img_size=(224, 400)):
         bbox_embedder_cls="magicdrive.networks.bbox_embedder.ContinuousBBoxWithTextEmbedding",
         bbox_embedder_param=dict(n_classes=bb["n_classes"], class_token_dim=bb["class_token_dim"], trainable_class_token=False,
                                  use_text_encoder_init=False, embedder_num_freq=bb["embedder_num_freq"],
-                                 proj_dims=list(bb["proj_dims"]), mode="all-xyz", minmax_normalize=False))
+                                 proj_dims=list(bb["proj_dims"]), mode=bb.get("mode", "all-xyz"),
+                                 minmax_normalize=bool(bb.get("minmax_normalize", False))))
     unet.load_state_dict(unet_sd, strict=True)
     cnet.load_state_dict(cn_sd, strict=True)
     return ns, unet.eval(), cnet.eval()

@@ -199,10 +199,17 @@ def run_unipc(op: O.UniPCStep):
     n = op.x.numel()
     c = op.coef[int(op.step.item())]
     e = op.eps[:n] + op.guidance * (op.eps[n:] - op.eps[:n]) if op.cfg else op.eps
+    given = None
+    if op.gv_mode:
+        given = op.gv_mask.bool().repeat_interleave(n // op.gv_mask.numel())
+        if op.gv_mode == 2:
+            e = torch.where(given, op.gv_noise, e)
     x = op.x.clone(); m1 = op.m1.clone(); m2 = op.m2.clone()
     mt = c[0] * x + c[1] * e
     xc = c[3] * op.x_last + c[4] * m1 + c[5] * m2 + c[6] * mt if c[2] != 0 else x
     xn = c[7] * xc + c[8] * mt + c[9] * m1
+    if op.gv_mode == 1 and int(op.step.item()) < op.gv_last_step:
+        xn = torch.where(given, c[10] * op.gv_cond + c[11] * op.gv_noise, xn)
     op.x.copy_(xn); op.x_last.copy_(xc); op.m2.copy_(m1); op.m1.copy_(mt)
     if op.x_in is not None:
         if op.x_in.dtype == torch.float32:

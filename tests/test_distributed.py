@@ -96,3 +96,32 @@ def test_gather_two_ranks_nccl():
         assert p.exitcode == 0
     for rank, same, t, n_dev in res:
         assert same and t == 2.0 and n_dev == 2, (rank, same, t, n_dev)
+
+
+def test_bench_two_ranks_gloo_prints_one_json_line(tmp_path):
+    """`bench.py --gpus 2` end to end under torch.distributed.run with the gloo backend and a stubbed pipeline
+    (tests/bench_stub.py through bench.py's --pipe-factory hook): both ranks exit 0, exactly ONE JSON line is printed (by rank 0, after
+    every rank has left the process group), it claims 2 ranks and the whole-job rate, and the side measurements are skipped for N > 1."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--scenes-per-gpu", "3", "--pipe-factory", "bench_stub:make"]
+    cmd = bench.launcher_command(2, argv, port)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, os.path.join(root, "tests"), os.environ.get("PYTHONPATH", "")]),
+               CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS="2")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["scenes_per_gpu"] == 3 and out["config"]["parallelism"] == "scene-sharded x2"
+    assert out["value"] > 0 and abs(out["value"] - 6 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]      # whole-job scenes / max-over-ranks time
+    assert out["config"]["full_cond_scenes_per_s"] is None and out["config"]["hires"] is None and "cpu_baseline" not in out

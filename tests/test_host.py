@@ -315,7 +315,9 @@ def test_config_keys_that_change_samples_are_honoured_or_refused(tmp_path):
     json.dump(js_dr, open(tmp_path / "cn_um" / "config.json", "w"))
     BEVControlNetModel.from_pretrained(str(tmp_path / "cn_um")).save_pretrained(str(tmp_path / "cn_um2"))
     assert json.load(open(tmp_path / "cn_um2" / "config.json"))["drop_cond_ratio"] == 0.4
-    # bbox_embedder mode: only all-xyz (8 corners) is built; the class default when the key is absent is cxyz (bbox_embedder.py:41)
+    # bbox_embedder mode: the class default when the key is absent is cxyz (bbox_embedder.py:41): 4 points.  THIS checkpoint holds 8-corner
+    # tensors, so a config that says (or defaults to) cxyz fails on the shape check — what load_state_dict does in the reference; a real
+    # cxyz checkpoint loads (test_cxyz_config_roundtrip_and_bbox_max_length_without_cfg)
     for bad_mode in ("cxyz", None):
         jsm = json.loads(json.dumps(js))
         if bad_mode is None:
@@ -323,7 +325,7 @@ def test_config_keys_that_change_samples_are_honoured_or_refused(tmp_path):
         else:
             jsm["bbox_embedder_param"]["mode"] = bad_mode
         json.dump(jsm, open(p, "w"))
-        with pytest.raises(NotImplementedError):
+        with pytest.raises(ValueError, match="null_pos_feature|bbox_proj"):
             BEVControlNetModel.from_pretrained(str(tmp_path / "cn"))
     js4 = json.loads(json.dumps(js)); js4.update(use_uncond_map="bogus", drop_cond_ratio=0.25)
     json.dump(js4, open(p, "w"))
@@ -376,3 +378,106 @@ def test_plan_cache_is_a_small_lru_that_releases_evicted_plans():
     assert released == [2] and "a" in c and "c" in c and "b" not in c and len(c) == 2
     c.clear()
     assert sorted(released) == [1, 2, 3] and len(c) == 0
+
+
+# ---- round 4: the given-view demo's call sequence, UniPC re-noising coefficients, cxyz configs, scene chunks ---------------------------
+def test_run_cond_on_view_call_sequence_replayed(tmp_path):
+    """demo/run_cond_on_view.py:131-146 (re-pointing `cfg.model.pipe_module` at the given-view pipeline, then `prepare_all` -> build_pipe with
+    its UniPC swap) and :88-110 (`pipe(prompt=, image=, camera_param=, height=, width=, conditional_latents=, generator=,
+    bev_controlnet_kwargs=, **cfg.runner.pipeline_param)`), replayed against a tiny checkpoint.  There is no GPU in this test, so the
+    call itself must stop at the device check — AFTER accepting the scheduler and every keyword of configs/runner/default.yaml:54-61
+    (round 3 raised NotImplementedError for given views under UniPC); the arithmetic of that path is tests/test_plan_cpu.py::
+    test_given_view_unipc_sampler_plan_matches_golden (CPU) and tests/test_e2e_gpu.py::test_given_view_unipc_pipeline_matches_reference_golden."""
+    import inspect
+    tcfg = spec.TINY_CONFIG
+    ckpt = tmp_path / "ckpt"
+    UNet2DConditionModelMultiview.from_config(tcfg, seed=0).save_pretrained(str(ckpt / "unet"))
+    BEVControlNetModel.from_config(tcfg, seed=1).save_pretrained(str(ckpt / "controlnet"))
+    _write_sd15_dir(tmp_path / "sd15")
+    pipe_module = "magicdrive_amd.pipeline.pipeline_bev_controlnet.StableDiffusionBEVControlNetPipeline"
+    assert pipe_module.endswith("pipeline_bev_controlnet.StableDiffusionBEVControlNetPipeline")          # the demo's own assert (:136)
+    pipe_module = pipe_module.replace("pipeline_bev_controlnet.StableDiffusionBEVControlNetPipeline",
+                                      "pipeline_bev_controlnet_given_view.StableDiffusionBEVControlNetGivenViewPipeline")
+    pipe_cls = load_module(pipe_module)
+    controlnet = BEVControlNetModel.from_pretrained(str(ckpt / "controlnet"), torch_dtype=torch.float16); controlnet.eval()
+    unet = UNet2DConditionModelMultiview.from_pretrained(str(ckpt / "unet"), torch_dtype=torch.float16); unet.eval()
+    pipe = pipe_cls.from_pretrained(str(tmp_path / "sd15"), controlnet=controlnet, unet=unet, safety_checker=None, feature_extractor=None,
+                                    torch_dtype=torch.float16)
+    pipe.scheduler = schedulers.UniPCMultistepScheduler.from_config(pipe.scheduler.config)               # misc/test_utils.py:129
+    pipe.enable_xformers_memory_efficient_attention()
+    pipe = pipe.to("cpu")
+    # the reference signature of the given-view __call__ (pipeline_bev_controlnet_given_view.py:26-58), positional order included
+    params = list(inspect.signature(pipe.__call__).parameters)
+    assert params[:7] == ["prompt", "image", "camera_param", "height", "width", "conditional_latents", "conditional_latents_change_every_input"]
+    pipeline_param = dict(guidance_scale=2, num_inference_steps=20, eta=0.0, controlnet_conditioning_scale=1.0, guess_mode=False,
+                          use_zero_map_as_unconditional=False, bbox_max_length=None)                     # configs/runner/default.yaml:54-61
+    assert set(pipeline_param) <= set(params)
+    sc = synthetic.make_scene_batch(1, ctx_dim=tcfg["cross_attention_dim"], max_len=5)
+    n_cam = 6
+    conditional_latents = [[None] * n_cam]
+    conditional_latents[0][0] = torch.zeros(4, 28, 50)          # stands in for vae.encode(pixel_values).latent_dist.mean * scaling_factor (:79-86; the VAE ENCODER is outside the built path)
+    with pytest.raises(RuntimeError, match="cuda"):             # every argument accepted; the sampler itself has no CPU path
+        pipe(prompt=None, image=sc["bev_map"], camera_param=sc["camera_param"], height=224, width=400, conditional_latents=conditional_latents,
+             generator=torch.manual_seed(0), bev_controlnet_kwargs={"bboxes_3d_data": sc["bboxes_3d_data"]}, prompt_embeds=sc["prompt_embeds"],
+             negative_prompt_embeds=sc["negative_prompt_embeds"], **pipeline_param)
+    # the re-noising the loop applies is the scheduler's own add_noise (scheduling_unipc_multistep.py add_noise / scheduling_ddim.py:470-492)
+    sch = pipe.scheduler
+    ts = sch.set_timesteps(20)
+    x0, nz = torch.randn(2, 4, 7, 9), torch.randn(2, 4, 7, 9)
+    acp = torch.cumprod(1.0 - torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000) ** 2, 0).double()
+    for t in (int(ts[0]), int(ts[7])):
+        want = acp[t].sqrt() * x0.double() + (1 - acp[t]).sqrt() * nz.double()
+        assert torch.allclose(sch.add_noise(x0, nz, torch.tensor([t])).double(), want, atol=1e-6)
+    tab = sch.coefficient_table()
+    for i in range(len(ts) - 1):                                 # row i carries (alpha, sigma) of timestep i + 1: the given views' next model input
+        t1 = int(ts[i + 1])
+        assert abs(float(tab[i, 10]) - float(acp[t1].sqrt())) < 1e-6 and abs(float(tab[i, 11]) - float((1 - acp[t1]).sqrt())) < 1e-6
+    assert float(tab[-1, 10]) == 0.0 and float(tab[-1, 11]) == 0.0
+    # row 0 also yields add_noise at the FIRST timestep the way SamplerPlan.load_inputs derives it: alpha = 1 / a, sigma = -b / a
+    assert abs(1.0 / float(tab[0, 0]) - float(acp[int(ts[0])].sqrt())) < 1e-6 and abs(-float(tab[0, 1]) / float(tab[0, 0]) - float((1 - acp[int(ts[0])]).sqrt())) < 1e-5
+
+
+def test_cxyz_config_roundtrip_and_bbox_max_length_without_cfg(tmp_path):
+    """(1) A ControlNet checkpoint whose bbox_embedder_param says mode='cxyz' — or omits the key: the reference CLASS default
+    (bbox_embedder.py:41) — loads with 4-point box inputs (round 3 refused it) and writes the mode back; 'owhr' raises like the reference
+    (bbox_embedder.py:58-59).  (2) `bbox_max_length` without classifier-free guidance is ignored, as in the reference, where the padding
+    lives inside add_uncond_to_kwargs and only the CFG branch calls it (pipeline_bev_controlnet.py:330-343)."""
+    import copy
+    import json
+    cfg = copy.deepcopy(spec.TINY_CONFIG)
+    cfg["controlnet"]["bbox"].update(mode="cxyz", n_corners=4, minmax_normalize=True)
+    cn = BEVControlNetModel.from_config(cfg, seed=1)
+    cn.save_pretrained(str(tmp_path / "cn"))
+    with open(tmp_path / "cn" / "config.json") as f:
+        js = json.load(f)
+    assert js["bbox_embedder_param"]["mode"] == "cxyz"
+    back = BEVControlNetModel.from_pretrained(str(tmp_path / "cn"))
+    assert back.cfg["controlnet"]["bbox"]["n_corners"] == 4 and back.state_dict()["bbox_embedder.bbox_proj.weight"].shape[1] == 4 * 27
+    del js["bbox_embedder_param"]["mode"]                        # key omitted -> class default cxyz
+    with open(tmp_path / "cn" / "config.json", "w") as f:
+        json.dump(js, f)
+    assert BEVControlNetModel.from_pretrained(str(tmp_path / "cn")).cfg["controlnet"]["bbox"]["mode"] == "cxyz"
+    js["bbox_embedder_param"]["mode"] = "owhr"
+    with open(tmp_path / "cn" / "config.json", "w") as f:
+        json.dump(js, f)
+    with pytest.raises(NotImplementedError):
+        BEVControlNetModel.from_pretrained(str(tmp_path / "cn"))
+    # CFG padding of absent boxes uses the mode's point count
+    kw = cn.add_uncond_to_kwargs(camera_param=torch.zeros(1, 6, 3, 7), bboxes_3d_data=None, image=torch.zeros(1, 8, 200, 200), max_len=3)
+    assert tuple(kw["bboxes_3d_data"]["bboxes"].shape) == (2, 6, 3, 4, 3)
+    # (2): source-level contract — the pipeline no longer refuses bbox_max_length when guidance is off
+    import inspect
+    src = inspect.getsource(StableDiffusionBEVControlNetPipeline.__call__)
+    assert "bbox_max_length padding without CFG" not in src
+
+
+def test_scene_chunk_rows_keep_cfg_halves_together():
+    """pipeline.streams > 1: a chunk of scenes [s0, s1) takes rows [s0, s1) of BOTH halves of every [uncond | cond] tensor
+    (the same expression as StableDiffusionBEVControlNetPipeline.__call__: rows())."""
+    b, c_halves = 5, 2
+    t = torch.arange(2 * b).view(2 * b, 1)
+    bounds = [(b * i) // 2 for i in range(3)]
+    got = [torch.cat([t[hf * b + s0:hf * b + s1] for hf in range(c_halves)]) for s0, s1 in zip(bounds[:-1], bounds[1:])]
+    assert got[0].flatten().tolist() == [0, 1, 5, 6] and got[1].flatten().tolist() == [2, 3, 4, 7, 8, 9]
+    src = __import__("inspect").getsource(StableDiffusionBEVControlNetPipeline.__call__)
+    assert "t[hf * b + s0:hf * b + s1] for hf in range(c_halves)" in src

@@ -26,6 +26,14 @@ Fixtures
 
 `python tools/make_golden.py unipc` / `... hires` / `... given` / `... vae` / `... nattn` regenerate only that fixture.
 
+Round 4:
+  tiny_pipeline_given_view_unipc.pt `... givenunipc`  the given-view pipeline with UniPC — the scheduler demo/run_cond_on_view.py's
+                    build_pipe installs — 6 steps, both re-noising modes.
+  tiny_forward_cxyz.pt `... cxyz`   bbox_embedder mode='cxyz' (the reference class default: 4 points per box), module forwards.
+  sd15_loop_given_view.pt `... sd15given`  SD-1.5 size, REAL reference given-view pipeline, camera + 32 boxes + map, CFG 2.0, 10 DDIM
+                    steps, views 0 and 3 given: the headline-size loop whose views genuinely differ.
+  `... cpuref` writes profiles/r04_cpu_reference_vs_port.json (reference vs CPU port seconds per denoise step, same threads).
+
 SD-1.5-SIZE fixtures (round 3; the REAL reference at spec.SD15_CONFIG, fp32 arithmetic on the bf16-rounded seeded weights — the
 weights the HIP model holds — so that the fixture measures arithmetic, not weight rounding; 8 host threads, minutes each):
   sd15_loop50.pt    `... sd15`      BASELINE configs[1]: reference pipeline __call__ (pipeline_bev_controlnet.py:349-451), 1 scene,
@@ -79,20 +87,134 @@ def given_view_inputs(hw=(28, 50)):
     return cl
 
 
-def given_view_fixture(out_dir, cfg, usd, csd, meta, hw=(28, 50)):
-    ns, pipe = ref_models.build_reference_pipeline(cfg, usd, csd, given_view=True)
+def given_view_fixture(out_dir, cfg, usd, csd, meta, hw=(28, 50), scheduler="ddim"):
+    """scheduler="unipc": what demo/run_cond_on_view.py really runs (build_pipe installs UniPC, misc/test_utils.py:129), 6 steps so that
+    the warm-up, order-2 and lower-order-final updates all occur beside the per-step re-noising."""
+    ns, pipe = ref_models.build_reference_pipeline(cfg, usd, csd, given_view=True, scheduler=scheduler)
     sc = scene(cfg, 2, 5, hw)
+    steps = 5 if scheduler == "ddim" else 6
     outs = {}
     with torch.no_grad():
         for every in (True, False):
             outs[every] = pipe(prompt=None, image=sc["bev_map"], camera_param=sc["camera_param"], height=224, width=400,
                                conditional_latents=given_view_inputs(hw), conditional_latents_change_every_input=every,
-                               num_inference_steps=5, guidance_scale=2.0, latents=sc["latents"].clone(), prompt_embeds=sc["prompt_embeds"],
+                               num_inference_steps=steps, guidance_scale=2.0, latents=sc["latents"].clone(), prompt_embeds=sc["prompt_embeds"],
                                negative_prompt_embeds=sc["negative_prompt_embeds"], output_type="latent",
                                bev_controlnet_kwargs={"bboxes_3d_data": sc["bboxes_3d_data"]}).images
-    torch.save({"meta": meta, "steps": 5, "guidance": 2.0, "latents_every": outs[True].clone(), "latents_once": outs[False].clone()},
-               os.path.join(out_dir, "tiny_pipeline_given_view.pt"))
-    print("tiny_pipeline_given_view: |x|", outs[True].abs().mean().item(), outs[False].abs().mean().item())
+    name = "tiny_pipeline_given_view.pt" if scheduler == "ddim" else "tiny_pipeline_given_view_unipc.pt"
+    torch.save({"meta": meta, "steps": steps, "guidance": 2.0, "scheduler": scheduler, "latents_every": outs[True].clone(),
+                "latents_once": outs[False].clone()}, os.path.join(out_dir, name))
+    print(name, "|x|", outs[True].abs().mean().item(), outs[False].abs().mean().item())
+
+
+def cxyz_fixture(out_dir, cfg0, usd, meta, hw=(28, 50)):
+    """bbox_embedder mode='cxyz' — the reference CLASS default (bbox_embedder.py:41, :52-54): 4 points per box instead of 8 corners, so
+    bbox_proj is Linear(4 * 27, .) and null_pos_feature has 108 entries.  Reference BEVControlNetModel.forward + UNet forward, 1 scene
+    x 6 views, 5 boxes per view (the first four corners of the synthetic boxes stand in for the four points), minmax_normalize on (the
+    class default too) with metre-scale coordinates."""
+    cfg = copy.deepcopy(cfg0)
+    cfg["controlnet"]["bbox"].update(mode="cxyz", n_corners=4, minmax_normalize=True)
+    csd = spec.random_state_dict(spec.controlnet_param_shapes(cfg), 1)
+    meta = dict(meta); meta["cn_checksum"] = checksum(csd)
+    ns, unet, cnet = ref_models.build_reference(cfg, usd, csd)
+    sc = scene(cfg, 1, 5, hw)
+    boxes = dict(sc["bboxes_3d_data"]); boxes["bboxes"] = boxes["bboxes"][..., :4, :].contiguous() * 20.0      # metres
+    lat = torch.randn(1, 6, 4, *hw, generator=torch.Generator().manual_seed(19))
+    t = torch.tensor([620])
+    with torch.no_grad():
+        d, m, ctx = cnet(lat, t, sc["camera_param"], boxes, sc["prompt_embeds"], sc["bev_map"], return_dict=False)
+        e = unet(lat.reshape(-1, 4, *hw), t.repeat_interleave(6), encoder_hidden_states=ctx,
+                 down_block_additional_residuals=d, mid_block_additional_residual=m).sample
+    torch.save({"meta": meta, "lat_seed": 19, "timesteps": t, "ctx": ctx.half(), "mid": m.clone(), "eps": e.half(),
+                "down_absmean": torch.tensor([x.abs().mean() for x in d])}, os.path.join(out_dir, "tiny_forward_cxyz.pt"))
+    print("tiny_forward_cxyz: eps std", e.std().item(), "ctx box rows |x|", ctx[:, 78:].abs().mean().item())
+
+
+def sd15_given_view_inputs(hw=(28, 50)):
+    """Known views of sd15_loop_given_view.pt: views 0 and 3 of the one scene (seed 78)."""
+    g = torch.Generator().manual_seed(78)
+    cl = [[None] * 6]
+    for j in (0, 3):
+        cl[0][j] = torch.randn(4, *hw, generator=g) * 0.8
+    return cl
+
+
+def sd15_given_view_fixture(out_dir):
+    """A headline-size loop whose six views GENUINELY differ: the REAL reference given-view pipeline
+    (pipeline_bev_controlnet_given_view.py:263-296) at spec.SD15_CONFIG, camera + 32 boxes + map, guidance 2.0, 10 DDIM steps, views 0
+    and 3 given and re-noised every step; latents after every 2nd step.  The reference __call__ stacks ONE latent over the cameras
+    (pipeline_bev_controlnet.py:326), so only the given views make the per-view states differ by O(1) instead of by the conditioning's ~1 %."""
+    import time
+    from helpers import bf16_round
+    torch.set_num_threads(8)
+    cfg = spec.SD15_CONFIG
+    usd, csd = state_dicts(cfg)
+    usd, csd = bf16_round(usd), bf16_round(csd)
+    meta = {"unet_checksum": checksum(usd), "cn_checksum": checksum(csd), "torch": str(torch.__version__),
+            "weights": "spec.random_state_dict seeds (0, 1), bf16-rounded; reference arithmetic fp32"}
+    ns, pipe = ref_models.build_reference_pipeline(cfg, usd, csd, given_view=True)
+    sc = scene(cfg, 1, 32, (28, 50))
+    trace = {}
+    t0 = time.time()
+    with torch.no_grad():
+        out = pipe(prompt=None, image=sc["bev_map"], camera_param=sc["camera_param"], height=224, width=400,
+                   conditional_latents=sd15_given_view_inputs(), conditional_latents_change_every_input=True,
+                   num_inference_steps=10, guidance_scale=2.0, latents=sc["latents"].clone(), prompt_embeds=sc["prompt_embeds"],
+                   negative_prompt_embeds=sc["negative_prompt_embeds"], output_type="latent", callback=_trace_cb(trace, 2), callback_steps=1,
+                   bev_controlnet_kwargs={"bboxes_3d_data": sc["bboxes_3d_data"]}).images
+    dt = time.time() - t0
+    meta["reference_seconds"] = dt; meta["reference_threads"] = torch.get_num_threads()
+    torch.save({"meta": meta, "steps": 10, "guidance": 2.0, "given": [0, 3], "latents": out.half().clone(), "trace": trace,
+                "absmean": out.abs().mean().item()}, os.path.join(out_dir, "sd15_loop_given_view.pt"))
+    v = out[0].float()
+    print("sd15_loop_given_view |x|", out.abs().mean().item(), f"reference: {dt:.1f} s; view-to-view rel diff vs view 1:",
+          [round(((v[j] - v[1]).norm() / v[1].norm()).item(), 3) for j in range(6)])
+
+
+def cpu_reference_vs_port(out_path):
+    """Time the REAL reference denoise step (BEVControlNetModel.forward + UNet forward through diffusers, fp32) next to the CPU port
+    (oracle/denoiser.py) on the same scene, weights and thread count — the ratio bench.py quotes beside its `cpu_baseline` (kind "port")
+    on boxes where /root/reference does not exist.  Written to profiles/ (no literals in bench.py)."""
+    import json
+    import time
+    from helpers import bf16_round
+    from oracle import denoiser as D
+    torch.set_num_threads(8)
+    cfg = spec.SD15_CONFIG
+    usd, csd = state_dicts(cfg)
+    usd, csd = bf16_round(usd), bf16_round(csd)
+    ns, unet, cnet = ref_models.build_reference(cfg, usd, csd)
+    sc = scene(cfg, 1, None, (28, 50), zero_map=True)
+    lat = torch.stack([sc["latents"]] * 6, 1)
+    cam = D.uncond_cam_param(csd, 1, 6)
+
+    def ref_step(t):
+        tt = torch.tensor([t])
+        d, m, ctx = cnet(lat, tt, cam, None, sc["prompt_embeds"], sc["bev_map"], return_dict=False)
+        return unet(lat.reshape(-1, 4, 28, 50), tt.repeat_interleave(6), encoder_hidden_states=ctx,
+                    down_block_additional_residuals=d, mid_block_additional_residual=m).sample
+
+    def port_step(t):
+        d, m, ctx = D.controlnet_forward(csd, cfg, lat, torch.tensor([t]), cam, None, sc["prompt_embeds"], sc["bev_map"])
+        return D.unet_forward(usd, cfg, lat.reshape(-1, 4, 28, 50), t, ctx, d, m)
+
+    res = {}
+    with torch.no_grad():
+        for name, fn in (("reference", ref_step), ("port", port_step)):
+            fn(981)
+            t0 = time.time()
+            outs = [fn(961 - 20 * i) for i in range(3)]
+            res[name] = (time.time() - t0) / 3
+            res[name + "_out"] = outs[-1]
+    rel = ((res["port_out"] - res["reference_out"]).norm() / res["reference_out"].norm()).item()
+    out = {"what": "one 6-view text-only denoise step (BEV-ControlNet + multi-view UNet, SD-1.5 size, fp32) on the host cores: the REAL reference "
+                   "(modules imported from /root/reference through oracle/refshim.py) vs the CPU port oracle/denoiser.py; 1 warm-up + 3 timed steps each",
+           "threads": torch.get_num_threads(), "reference_s_per_step": round(res["reference"], 3), "port_s_per_step": round(res["port"], 3),
+           "reference_over_port": round(res["port"] / res["reference"], 3), "port_vs_reference_rel_l2": rel,
+           "torch": str(torch.__version__), "where": "authoring container (no GPU); written by tools/make_golden.py cpuref"}
+    with open(out_path, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out))
 
 
 def vae_fixture(out_dir):
@@ -246,6 +368,10 @@ def main():
         return sd15_loop_fixture(out_dir, True)
     if sys.argv[1:] == ["sd15hires"]:
         return sd15_hires_fixture(out_dir)
+    if sys.argv[1:] == ["sd15given"]:
+        return sd15_given_view_fixture(out_dir)
+    if sys.argv[1:] == ["cpuref"]:
+        return cpu_reference_vs_port(os.path.join(ROOT, "profiles", "r04_cpu_reference_vs_port.json"))
     cfg = spec.TINY_CONFIG
     usd, csd = state_dicts(cfg)
     meta = {"unet_checksum": checksum(usd), "cn_checksum": checksum(csd), "torch": str(torch.__version__)}
@@ -255,6 +381,10 @@ def main():
         return hires_fixture(out_dir, cfg, usd, csd, meta)
     if sys.argv[1:] == ["given"]:
         return given_view_fixture(out_dir, cfg, usd, csd, meta)
+    if sys.argv[1:] == ["givenunipc"]:
+        return given_view_fixture(out_dir, cfg, usd, csd, meta, scheduler="unipc")
+    if sys.argv[1:] == ["cxyz"]:
+        return cxyz_fixture(out_dir, cfg, usd, meta)
     if sys.argv[1:] == ["vae"]:
         return vae_fixture(out_dir)
     if sys.argv[1:] == ["nattn"]:
