@@ -198,10 +198,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scenes-per-gpu", type=int, default=128,
+    ap.add_argument("--scenes-per-gpu", type=int, default=192,
                     help="scenes sampled per rank per pipe() call (throughput grows with the batch — fewer partial rounds of tiles: 6.33 / 6.46 / 6.53 "
-                         "scenes/s at 64 / 96 / 128 in round 2; a 128-scene call takes 20 s)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("MDX_STREAMS", "1")),
+                         "scenes/s at 64 / 96 / 128 in round 2; round 4, two streams: 7.21 / 7.23 / 7.18 at 128 / 192 / 256; a 192-scene call takes 27 s)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("MDX_STREAMS", "2")),
                     help="HIP streams a pipe() call spreads its scenes over (pipeline.streams: contiguous scene chunks, one plan + hipGraph each, "
                          "replayed concurrently; fills the tail / boundary gaps of whole-CU kernels)")
     ap.add_argument("--side-runs", action="store_true",

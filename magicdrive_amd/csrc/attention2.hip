@@ -117,8 +117,8 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
     constexpr int BUF = K_BYTES + PAD_TAIL + V_BYTES;
     constexpr bool ONES = (D % 16) != 0;           // a spare V^T row of ones carries the row sums
     constexpr int KP = D8, VP = D8;                // 1-KiB pieces per tile: K 64 * D8 chunks, V^T D rows * 8 chunks
-    constexpr int PPW = (KP + VP + A2_NW - 1) / A2_NW;     // pieces per wave per tile (the excess are dummies into scratch)
-    constexpr int SCRATCH = A2_NBUF * BUF;         // 1 KiB scratch for the dummy pieces
+    constexpr int PPW = (KP + VP + A2_NW - 1) / A2_NW;     // most pieces a wave issues per tile (some waves issue one fewer)
+    constexpr int SCRATCH = A2_NBUF * BUF;         // (+ 1 KiB of slack behind the ring)
     constexpr int QW = 32 * QT;                    // queries per wave
     static_assert(SCRATCH + 1024 <= 65536 || A2_RING > 3, "LDS budget: d = 40 -> 35 KB (4 workgroups per CU), d = 80 -> 61 KB (2)");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SCRATCH + 1024];
@@ -172,55 +172,58 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
 #pragma unroll
         for (int ks = 0; ks < D16; ++ks) asm volatile("" : "+v"(qf[qt][ks].u.x), "+v"(qf[qt][ks].u.y), "+v"(qf[qt][ks].u.z), "+v"(qf[qt][ks].u.w));
 
-    // ---- DMA bookkeeping: this wave's pieces (piece index pc = wave * PPW + j; K pieces first, then V^T, then dummies) ----
+    // ---- DMA bookkeeping (round 4): piece pc = wave + j * A2_NW of the tile's NP = KP + VP pieces (K pieces first, then V^T); a wave issues
+    // PPW or PPW - 1 of them (d = 40: 10 pieces over 4 waves = 3, 3, 2, 2 — round 3 padded every wave to 3 with dummy pieces into a scratch
+    // row).  Everything a piece needs is resolved HERE, once: round 3's per-tile "kind" selects were wave-uniform values the compiler kept
+    // in SGPRs and tested with scalar branches — ~180 scalar instructions, 16 branches and 34 v_readlane (spilled SGPRs) per tile per wave
+    // in the ISA of the self-attention kernel, around three DMA instructions.  Now a tile's issue is straight-line: per piece one s_mul
+    // (tile offset), one s_add (LDS address), one v_cndmask (the last tile's row / kv bound, pre-computed per lane) and the DMA statement.
+    constexpr int NP = KP + VP;
     unsigned pv_off[PPW];          // per-lane byte offset inside the (b, h) K or V^T matrix at tile 0
+    unsigned pv_last[PPW];         // the same for the LAST tile of a source: A2_OOB where the lane's row / kv chunk lies past Tk (zero fill)
     int p_lds[PPW];                // wave-uniform LDS byte offset inside a buffer
-    int p_kind[PPW];               // 0 K, 1 V^T, 2 dummy (wave-uniform)
-    int p_row[PPW], p_kv[PPW];     // K: tile row of this lane's chunk; V^T: first kv of this lane's chunk (last-tile range checks)
+    int p_step[PPW];               // wave-uniform source bytes per tile: K 64 rows, V^T 64 kv
+    bool p_isk[PPW];               // wave-uniform: piece of K (else of V^T)
+    const int ntile = (p.Tk + A2_KV - 1) / A2_KV;
+    const int tk_last = p.Tk - (ntile - 1) * A2_KV;          // valid kv of a source's last tile (1..64)
+    const bool full_wave = wave + (PPW - 1) * A2_NW < NP;    // this wave issues PPW pieces per tile (else PPW - 1)
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-        const int pc = wave * PPW + j;
+        const int pc = min(wave + j * A2_NW, NP - 1);          // (clamped: a wave without piece j never issues it)
         if (pc < KP) {
             const int n = pc * 64 + lane;                      // linear 16-byte chunk of the K tile
             const int row = n / D8, ch = n - row * D8;
-            p_kind[j] = 0; p_lds[j] = pc * 1024; p_row[j] = row; p_kv[j] = 0;
+            p_isk[j] = true; p_lds[j] = pc * 1024; p_step[j] = A2_KV * (int)p.ldk * 2;
             pv_off[j] = (unsigned)((row * p.ldk + ch * 8) * 2);
-        } else if (pc < KP + VP) {
+            pv_last[j] = row < tk_last ? pv_off[j] : A2_OOB;
+        } else {
             const int row0 = (pc - KP) * 8;
             const int row = mdx_xl::piece_lane_row(row0, lane), ch = mdx_xl::piece_lane_chunk(row0, lane);
-            p_kind[j] = 1; p_lds[j] = K_BYTES + PAD_TAIL + row0 * 128; p_row[j] = row; p_kv[j] = ch * 8;
+            p_isk[j] = false; p_lds[j] = K_BYTES + PAD_TAIL + row0 * 128; p_step[j] = A2_KV * 2;
             pv_off[j] = (unsigned)((row * p.ldv + ch * 8) * 2);
-        } else {
-            p_kind[j] = 2; p_lds[j] = SCRATCH; p_row[j] = 0; p_kv[j] = 0; pv_off[j] = A2_OOB;
+            pv_last[j] = ch * 8 < tk_last ? pv_off[j] : A2_OOB;
         }
+        p_lds[j] = __builtin_amdgcn_readfirstlane(p_lds[j]);
+        p_step[j] = __builtin_amdgcn_readfirstlane(p_step[j]);
     }
-    a2_rsrc_t rsK, rsV;
+    a2_rsrc_t rs_p[PPW];           // the descriptor each piece loads through (K or V^T of the current source)
     auto set_source = [&](int sidx) {
         const int bkv = p.kvmap ? p.kvmap[b * p.nsrc + sidx] : b;
-        rsK = a2_make_rsrc(p.K + (long)bkv * p.sK + (long)h * D);
-        rsV = a2_make_rsrc(p.Vt + (long)bkv * p.sV + (long)h * D * p.ldv);
+        const a2_rsrc_t rsK = a2_make_rsrc(p.K + (long)bkv * p.sK + (long)h * D);
+        const a2_rsrc_t rsV = a2_make_rsrc(p.Vt + (long)bkv * p.sV + (long)h * D * p.ldv);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) rs_p[j] = p_isk[j] ? rsK : rsV;
     };
-    const int ntile = (p.Tk + A2_KV - 1) / A2_KV;
     const int total = ntile * p.nsrc;
-    const int ldk2 = (int)p.ldk * 2;
-    // issue tile `t` of the current source into ring slot `slot`: branch-free (descriptor / tile offset / destination by scalar select)
+    // issue tile `t` of the current source into ring slot `slot`
     auto issue = [&](int t, int slot) {
-        const int j0 = t * A2_KV;
-        const bool last = j0 + A2_KV > p.Tk;
+        const bool last = t == ntile - 1;                      // wave-uniform
         const unsigned dst = lds0 + slot * BUF;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
-            unsigned vo = pv_off[j];
-            if (last) {                                       // rows / kv chunks past the end: zero fill
-                const int lim = p_kind[j] == 0 ? p_row[j] : p_kv[j];
-                if (p_kind[j] != 2 && j0 + lim >= p.Tk) vo = A2_OOB;
-            }
-            const bool isK = p_kind[j] != 1;                  // the dummy pieces go through the K descriptor (all lanes out of range)
-            a2_rsrc_t rs;
-            rs.x = isK ? rsK.x : rsV.x; rs.y = isK ? rsK.y : rsV.y; rs.z = A2_RECORDS; rs.w = 0x00020000u;
-            const int soff = p_kind[j] == 0 ? j0 * ldk2 : (p_kind[j] == 1 ? j0 * 2 : 0);
-            const unsigned ldsa = p_kind[j] == 2 ? lds0 + p_lds[j] : dst + p_lds[j];
-            a2_glds(rs, ldsa, vo, soff);
+            if (j == PPW - 1 && !full_wave) break;             // wave-uniform: the one scalar branch of the issue path
+            const unsigned vo = last ? pv_last[j] : pv_off[j];
+            a2_glds(rs_p[j], dst + p_lds[j], vo, t * p_step[j]);
         }
     };
 
@@ -367,10 +370,10 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
     int slot = 0;
     // start of tile g: its pieces have landed for every wave, every wave is done with tile g - 1, tile g + A2_NBUF - 1 goes out
     auto tile_sync = [&]() {
-        // at most the A2_NBUF - 2 younger tiles' pieces outstanding (fewer at the end of the stream)
+        // at most the A2_NBUF - 2 younger tiles' pieces outstanding (fewer at the end of the stream); a wave's tile is PPW or PPW - 1 pieces
         const int younger = total - 1 - g;
-        if (younger >= A2_NBUF - 2) a2_wait_vmcnt<PPW * (A2_NBUF - 2)>();
-        else if (A2_NBUF > 3 && younger == 1) a2_wait_vmcnt<PPW>();
+        if (younger >= A2_NBUF - 2) { if (full_wave) a2_wait_vmcnt<PPW * (A2_NBUF - 2)>(); else a2_wait_vmcnt<(PPW - 1) * (A2_NBUF - 2)>(); }
+        else if (A2_NBUF > 3 && younger == 1) { if (full_wave) a2_wait_vmcnt<PPW>(); else a2_wait_vmcnt<PPW - 1>(); }
         else a2_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");

@@ -173,6 +173,32 @@ class Act:
     def btc(self):
         return self.t.view(self.B, self.H * self.W, self.C)
 
+    def channels(self, c0: int, c1: int) -> "ActSlice":
+        """The channel range [c0, c1) of this activation as a strided view (row stride = self.C): what a producer writes when its output
+        is the first part of a decoder concat (Builder.decoder)."""
+        return ActSlice(self, c0, c1)
+
+
+class ActSlice:
+    """Channels [c0, c1) of a wider channels-last buffer: same accessors as Act, strided rows.  Owns no storage (Builder.free ignores it)."""
+
+    __slots__ = ("parent", "c0", "B", "H", "W", "C")
+
+    def __init__(self, parent: Act, c0: int, c1: int):
+        self.parent, self.c0, self.B, self.H, self.W, self.C = parent, c0, parent.B, parent.H, parent.W, c1 - c0
+
+    @property
+    def tok(self):
+        return self.parent.tok[:, self.c0:self.c0 + self.C]
+
+    @property
+    def bhwc(self):
+        return self.parent.bhwc[..., self.c0:self.c0 + self.C]
+
+    @property
+    def btc(self):
+        return self.parent.btc[..., self.c0:self.c0 + self.C]
+
 
 class Builder:
     """Emits IR ops for the two networks at a fixed batch geometry."""
@@ -220,6 +246,8 @@ class Builder:
         return Act(self.pool.get((B * H * W, C)), B, H, W, C)
 
     def free(self, a):
+        if isinstance(a, ActSlice):           # a view into a concat buffer: the buffer is freed by whoever allocated it
+            return
         self.pool.put(a.t if isinstance(a, Act) else a)
 
     def groupnorm(self, net, pre, x: Act, eps, silu, name) -> Act:
@@ -238,8 +266,8 @@ class Builder:
         return C
 
     # ---- resnet -------------------------------------------------------------------------
-    def resnet(self, net, pre, x: Act, temb: "TembTable", name) -> Act:
-        """ResnetBlock2D.forward (resnet.py:590-640)."""
+    def resnet(self, net, pre, x: Act, temb: "TembTable", name, out=None) -> Act:
+        """ResnetBlock2D.forward (resnet.py:590-640).  `out`: where the block's output goes (an ActSlice of the next decoder concat)."""
         cout = net.sd[pre + "conv1.weight"].shape[0]
         a = self.groupnorm(net, pre + "norm1.", x, self.eps, True, name + ".norm1")
         h = self.new(x.B, x.H, x.W, cout)
@@ -255,7 +283,9 @@ class Builder:
             self.gemm(x.tok, net.lin(pre + "conv_shortcut.weight"), cout, bias=net.vec(pre + "conv_shortcut.bias"), out=sc.tok, name=name + ".shortcut")
         else:
             sc = x
-        out = self.new(x.B, x.H, x.W, cout)
+        if out is None:
+            out = self.new(x.B, x.H, x.W, cout)
+        assert (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, cout)
         self.emit(O.Conv(b.bhwc, net.conv(pre + "conv2.weight"), out.bhwc, bias=net.vec(pre + "conv2.bias"), R=sc.bhwc, ws=self.ws, name=name + ".conv2"))
         self.free(b)
         if sc is not x:
@@ -359,8 +389,8 @@ class Builder:
         self.pool.put(g); self.pool.put(h3)
         return h4
 
-    def transformer2d(self, net, pre, x: Act, heads, ctx_kv, name) -> Act:
-        """Transformer2DModel.forward (transformer_2d.py:276-315): GN(eps 1e-6) -> 1x1 -> block -> 1x1 -> + input."""
+    def transformer2d(self, net, pre, x: Act, heads, ctx_kv, name, out=None) -> Act:
+        """Transformer2DModel.forward (transformer_2d.py:276-315): GN(eps 1e-6) -> 1x1 -> block -> 1x1 -> + input.  `out` as in resnet."""
         B, T, C = x.B, x.H * x.W, x.C
         gn = self.groupnorm(net, pre + "norm.", x, 1e-6, False, name + ".norm")
         h = self.gemm(gn.tok, net.lin(pre + "proj_in.weight"), C, bias=net.vec(pre + "proj_in.bias"), name=name + ".proj_in")
@@ -369,7 +399,9 @@ class Builder:
         while net.has(f"{pre}transformer_blocks.{i}.norm1.weight"):
             h = self.transformer_block(net, f"{pre}transformer_blocks.{i}.", h, B, T, C, heads, ctx_kv, f"{name}.tb{i}")
             i += 1
-        out = self.new(x.B, x.H, x.W, C)
+        if out is None:
+            out = self.new(x.B, x.H, x.W, C)
+        assert (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, C)
         self.gemm(h, net.lin(pre + "proj_out.weight"), C, bias=net.vec(pre + "proj_out.bias"), R=x.tok, out=out.tok, name=name + ".proj_out")
         self.pool.put(h)
         return out
@@ -411,28 +443,44 @@ class Builder:
         cfg = self.cfg
         nblk = len(cfg["block_out_channels"])
         rev_heads = [heads_at(cfg, k) for k in reversed(range(nblk))]
+        # The concat [x | skip] of every up-block layer (unet_2d_blocks.py:1948-1951): the layer that PRODUCES x writes it straight into
+        # the first channels of the next concat buffer (strided output of its last conv / GEMM), so only the skip half is copied — the
+        # x half was a read + write of the whole tensor per layer (round 3: 12 of the step's 24 ew_vec8 launches).  `cat` is allocated
+        # before the producer runs; x's only other consumers (the upsampler, conv_norm_out) get a standalone buffer.
+        n_layers = cfg["layers_per_block"] + 1
+        cat = None                                 # concat buffer whose first x.C channels already hold x
         for i in range(nblk):
             has_attn = cfg["up_block_types"][i].startswith("CrossAttn")
-            for j in range(cfg["layers_per_block"] + 1):
+            for j in range(n_layers):
                 s = skips.pop()
-                cat = self.new(x.B, x.H, x.W, x.C + s.C)
-                self.emit(O.Ew(L.EW_COPY, x.tok, cat.tok[:, :x.C], name=f"{tag}.u{i}.cat{j}a"))
+                if cat is None:
+                    cat = self.new(x.B, x.H, x.W, x.C + s.C)
+                    self.emit(O.Ew(L.EW_COPY, x.tok, cat.tok[:, :x.C], name=f"{tag}.u{i}.cat{j}a"))
+                    self.free(x)
+                assert cat.C == x.C + s.C and (cat.H, cat.W) == (s.H, s.W)
                 self.emit(O.Ew(L.EW_COPY, s.tok, cat.tok[:, x.C:], name=f"{tag}.u{i}.cat{j}b"))
-                self.free(x); self.free(s)
-                y = self.resnet(net, f"up_blocks.{i}.resnets.{j}.", cat, temb, f"{tag}.u{i}.r{j}")
+                self.free(s)
+                # where this layer's output goes: into the next layer's concat when that one follows at the same resolution
+                cout = net.sd[f"up_blocks.{i}.resnets.{j}.conv1.weight"].shape[0]
+                nxt = None
+                if j + 1 < n_layers:
+                    nxt = self.new(x.B, x.H, x.W, cout + skips[-1].C)
+                dst = nxt.channels(0, cout) if nxt is not None else None
+                y = self.resnet(net, f"up_blocks.{i}.resnets.{j}.", cat, temb, f"{tag}.u{i}.r{j}", out=None if has_attn else dst)
                 self.free(cat)
                 if has_attn:
-                    z = self.transformer2d(net, f"up_blocks.{i}.attentions.{j}.", y, rev_heads[i], ctx_kv, f"{tag}.u{i}.a{j}")
+                    z = self.transformer2d(net, f"up_blocks.{i}.attentions.{j}.", y, rev_heads[i], ctx_kv, f"{tag}.u{i}.a{j}", out=dst)
                     self.free(y)
                     y = z
-                x = y
+                x, cat = y, nxt
             uk = f"up_blocks.{i}.upsamplers.0.conv."
             if net.has(uk + "weight"):
                 Ho, Wo = skips[-1].H, skips[-1].W          # next skip's size (forced interpolation size)
                 up = self.new(x.B, Ho, Wo, x.C)
                 self.emit(O.Upsample(x.bhwc, up.bhwc, PK.nearest_index(x.H, Ho).to(self.device), PK.nearest_index(x.W, Wo).to(self.device), name=f"{tag}.u{i}.nearest"))
                 self.free(x)
-                y = self.new(x.B, Ho, Wo, x.C)
+                cat = self.new(x.B, Ho, Wo, x.C + skips[-1].C)      # the upsampler conv writes the x half of the next block's first concat
+                y = cat.channels(0, x.C)
                 self.emit(O.Conv(up.bhwc, net.conv(uk + "weight"), y.bhwc, bias=net.vec(uk + "bias"), ws=self.ws, name=f"{tag}.u{i}.upconv"))
                 self.free(up)
                 x = y

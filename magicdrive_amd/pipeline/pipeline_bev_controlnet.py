@@ -61,7 +61,8 @@ class StableDiffusionBEVControlNetPipeline:
         self.use_graph = True
         # Scene chunks replayed concurrently on separate HIP streams (see __call__): MDX_STREAMS overrides; chunks hold at least
         # `min_scenes_per_stream` scenes (below that a launch has too few tiles to fill the chip even alone).
-        self.streams = max(1, int(os.environ.get("MDX_STREAMS", "1")))
+        # Measured on one box (profiles/r04_streams_ab.log, configs[1]): 128 scenes 7.02 -> 7.21 scenes/s, 192 scenes 7.14 -> 7.23.
+        self.streams = max(1, int(os.environ.get("MDX_STREAMS", "2")))
         self.min_scenes_per_stream = 16
         self._side: Dict[Any, List[Any]] = {}
 

