@@ -37,6 +37,7 @@ struct AttnParams {
     long ldq, sQ, ldk, sK, ldv, sV, ldo, sO;
     float scale_log2;  // scale * log2(e)
     int qblocks;       // query blocks per (batch, head); >0 selects the XCD-aware 1-D grid
+    int viewmap;       // with qblocks > 0: 1 = every head and query block of a view on one XCD (ATTN_SWZ = 2), 0 = per (batch, head)
 };
 
 constexpr int KVT = 64;          // kv tile
@@ -68,9 +69,17 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
     int qb, h, b;
     if (p.qblocks > 0) {
         const int L = blockIdx.x, xcd = L & 7, idx = L >> 3;
-        const int bh = (idx / p.qblocks) * 8 + xcd;
-        if (bh >= p.B * p.H) return;
-        qb = idx % p.qblocks; b = bh / p.H; h = bh - b * p.H;
+        if (p.viewmap) {          // round 4 (see attention2.hip): the heads' Q / K / O are slices of rows whose 128-byte lines all heads share
+            const int per_view = p.H * p.qblocks;
+            const int vl = idx / per_view, rem = idx - vl * per_view;
+            b = vl * 8 + xcd;
+            if (b >= p.B) return;
+            h = rem / p.qblocks; qb = rem - h * p.qblocks;
+        } else {
+            const int bh = (idx / p.qblocks) * 8 + xcd;
+            if (bh >= p.B * p.H) return;
+            qb = idx % p.qblocks; b = bh / p.H; h = bh - b * p.H;
+        }
     } else {
         qb = blockIdx.x; h = blockIdx.y; b = blockIdx.z;
     }
@@ -307,9 +316,12 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
     const int swz = (int)opt(OPT_ATTN_SWZ);
     dim3 grid(qblocks, p.H, p.B);
     q.qblocks = 0;
+    q.viewmap = 0;
     if (swz && qblocks > 1) {
         q.qblocks = qblocks;
-        grid = dim3((unsigned)(((long)p.B * p.H + 7) / 8 * 8 * qblocks), 1, 1);
+        q.viewmap = swz >= 2;
+        grid = q.viewmap ? dim3((unsigned)(((long)p.B + 7) / 8 * 8 * p.H * qblocks), 1, 1)
+                         : dim3((unsigned)(((long)p.B * p.H + 7) / 8 * 8 * qblocks), 1, 1);
     }
     const bool two = p.nsrc == 2 && !p.joint;
     if (two)

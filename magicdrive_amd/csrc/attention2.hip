@@ -104,8 +104,13 @@ constexpr float A2_DEFER = 4.0f;   // log2 units: the running max is only raised
 // 64 kv) of `exp2(s * scale - m)` — a fifth of the kernel's VALU time, and the kernel is VALU-bound — disappear.  m is kept on the bf16
 // grid (any value works as the subtracted maximum as long as numerator and row sum use the same one); a tile that raises it (rare:
 // deferred maximum) re-bases its own scores with an explicit subtraction.
-template <int D8, bool TWO, int QT, bool FOLD>
-__global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kernel(Attn2Params p) {
+// RES (round 4): "resident" K / V^T for short kv sequences — the text-context attention of level 0 (S = 1 + 77 (+ boxes) tokens, Tq = 1400).
+// With one workgroup per (view, head, 128-query block) that launch spent more than half of its time on per-workgroup fixed cost (zeroing
+// the LDS image, the DMA round trip of two tiles, launch / drain): 168 TFLOP/s.  Here ONE workgroup per (view, head) stages all
+// ntile <= A2_RING tiles once and then walks the query blocks: no DMA, no barrier and no vmcnt wait inside the walk.
+template <int D8, bool TWO, int QT, bool FOLD, bool RES = false>
+__global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : (RES ? 4 : 3)) void attn2_kernel(Attn2Params p) {
+    static_assert(!RES || (!TWO && QT == 1), "resident K / V^T: one kv source, 32-query waves");
     constexpr int D = D8 * 8;
     static_assert(!FOLD || (D % 16) == 8, "FOLD needs the 8 spare k slots of a head dim that is 8 mod 16");
     constexpr int D16 = (D + 15) / 16;             // QK k-steps of 16 and PV row tiles of 16
@@ -127,13 +132,26 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col = lane & 31;
     int qb, h, b;
-    {   // XCD-aware order: all query blocks of one (batch, head) on one XCD, back to back (its K / V^T stay in that L2)
+    {   // XCD-aware order (workgroup L runs on XCD L % 8: speed only).  viewmap 0 (rounds 2-3): the query blocks of one (batch, head) on one
+        // XCD, back to back — its K / V^T stay in that L2, but the eight heads of a view land on eight XCDs, and a head's Q / K / O are
+        // 80-byte slices of rows that all heads share: every L2 fetches (and partially writes back) the same 128-byte lines.  viewmap 1
+        // (round 4): EVERY head and query block of a view on one XCD, head-major, so a line is fetched once per L2 and the heads' O
+        // slices merge there before they are written back.
         const int L = blockIdx.x, xcd = L & 7, idx = L >> 3;
-        const int bh = (idx / p.qblocks) * 8 + xcd;
-        if (bh >= p.B * p.H) return;
-        qb = idx % p.qblocks; b = bh / p.H; h = bh - b * p.H;
+        const int nq = RES ? 1 : p.qblocks;
+        if (p.viewmap) {
+            const int per_view = p.H * nq;
+            const int vl = idx / per_view, rem = idx - vl * per_view;
+            b = vl * 8 + xcd;
+            if (b >= p.B) return;
+            h = rem / nq; qb = rem - h * nq;
+        } else {
+            const int bh = (idx / nq) * 8 + xcd;
+            if (bh >= p.B * p.H) return;
+            qb = idx % nq; b = bh / p.H; h = bh - b * p.H;
+        }
     }
-    const int q0w = qb * (A2_NW * QW) + wave * QW;           // this wave's first query
+    int q0w = qb * (A2_NW * QW) + wave * QW;                 // this wave's first query
     // 32-query tiles of this wave that hold a real query (wave-uniform): the waves past Tq still stage and synchronise
     int nact = (p.Tq - q0w + 31) >> 5;
     nact = __builtin_amdgcn_readfirstlane(nact < 0 ? 0 : (nact > QT ? QT : nact));
@@ -152,25 +170,28 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane -> query column, 8 consecutive dims ----
     Frag8 qf[QT][D16];
+    auto load_q = [&]() {
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const int q = q0w + qt * 32 + col;
-        const bf16_t* qp = p.Q + (long)b * p.sQ + (long)(q < p.Tq ? q : 0) * p.ldq + (long)h * D;
+        for (int qt = 0; qt < QT; ++qt) {
+            const int q = q0w + qt * 32 + col;
+            const bf16_t* qp = p.Q + (long)b * p.sQ + (long)(q < p.Tq ? q : 0) * p.ldq + (long)h * D;
 #pragma unroll
-        for (int ks = 0; ks < D16; ++ks) {
-            const int dd = ks * 16 + half * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (q < p.Tq && dd < D) v = *(const uint4*)(qp + dd);
-            qf[qt][ks].u = v;
+            for (int ks = 0; ks < D16; ++ks) {
+                const int dd = ks * 16 + half * 8;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (q < p.Tq && dd < D) v = *(const uint4*)(qp + dd);
+                qf[qt][ks].u = v;
+            }
         }
-    }
-    // The compiler cannot see the hand-counted LDS-DMA traffic on the VM counter: left alone it guards the first in-loop use of the Q
-    // registers with `s_waitcnt vmcnt(0)` on EVERY iteration (the loads are outside the loop), which drains the tile just issued and
-    // puts its whole latency on the critical path.  Consuming the registers here settles its bookkeeping before the loop.
+        // The compiler cannot see the hand-counted LDS-DMA traffic on the VM counter: left alone it guards the first in-loop use of the Q
+        // registers with `s_waitcnt vmcnt(0)` on EVERY iteration (the loads are outside the loop), which drains the tile just issued and
+        // puts its whole latency on the critical path.  Consuming the registers here settles its bookkeeping before the loop.
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int ks = 0; ks < D16; ++ks) asm volatile("" : "+v"(qf[qt][ks].u.x), "+v"(qf[qt][ks].u.y), "+v"(qf[qt][ks].u.z), "+v"(qf[qt][ks].u.w));
+            for (int ks = 0; ks < D16; ++ks) asm volatile("" : "+v"(qf[qt][ks].u.x), "+v"(qf[qt][ks].u.y), "+v"(qf[qt][ks].u.z), "+v"(qf[qt][ks].u.w));
+    };
+    if (!RES) load_q();
 
     // ---- DMA bookkeeping (round 4): piece pc = wave + j * A2_NW of the tile's NP = KP + VP pieces (K pieces first, then V^T); a wave issues
     // PPW or PPW - 1 of them (d = 40: 10 pieces over 4 waves = 3, 3, 2, 2 — round 3 padded every wave to 3 with dummy pieces into a scratch
@@ -257,23 +278,23 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
     // Online softmax with a deferred maximum: m_run is raised only when a tile exceeds it by more than A2_DEFER (wave-uniform
     // decision), so most tiles skip the O rescale and its two cross-lane fetches.  Until then probabilities are relative to the older
     // maximum (at most 2^A2_DEFER instead of 1) — the numerator and the row sum carry the same factor and it cancels in O = (P V) / l.
-#define A2_TILE(LAST, NQ_, slot_, j0_, FIRST_)                                                                         \
+#define A2_TILE(LAST, NQ_, slot_, j0_, FIRST_, NS_)                                                                        \
     {                                                                                                                  \
         const unsigned char* sb_ = smem + (slot_) * BUF;                                                               \
         Frag8 kf_[2][D16], vf_[2][D16];                                                                                \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                  \
+        _Pragma("unroll") for (int s = 0; s < (NS_); ++s)                                                                  \
             _Pragma("unroll") for (int ks = 0; ks < D16; ++ks) kf_[s][ks].u = *(const uint4*)(sb_ + k_rd[s] + ks * 32); \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                  \
+        _Pragma("unroll") for (int s = 0; s < (NS_); ++s)                                                                  \
             _Pragma("unroll") for (int i = 0; i < D16; ++i) vf_[s][i].u = *(const uint4*)(sb_ + (s ? v_rd1 : v_rd0) + i * 2048); \
         if (FOLD) {   /* upper-half lanes of the last k-step hold only pad dims (bytes of the NEXT K row in LDS): make them (1, 0 x 7) */ \
-            _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                            \
+            _Pragma("unroll") for (int s = 0; s < (NS_); ++s) {                                                            \
                 kf_[s][D16 - 1].u.x = half ? one_slot : kf_[s][D16 - 1].u.x; kf_[s][D16 - 1].u.y = half ? 0u : kf_[s][D16 - 1].u.y; \
                 kf_[s][D16 - 1].u.z = half ? 0u : kf_[s][D16 - 1].u.z; kf_[s][D16 - 1].u.w = half ? 0u : kf_[s][D16 - 1].u.w; \
             }                                                                                                          \
         }                                                                                                              \
         _Pragma("unroll") for (int qt = 0; qt < NQ_; ++qt) {                                                           \
             f32x16_t sacc[2];                                                                                          \
-            _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                            \
+            _Pragma("unroll") for (int s = 0; s < (NS_); ++s) {                                                            \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) sacc[s][r] = 0.f;                                       \
                 _Pragma("unroll") for (int ks = 0; ks < D16; ++ks) {                                                   \
                     if (A2_ABL & 8) sacc[s][ks] += __uint_as_float(kf_[s][ks].u.x ^ qf[qt][ks].u.x);                   \
@@ -281,12 +302,12 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
                 }                                                                                                      \
             }                                                                                                          \
             if (LAST) {                                                                                                \
-                _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                          \
+                _Pragma("unroll") for (int s = 0; s < (NS_); ++s)                                                          \
                     _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                     \
                         if ((j0_) + s * 32 + mfma32_row(r, lane) >= p.Tk) sacc[s][r] = -INFINITY;                      \
             }                                                                                                          \
             float mx = -INFINITY;                                                                                      \
-            _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                              \
+            _Pragma("unroll") for (int s = 0; s < (NS_); ++s)                                                              \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[s][r]);                             \
             {   /* max with the other half of this query (lane ^ 32): one v_permlane32_swap instead of a ds_bpermute */  \
                 const unsigned mu_ = __float_as_uint(mx);                                                              \
@@ -304,7 +325,7 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
                     alpha = (FIRST_) ? 0.f : __builtin_amdgcn_exp2f(-delta_);      /* first tile: O is zero; exp2 of a large -delta would be inf */ \
                     m_run[qt] = m_new;                                                                                 \
                     if (half) qf[qt][D16 - 1].u.x = pack2bf(-m_new, 0.f);          /* -m into the pad k slot of this query */ \
-                    _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                      \
+                    _Pragma("unroll") for (int s = 0; s < (NS_); ++s)                                                      \
                         _Pragma("unroll") for (int r = 0; r < 16; ++r) sacc[s][r] -= delta_;      /* this tile was multiplied with the old m */ \
                     const float al0 = __shfl(alpha, lane & 15, 64), al1 = __shfl(alpha, 16 + (lane & 15), 64);          \
                     _Pragma("unroll") for (int i = 0; i < D16; ++i)                                                    \
@@ -329,7 +350,7 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
             }                                                                                                          \
             const float mneg_ = -m_run[qt];                                                                            \
             float psum = 0.f;                                                                                          \
-            _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                            \
+            _Pragma("unroll") for (int s = 0; s < (NS_); ++s) {                                                            \
                 Frag8 b0, b1;                                                                                          \
                 _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                        \
                     float p0 = FOLD ? sacc[s][2 * u] : __builtin_fmaf(sacc[s][2 * u], p.scale_log2, mneg_);            \
@@ -353,6 +374,87 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
             if (!ONES) l_run[qt] = l_run[qt] * alpha + psum;                                                           \
         }                                                                                                              \
     }
+    if constexpr (RES) {
+        // ---- resident K / V^T: stage every tile of the (one) source once, then walk the query blocks ----
+        set_source(0);
+        for (int t = 0; t < ntile; ++t) issue(t, t);              // ntile <= A2_NBUF (launch_attn2)
+        a2_wait_vmcnt<0>();
+        __syncthreads();
+        const int nfull_r = p.Tk / A2_KV;
+        if (nfull_r < ntile) {
+            // scrub the V^T pad columns of the partial tile (kv >= Tk inside the last partially valid 16-byte chunk may hold anything)
+            const int kv_lo = p.Tk - nfull_r * A2_KV;
+            if ((kv_lo & 7) != 0) {
+                const int chunk = kv_lo >> 3, e0 = kv_lo & 7;
+                for (int r = tid; r < D; r += A2_NT) {
+                    bf16_t* rowp = (bf16_t*)(smem + nfull_r * BUF + K_BYTES + PAD_TAIL + r * 128 + ((chunk ^ mdx_xl::swz(r)) << 4));
+                    for (int e = e0; e < 8; ++e) rowp[e] = 0;
+                }
+                __syncthreads();
+            }
+        }
+        const bool short_last = nfull_r < ntile && p.Tk - nfull_r * A2_KV <= 32;      // the partial tile fits its first 32-kv sub-tile
+        const int nqb = (p.Tq + A2_NW * QW - 1) / (A2_NW * QW);
+        for (int qbi = 0; qbi < nqb; ++qbi) {
+            q0w = qbi * (A2_NW * QW) + wave * QW;
+            if (q0w >= p.Tq) break;                                // wave-uniform; nothing synchronises inside the walk
+            load_q();
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                m_run[qt] = FOLD ? 0.f : -INFINITY; l_run[qt] = 0.f;
+#pragma unroll
+                for (int i = 0; i < D16; ++i)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) oacc[qt][i][t][e] = 0.f;
+            }
+            int fresh_r = 1;
+            for (int t = 0; t < nfull_r; ++t) {
+                A2_TILE(false, 1, t, t * A2_KV, fresh_r, 2)
+                fresh_r = 0;
+            }
+            if (nfull_r < ntile) {
+                if (short_last) { A2_TILE(true, 1, nfull_r, nfull_r * A2_KV, fresh_r, 1) }
+                else { A2_TILE(true, 1, nfull_r, nfull_r * A2_KV, fresh_r, 2) }
+            }
+            // normalise and store this block's O
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                float inv0, inv1;
+                if (ONES) {
+                    constexpr int LT = ONES ? D / 16 : 0;
+                    inv0 = 1.0f / __shfl(oacc[qt][LT][0][0], 32 + (lane & 15), 64);
+                    inv1 = 1.0f / __shfl(oacc[qt][LT][1][0], 32 + (lane & 15), 64);
+                } else {
+                    const float l_tot = l_run[qt] + __shfl_xor(l_run[qt], 32, 64);
+                    const float inv = 1.0f / l_tot;
+                    inv0 = __shfl(inv, lane & 15, 64); inv1 = __shfl(inv, 16 + (lane & 15), 64);
+                }
+#pragma unroll
+                for (int tq = 0; tq < 2; ++tq) {
+                    const int qq = q0w + qt * 32 + tq * 16 + (lane & 15);
+                    if (qq >= p.Tq) continue;
+                    bf16_t* op = p.O + (long)b * p.sO + (long)qq * p.ldo + (long)h * D;
+                    const float inv = tq ? inv1 : inv0;
+#pragma unroll
+                    for (int i = 0; i < D16; ++i) {
+                        const int dd = i * 16 + 4 * (lane >> 4);
+                        if (dd < D) {
+                            const f32x4_t& a = oacc[qt][i][tq];
+                            uint2 ov;
+                            ov.x = pack2bf(a[0] * inv, a[1] * inv);
+                            ov.y = pack2bf(a[2] * inv, a[3] * inv);
+                            *(uint2*)(op + dd) = ov;
+                        }
+                    }
+                }
+                if (FOLD && half) qf[qt][D16 - 1].u.x = 0u;
+            }
+        }
+        return;
+    }
+
     // ---- prologue: tiles 0 and 1 of the stream in flight ----
     int ds = 0;                          // source the descriptors currently describe
     set_source(0);
@@ -393,7 +495,7 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
     {                                                                                                                  \
         for (int t = 0; t < nfull; ++t) {                                                                              \
             tile_sync();                                                                                               \
-            A2_TILE(false, NQ_, slot, t * A2_KV, fresh)                                                                \
+            A2_TILE(false, NQ_, slot, t * A2_KV, fresh, 2)                                                                \
             tile_done();                                                                                               \
         }                                                                                                              \
         if (nfull < ntile) {                                                                                           \
@@ -408,7 +510,7 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
                 }                                                                                                      \
                 __syncthreads();                                                                                       \
             }                                                                                                          \
-            A2_TILE(true, NQ_, slot, nfull * A2_KV, fresh)                                                          \
+            A2_TILE(true, NQ_, slot, nfull * A2_KV, fresh, 2)                                                          \
             tile_done();                                                                                               \
         }                                                                                                              \
     }
@@ -482,11 +584,25 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : 3) void attn2_kern
         }
 }
 
+// resident K / V^T (attn2_kernel<.., RES>): one workgroup per (batch, head)
+template <int D8, bool FOLD>
+static int launch_attn2_res(const Attn2Params& p, hipStream_t st) {
+    Attn2Params q = p;
+    q.qblocks = 1;
+    q.viewmap = opt(OPT_ATTN2_VIEWMAP) != 0;
+    const dim3 grid(q.viewmap ? (unsigned)(((long)p.B + 7) / 8 * 8 * p.H) : (unsigned)(((long)p.B * p.H + 7) / 8 * 8), 1, 1);
+    hipLaunchKernelGGL((attn2_kernel<D8, false, 1, FOLD, true>), grid, dim3(A2_NT), 0, st, q);
+    char tag[64];
+    snprintf(tag, sizeof tag, "attn2_kernel<%d,resident,q32%s>", D8 * 8, FOLD ? ",fold" : "");
+    return check_launch(tag);
+}
+
 template <int D8, int QT, bool FOLD>
 static int launch_attn2_d(const Attn2Params& p, hipStream_t st) {
     Attn2Params q = p;
     q.qblocks = (p.Tq + A2_NW * 32 * QT - 1) / (A2_NW * 32 * QT);
-    const dim3 grid((unsigned)(((long)p.B * p.H + 7) / 8 * 8 * q.qblocks), 1, 1);
+    q.viewmap = opt(OPT_ATTN2_VIEWMAP) != 0;
+    const dim3 grid(q.viewmap ? (unsigned)(((long)p.B + 7) / 8 * 8 * p.H * q.qblocks) : (unsigned)(((long)p.B * p.H + 7) / 8 * 8 * q.qblocks), 1, 1);
     const bool two = p.nsrc == 2 && !p.joint;                   // TWO = the summed two-neighbour form; everything else is one softmax over nsrc sources
     if (two) hipLaunchKernelGGL((attn2_kernel<D8, true, QT, FOLD>), grid, dim3(A2_NT), 0, st, q);
     else hipLaunchKernelGGL((attn2_kernel<D8, false, QT, FOLD>), grid, dim3(A2_NT), 0, st, q);
@@ -499,8 +615,11 @@ static int launch_attn2_d(const Attn2Params& p, hipStream_t st) {
 // 16-byte aligned K rows / V^T rows, matrices within the 2 GiB DMA window.
 bool attn2_supported(const Attn2Params& p) {
     const int on = (int)opt(OPT_ATTN2);
-    const int d80 = (int)opt(OPT_ATTN2_D80);   // d = 80: slower than attention.hip so far
-    if (!on || (p.d != 40 && !(p.d == 80 && d80))) return false;
+    // d = 80 (level 1, T = 350): 0 never, 1 always, 2 (default) only the two-source cross-view form — measured at 768 views with the
+    // round-4 issue path (profiles/r04_attn_d80.log): cross-view 923 vs 1000-1012 us on attention.hip, self 545 vs 517-529 us
+    const int d80 = (int)opt(OPT_ATTN2_D80);
+    const bool xview2 = p.nsrc == 2 && !p.joint;
+    if (!on || (p.d != 40 && !(p.d == 80 && (d80 == 1 || (d80 == 2 && xview2))))) return false;
     if (p.Tq < 256 || (long)((p.Tq + 127) / 128) * p.H * p.B < 128) return false;
     if ((p.ldk % 8) || (p.ldv % 8) || (p.sK % 8) || (p.sV % 8) || (p.ldv < ((p.Tk + 7) / 8) * 8)) return false;
     if ((long)p.Tk * p.ldk * 2 >= 0x40000000L || (long)p.d * p.H * p.ldv * 2 >= 0x40000000L) return false;
@@ -515,6 +634,12 @@ int launch_attn2(const Attn2Params& p, hipStream_t st) {
     const bool two = qt == 2 && p.Tq >= 512 && p.d == 40;
     // pre-scaled Q (scale * log2 e folded into to_q at pack time): scores are base-2 exponents as they come out of the MFMA
     const bool fold = p.q_prescaled && opt(OPT_ATTN2_FOLD) != 0;
+    // short kv sequences (the text context): every tile resident in the ring, one workgroup per (batch, head) walks the query blocks
+    // (ATTN2_RES: 1 = when the launch has enough (batch, head) pairs to fill the chip on its own and several query blocks to walk; 2 = whenever supported)
+    const int res_opt = (int)opt(OPT_ATTN2_RES);
+    if (p.d == 40 && fold && p.nsrc == 1 && (p.Tk + A2_KV - 1) / A2_KV <= A2_NBUF &&
+        (res_opt == 2 || (res_opt == 1 && p.Tq >= 512 && (long)p.B * p.H >= 1024)))
+        return launch_attn2_res<5, true>(p, st);
     if (p.d == 40) {
         // FOLD frees the registers / VALU slots of the scale-and-subtract: with it the 32-query form (<= 142 VGPRs: three waves per SIMD)
         // is the faster one for one kv source (768 views, T = 1400: self 3157 vs 3332 us, text context 640 vs 795 us; the two-source

@@ -11,6 +11,7 @@ struct Attn2Params {
     float scale_log2;  // scale * log2(e); 1 when q_prescaled
     int q_prescaled;   // Q already carries scale * log2(e) (MdxAttnDesc.q_prescaled)
     int qblocks;       // query blocks per (batch, head), filled in by launch_attn2
+    int viewmap;       // block order (launch_attn2, option ATTN2_VIEWMAP): 1 = every head and query block of a view on ONE XCD
 
 };
 bool attn2_supported(const Attn2Params& p);

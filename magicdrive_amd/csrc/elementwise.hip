@@ -5,6 +5,7 @@
 // 16-byte vectorised where the layout allows, fp32 math.  Reference call sites: include/mdx.h.
 #include "common.h"
 #include "launch.h"
+#include "options.h"
 
 namespace mdx {
 
@@ -113,6 +114,106 @@ __global__ __launch_bounds__(256) void conv_direct_kpar_kernel(CDParams p) {
         for (int n = 0; n < NOUT; ++n) if (n == lane) a = acc[n];
         a = cd_finish(p, a, m, lane, b);
         if (p.y_f32) ((float*)p.Y)[m * p.ldy + lane] = a; else ((bf16_t*)p.Y)[m * p.ldy + lane] = f2bf(a);
+    }
+}
+
+// Weight-stationary form of the K-parallel kernel (round 4; conv_out of the UNet: Cout = 4, K = 9 x 320 = 2880, one launch per step over
+// every latent pixel).  The kernel above re-fetches its 4 x 16 bytes of weights per chunk and pixel — 23 KB of L1 traffic per pixel for
+// 5.8 KB of activations: 1.97 ms per step at 768 views, 13 TFLOP/s.  Here a wave keeps ITS share of the weights in registers
+// (lane l owns the 16-byte chunks l, l + 64, ... of the (tap, channel) axis for all Cout rows: NCHK x 4 x 4 packed words) and walks
+// PIX consecutive output pixels: per pixel NCHK activation loads (zero for taps outside the image), NCHK x 16 packed dot products
+// (v_dot2c_f32_bf16 / _f16: two 16-bit products + fp32 accumulate per instruction, no unpacking) and one wave reduction per output channel.
+// Summation order per output element: lane-local over the lane's chunks, then across lanes — a permutation of the kernel above's;
+// fp32 throughout (the 16-bit products are exact in fp32).
+__device__ __forceinline__ float dot2_16(unsigned a, unsigned b, float c) {
+#if MDX_F16
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a), __builtin_bit_cast(h2_t, b), c, false);
+#else
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2_t, a), __builtin_bit_cast(b2_t, b), c, false);
+#endif
+}
+
+template <int NCHK, int PIX>
+__global__ __launch_bounds__(256) void conv_direct_kpar_ws_kernel(CDParams p) {
+    constexpr int NOUT = 4;
+    const int lane = threadIdx.x & 63;
+    const long M = (long)p.B * p.Ho * p.Wo;
+    const long m_first = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * PIX;
+    if (m_first >= M) return;
+    const int cpc = p.Cin / 8;                 // chunks per tap
+    const int nch = p.kh * p.kw * cpc;
+    const long K = (long)p.kh * p.kw * p.Cin;
+    // this lane's chunks: (tap, channel offset) and the weights of the Cout rows
+    uint4 w[NCHK][NOUT];
+    int c_dy[NCHK], c_dx[NCHK], c_ci[NCHK];
+    bool c_on[NCHK];
+#pragma unroll
+    for (int i = 0; i < NCHK; ++i) {
+        const int c = lane + 64 * i;
+        c_on[i] = c < nch;
+        const int cc = c_on[i] ? c : 0;
+        const int tap = cc / cpc;
+        c_ci[i] = (cc - tap * cpc) * 8;
+        const int ky = tap / p.kw;
+        c_dy[i] = ky - p.ph; c_dx[i] = tap - ky * p.kw - p.pw;
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (c_on[i] && n < p.Cout) v = *(const uint4*)(p.W + (long)n * K + (long)tap * p.Cin + c_ci[i]);
+            w[i][n] = v;
+        }
+    }
+    const int hw = p.Ho * p.Wo;
+    for (int q = 0; q < PIX; ++q) {
+        const long m = m_first + q;
+        if (m >= M) break;                     // wave-uniform
+        const int b = (int)(m / hw);
+        const int rem = (int)(m - (long)b * hw);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        uint4 x[NCHK];
+#pragma unroll
+        for (int i = 0; i < NCHK; ++i) {       // unconditional loads from clamped addresses, masked afterwards (no per-load branch + wait)
+            const int iy = oy * p.sh + c_dy[i], ix = ox * p.sw + c_dx[i];
+            const bool ok = c_on[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const int iyc = min(max(iy, 0), p.Hi - 1), ixc = min(max(ix, 0), p.Wi - 1);
+            const uint4 v = *(const uint4*)((const bf16_t*)p.X + (((long)b * p.Hi + iyc) * p.Wi + ixc) * p.ldx + c_ci[i]);
+            x[i].x = ok ? v.x : 0u; x[i].y = ok ? v.y : 0u; x[i].z = ok ? v.z : 0u; x[i].w = ok ? v.w : 0u;
+        }
+        float acc[NOUT];
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCHK; ++i) {
+                a = dot2_16(x[i].x, w[i][n].x, a); a = dot2_16(x[i].y, w[i][n].y, a);
+                a = dot2_16(x[i].z, w[i][n].z, a); a = dot2_16(x[i].w, w[i][n].w, a);
+            }
+            acc[n] = a;
+        }
+        // Reduce the four per-lane sums over the wave TOGETHER (10 VALU operations instead of 4 x 6 ds_bpermute round trips): two
+        // v_permlane32_swap fold the wave's halves (lanes 0-31 keep outputs 0 / 1, lanes 32-63 outputs 2 / 3), one v_permlane16_swap
+        // folds the 16-lane rows (row r keeps output r), four DPP row rotations finish inside each row: every lane of row r ends up
+        // with the total of output channel r.
+        {
+            unsigned a0 = __float_as_uint(acc[0]), a1 = __float_as_uint(acc[1]), a2 = __float_as_uint(acc[2]), a3 = __float_as_uint(acc[3]);
+            { auto r_ = __builtin_amdgcn_permlane32_swap(a0, a2, false, false); a0 = r_[0]; a2 = r_[1]; }
+            { auto r_ = __builtin_amdgcn_permlane32_swap(a1, a3, false, false); a1 = r_[0]; a3 = r_[1]; }
+            unsigned b0 = __float_as_uint(__uint_as_float(a0) + __uint_as_float(a2));     // lanes 0-31: output 0, lanes 32-63: output 2
+            unsigned b1 = __float_as_uint(__uint_as_float(a1) + __uint_as_float(a3));     // lanes 0-31: output 1, lanes 32-63: output 3
+            { auto r_ = __builtin_amdgcn_permlane16_swap(b0, b1, false, false); b0 = r_[0]; b1 = r_[1]; }
+            float c = __uint_as_float(b0) + __uint_as_float(b1);                           // row r (lanes 16 r .. 16 r + 15): output r
+            c += __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(c), 0x128, 0xf, 0xf, false));   // row_ror:8
+            c += __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(c), 0x124, 0xf, 0xf, false));   // row_ror:4
+            c += __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(c), 0x122, 0xf, 0xf, false));   // row_ror:2
+            c += __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(c), 0x121, 0xf, 0xf, false));   // row_ror:1
+            const int n = lane >> 4;
+            if ((lane & 15) == 0 && n < p.Cout) {
+                const float a = cd_finish(p, c, m, n, b);
+                if (p.y_f32) ((float*)p.Y)[m * p.ldy + n] = a; else ((bf16_t*)p.Y)[m * p.ldy + n] = f2bf(a);
+            }
+        }
     }
 }
 
@@ -406,6 +507,14 @@ extern "C" int mdx_conv2d_direct(const MdxConvDirectDesc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const bool kpar = !p.x_f32 && p.Cout <= 8 && (p.Cin % 8) == 0 && (p.ldx % 8) == 0 && (long)p.kh * p.kw * p.Cin >= 512 &&
                       ((uintptr_t)p.X & 15) == 0 && ((uintptr_t)p.W & 15) == 0;
+    // weight-stationary form: Cout <= 4, at most 6 x 64 chunks of (tap, channel) — conv_out at every width of the SD family up to Cin = 336
+    // ... Cin = 320: 360 chunks.  Enough pixels that a wave's weight prologue (6 x 4 x 16 bytes per lane) is amortised over PIX of them.
+    if (kpar && p.Cout <= 4 && (long)p.kh * p.kw * (p.Cin / 8) <= 384 && M >= 65536 && opt(OPT_CONV_OUT_WS) != 0) {
+        constexpr int PIX = 16;
+        dim3 grid((unsigned)((M + 4 * PIX - 1) / (4 * PIX)));
+        hipLaunchKernelGGL((conv_direct_kpar_ws_kernel<6, PIX>), grid, dim3(256), 0, st, p);
+        return check_launch("conv_direct_kpar_ws_kernel");
+    }
     if (kpar) {
         dim3 grid((unsigned)((M + 3) / 4));
         if (p.Cout <= 4) hipLaunchKernelGGL(conv_direct_kpar_kernel<4>, grid, dim3(256), 0, st, p);

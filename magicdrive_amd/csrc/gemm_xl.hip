@@ -179,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
 #define XL_PIECE_B(part, e, T)                                                                                                    \
     if constexpr ((e) < ((part) ? PB1 : PB0)) {                                                                                   \
         if ((T) < nt && do_dma)                                                                                                   \
-            xl_glds(rsB, lds0 + ((T) & 1) * BUF + b_lds[part][(e) < UNIT_MAX ? (e) : 0], b_voff[part][(e) < UNIT_MAX ? (e) : 0],  \
+            xl_glds_b(rsB, lds0 + ((T) & 1) * BUF + b_lds[part][(e) < UNIT_MAX ? (e) : 0], b_voff[part][(e) < UNIT_MAX ? (e) : 0],  \
                     b_soff((T)));                                                                                                 \
     }
 #define XL_ISSUE_A(h, T) { XL_PIECE_A(h, 0, T) XL_PIECE_A(h, 1, T) }
@@ -679,6 +679,41 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
             const int total = HROWS * cpr;
             const int bfirst = n0 / cs;
             const int tfirst = n0 - bfirst * cs;
+            if constexpr (NTH % (BN >> 1) == 0) {
+                // (round 4) a thread owns ONE column pair for all its rows: image / token / validity of the pair are resolved once (the
+                // generic walk below divides and searches per element pair: ~3 k scalar-ish instructions per thread and tile beside a 16 us
+                // main loop at K = 640 — the level-1/2 V^T projections ran at 520-690 TFLOP/s, their q/k siblings at 970-1130), then
+                // batches of eight LDS reads followed by eight stores.
+                constexpr int RPP2 = NTH / (BN >> 1);                    // rows per pass (4 at 256 columns)
+                const int c2 = (tid % cpr) * 2, r0 = tid / cpr;
+                int b = bfirst, t = tfirst + c2;
+                while (t >= cs) { t -= cs; ++b; }
+                const bool ok0 = n0 + c2 < p.N, ok1 = n0 + c2 + 1 < p.N;
+                const bool split = !pairs && t + 1 >= cs;                // odd cs: the pair's second token is token 0 of the next image
+                bf16_t* d0 = Cg + (long)b * p.sC + (long)(mh + r0) * p.ldc + t;
+                bf16_t* d1 = split ? Cg + (long)(b + 1) * p.sC + (long)(mh + r0) * p.ldc : d0 + 1;
+                const bf16_t* src = Cs + r0 * CSTR + c2;
+                const int rmax = min(HROWS, p.M - mh);                   // rows of this (half) tile that exist
+                constexpr int UB = 8;
+#pragma unroll 1
+                for (int u0 = 0; u0 < HROWS / RPP2; u0 += UB) {
+                    unsigned v[UB];
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) v[u] = *(const unsigned*)(src + (long)(u0 + u) * RPP2 * CSTR);
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const int row = r0 + (u0 + u) * RPP2;
+                        if (row >= rmax || !ok0) continue;
+                        const long ro = (long)(u0 + u) * RPP2 * p.ldc;
+                        if (pairs && ok1) {
+                            *(unsigned*)(d0 + ro) = v[u];
+                        } else {
+                            d0[ro] = (bf16_t)(v[u] & 0xffffu);
+                            if (ok1) d1[ro] = (bf16_t)(v[u] >> 16);
+                        }
+                    }
+                }
+            } else {
 #pragma unroll 1
             for (int idx = tid; idx < total; idx += NTH) {
                 const int row = idx / cpr, c2 = (idx - row * cpr) * 2;
@@ -696,6 +731,7 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
                         else Cg[(long)(b + 1) * p.sC + (long)(mh + row) * p.ldc] = (bf16_t)(v >> 16);
                     }
                 }
+            }
             }
         } else if (rpref) {
             if (NH == 2) fetch_residual(hh);                      // 320-wide: one batch right behind the staging barrier
@@ -867,7 +903,7 @@ __global__ __launch_bounds__(512, 2) void gemm_xlp_kernel(GCParams p) {
     set_tile(m0, n0);
 
 #define XLP_PIECE_A(h, e, T) { if ((T) < nt) xl_glds(rsA, lds0 + ((T) & 1) * BUF + a_lds[h][e], a_voff[h][e], (T) * 128); }
-#define XLP_PIECE_B(part, e, T) { if ((T) < nt) xl_glds(rsB, lds0 + ((T) & 1) * BUF + b_lds[part][e], b_voff[part][e], (T) * 128); }
+#define XLP_PIECE_B(part, e, T) { if ((T) < nt) xl_glds_b(rsB, lds0 + ((T) & 1) * BUF + b_lds[part][e], b_voff[part][e], (T) * 128); }
 #define XLP_ISSUE_A(h, T) { XLP_PIECE_A(h, 0, T) XLP_PIECE_A(h, 1, T) }
 #define XLP_ISSUE_B(part, T) { XLP_PIECE_B(part, 0, T) XLP_PIECE_B(part, 1, T) }
 #define XLP_PROLOGUE() { XLP_ISSUE_A(0, 0) XLP_ISSUE_B(0, 0) XLP_ISSUE_B(1, 0) XLP_ISSUE_A(1, 0) XLP_ISSUE_A(0, 1) XLP_ISSUE_B(0, 1) XLP_ISSUE_B(1, 1) }

@@ -14,14 +14,17 @@ int64_t opt(int id);                 // current value of a switch (api.hip; one 
 namespace mdx {
 
 #define MDX_OPTIONS(X) \
-    X(ATTN_SWZ, 1, "XCD-aware block order of attention.hip") \
+    X(ATTN_SWZ, 2, "XCD-aware block order of attention.hip: 0 off, 1 per (view, head), 2 per view (all heads of a view on one XCD)") \
     X(ATTN_NW4_BLOCKS, 256L, "attention.hip: 4-wave workgroups from this many blocks") \
     X(ATTN_NW8_BLOCKS, (1L << 40), "attention.hip: 8-wave workgroups from this many blocks") \
     X(ATTN_NW, 0, "force the waves per workgroup of attention.hip (0 = heuristic)") \
     X(ATTN2, 1, "attention2.hip for head dim 40") \
-    X(ATTN2_D80, 0, "attention2.hip also for head dim 80") \
+    X(ATTN2_D80, 2, "attention2.hip for head dim 80: 0 never, 1 always, 2 only the two-source cross-view form") \
     X(ATTN2_FOLD, 1, "attention2.hip: subtract the running maximum inside the QK MFMA when Q is pre-scaled (head dim 40)") \
+    X(ATTN2_RES, 1, "attention2.hip: kv sequences of <= 3 tiles (text context) resident in LDS, one workgroup per (view, head) walks the query blocks: 0 off, 1 for launches of >= 1024 (view, head) pairs, 2 whenever supported") \
+    X(ATTN2_VIEWMAP, 1, "attention2.hip block order: 1 = all heads and query blocks of a view on one XCD (a row's 128-byte lines are shared by the heads), 0 = per (view, head)") \
     X(ATTN2_QT, 0, "32-query tiles per wave in attention2.hip: 0 = automatic (2; 1 for one-source FOLD launches), 1 / 2 = force") \
+    X(CONV_OUT_WS, 1, "direct conv with Cout <= 4 and a long K (conv_out): weight-stationary K-parallel kernel (weights in registers, 16 pixels per wave)") \
     X(GEMM_SWZ, 1, "XCD-aware tile order of the generic / conv3x3 kernels") \
     X(C3_DBG, 0, "conv3x3 ablation bits (wrong results)") \
     X(GEMM_PIPE, 1, "software-pipelined fragment reads in the generic 128x128x64 tile") \

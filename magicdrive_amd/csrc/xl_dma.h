@@ -47,6 +47,37 @@ __device__ __forceinline__ void xl_glds(const xl_rsrc_t rs, unsigned lds_addr, u
         : "memory");
 }
 
+// The weight (B operand) pieces may carry a cache policy (side builds: -DMDX_XL_BPOL=1 sc1, 2 nt, 3 sc0 sc1): `sc1` loads are served by
+// the L2 WITHOUT allocating in the CU's 32 KiB vector L1 (MI355X_MICROARCH.md, visibility table).  Why that could pay for the 3x3
+// convolutions: the nine taps of a channel block re-read (almost) the same 256 activation lines — a 256-row A slab is exactly the L1's
+// capacity — but each tap's 40 KB weight slab streams through the same L1 in between and evicts them; with the weights bypassing L1 the
+// taps kx = 1, 2 (and most of ky + 1) of the A operand can hit.  Measured: profiles/r04_xl_bpol_ab.log.
+#ifndef MDX_XL_BPOL
+#define MDX_XL_BPOL 0
+#endif
+__device__ __forceinline__ void xl_glds_b(const xl_rsrc_t rs, unsigned lds_addr, unsigned voff, int soff) {
+#if MDX_XL_BPOL == 0
+    xl_glds(rs, lds_addr, voff, soff);
+#else
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+#if MDX_XL_BPOL == 1
+        "buffer_load_dwordx4 %2, %3, %4 offen sc1 lds\n\t"
+#elif MDX_XL_BPOL == 2
+        "buffer_load_dwordx4 %2, %3, %4 offen nt lds\n\t"
+#else
+        "buffer_load_dwordx4 %2, %3, %4 offen sc0 sc1 lds\n\t"
+#endif
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
+        : "memory");
+#endif
+}
+
 // The same descriptor with a byte bound: lanes whose (voffset + soffset) reaches `records` read zeros — row / column tails of a tile
 // expressed through the descriptor instead of through per-lane offsets (which then do not depend on the tile: gemm_xlp.hip).
 __device__ __forceinline__ xl_rsrc_t xl_make_rsrc_bounded(const void* base, long records) {

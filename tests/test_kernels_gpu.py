@@ -334,6 +334,29 @@ def test_conv_direct(dev, case):
     close(y, ref, name=case)
 
 
+@pytest.mark.parametrize("B,H,W,Cin", [(48, 28, 50, 320), (47, 28, 50, 320), (24, 54, 96, 320), (64, 28, 50, 128)])
+def test_conv_out_weight_stationary(dev, B, H, W, Cin):
+    """conv_out at sampler batch sizes (M >= 65536 pixels) runs the weight-stationary K-parallel kernel (round 4: weights in registers,
+    16 pixels per wave, packed dot products): vs F.conv2d in fp32, fp32 output like the sampler's eps; 47 views: a wave whose pixel run
+    crosses the end of the tensor; Cin = 128: lanes without a chunk.  The two routes agree to fp32 summation order."""
+    Cout, k = 4, 3
+    x = rnd(B, H, W, Cin, seed=1)
+    w = rnd(Cout, Cin, k, k, scale=(Cin * k * k) ** -0.5, seed=2, dtype=torch.float32, dev="cpu"); b = rnd(Cout, seed=3, dtype=torch.float32)
+    wp = PK.pack_conv_weight(w, BF).to(dev)
+    y = torch.full((B, H, W, Cout), float("nan"), dtype=torch.float32, device=dev)
+    O.run_ops([O.Conv(x, wp, y, bias=b, pad=(1, 1), direct=True)])
+    kern = (L.lib().mdx_last_kernel() or b"").decode()
+    assert kern == "conv_direct_kpar_ws_kernel", kern
+    y0 = torch.full_like(y, float("nan"))
+    with L.options(CONV_OUT_WS=0):
+        O.run_ops([O.Conv(x, wp, y0, bias=b, pad=(1, 1), direct=True)])
+        assert (L.lib().mdx_last_kernel() or b"").decode() == "conv_direct_kpar_kernel"
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.to(BF).float(), b.cpu(), padding=1).permute(0, 2, 3, 1)
+    assert rel_l2(y, ref) < 2e-5 and rel_l2(y0, ref) < 2e-5, (rel_l2(y, ref), rel_l2(y0, ref))
+    assert (y.cpu() - ref).abs().max() < 1e-4
+
+
 def ref_attention(q, k, v, heads, scale):
     # xformers tests/test_mem_eff_attention.py:214-264 semantics (BMHK), fp32
     B, Tq, Cc = q.shape
@@ -746,7 +769,8 @@ def attn2_route(d, Tq, xview=False, pre=False):
     """Kernel mdx_attention_bf16 must pick for (d, Tq) under the library's current switches (csrc/options.h;
     tests/test_routes_gpu.py::test_forced_attention_routes re-runs these tests with ATTN2_QT=1, ATTN2_D80=1 and ATTN2=0)."""
     mode = "xview" if xview else "self"
-    if L.get_option("ATTN2") == 0 or (d == 80 and L.get_option("ATTN2_D80") == 0):
+    d80 = L.get_option("ATTN2_D80")              # 0 never, 1 always, 2 (default): only the two-source cross-view form
+    if L.get_option("ATTN2") == 0 or (d == 80 and not (d80 == 1 or (d80 == 2 and xview))):
         return "attn_kernel<"                                       # attention.hip (prefix)
     fold = ",fold" if (pre and d == 40 and L.get_option("ATTN2_FOLD")) else ""
     qt = L.get_option("ATTN2_QT")                  # 0: automatic = 64-query waves, except one-source FOLD launches (32: three waves per SIMD)
@@ -784,6 +808,38 @@ def test_attention2(dev, B, heads, Tq, Tk, d, pre):
     assert kern.startswith(attn2_route(d, Tq, pre=pre)), kern
     ref = ref_attention(qref.float().cpu(), k.float().cpu(), v.float().cpu(), heads, d ** -0.5)
     close(o, ref, name=f"attn2 {B},{heads},{Tq},{Tk},{d}{' prescaled' if pre else ''}")
+
+
+@pytest.mark.parametrize("B,heads,Tq,Tk", [(6, 8, 1400, 78), (6, 8, 1400, 110), (6, 8, 1400, 64), (6, 8, 1400, 129), (3, 8, 777, 150), (6, 8, 300, 32),
+                                           (2, 8, 1400, 192), (6, 8, 512, 17)])
+def test_attention2_resident_short_kv(dev, B, heads, Tq, Tk):
+    """Round 4: the text-context form (kv sequences of <= 3 tiles: S = 1 + 77 + boxes) with K / V^T RESIDENT in LDS and one workgroup per
+    (view, head) walking the query blocks (attn2_kernel<.., RES>; ATTN2_RES=2 forces the route at test batch sizes).  Partial last tiles of
+    every kind: 14 / 46 / 1 / 22 valid kv (<= 32: only the first 32-kv sub-tile is multiplied), none (64, 192), a lone 17-kv tile."""
+    d = 40
+    Cc = heads * d
+    q = rnd(B, Tq, Cc, seed=1); k = rnd(B, Tk, Cc, seed=2); v = rnd(B, Tk, Cc, seed=3)
+    # a score spike in the LAST tile for one query (the deferred maximum must re-base there) and an early one
+    k[0, Tk - 1, :d] = q[0, 7, :d] * 6.0
+    k[0, 3, d:2 * d] = q[0, 9, d:2 * d] * 6.0
+    q, qref = prescale_q(q, d, True)
+    ldv = PK.round_up(Tk, 8)
+    vt = torch.full((B, Cc, ldv), float("nan"), dtype=BF, device=dev)   # garbage in the kv pad must not leak
+    vt[:, :, :Tk] = v.transpose(1, 2)
+    o = torch.full((B, Tq, Cc), float("nan"), dtype=BF, device=dev)
+    with L.options(ATTN2_RES=2):
+        O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=Tk, scale=d ** -0.5, q_prescaled=True)])
+        kern = (L.lib().mdx_last_kernel() or b"").decode()
+    torch.cuda.synchronize()
+    assert kern == "attn2_kernel<40,resident,q32,fold>", kern
+    ref = ref_attention(qref.double().cpu(), k.double().cpu(), v.double().cpu(), heads, d ** -0.5)
+    close(o, ref, name=f"attn2 resident {B},{heads},{Tq},{Tk}")
+    # same inputs through the streaming form: the two routes agree to rounding
+    o2 = torch.full((B, Tq, Cc), float("nan"), dtype=BF, device=dev)
+    with L.options(ATTN2_RES=0):
+        O.run_ops([O.Attn(q, k, vt, o2, heads=heads, Tk=Tk, scale=d ** -0.5, q_prescaled=True)])
+    torch.cuda.synchronize()
+    assert rel_l2(o, o2) < 4e-3, rel_l2(o, o2)
 
 
 @pytest.mark.parametrize("pre", [False, True])

@@ -40,6 +40,22 @@ def main():
             return O.Gemm(A, W, C, bias=torch.randn(N, device=dev), R=r(M, No) if res else None, epilogue=epi, ws=ws), 2.0 * M * N * K
         cases[name] = mk
 
+    def gemm_vt(name, T, C):            # the batch-flattened V^T projection of levels 1 / 2 (GCParams.col_split epilogue)
+        def mk():
+            from magicdrive_amd import packing as PK
+            X = r(B, T, C); Wv = r(C, C); Vt = torch.zeros(B, C, PK.round_up(T, 8), dtype=BF, device=dev)
+            return O.Gemm(Wv, X, Vt[:, :, :T]), 2.0 * B * T * C * C
+        cases[name] = mk
+
+    def conv_out(name, h, w, cin):      # the UNet's conv_out: Cout = 4, fp32 eps (direct K-parallel kernels)
+        def mk():
+            x = r(B, h, w, cin); wt = r(4, 3, 3, cin); y = torch.empty(B, h, w, 4, dtype=torch.float32, device=dev)
+            return O.Conv(x, wt, y, bias=torch.randn(4, device=dev), direct=True), 2.0 * B * h * w * 4 * 9 * cin
+        cases[name] = mk
+
+    gemm_vt("vt_L1", 350, 640)
+    gemm_vt("vt_L2", 91, 1280)
+    conv_out("convout_28x50_320", 28, 50, 320)
     conv("c_28x50_640_320", 28, 50, 640, 320)
     conv("c_28x50_960_320", 28, 50, 960, 320)
     conv("c_14x25_640_640", 14, 25, 640, 640)
