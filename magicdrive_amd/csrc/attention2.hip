@@ -109,7 +109,11 @@ constexpr float A2_DEFER = 4.0f;   // log2 units: the running max is only raised
 // the LDS image, the DMA round trip of two tiles, launch / drain): 168 TFLOP/s.  Here ONE workgroup per (view, head) stages all
 // ntile <= A2_RING tiles once and then walks the query blocks: no DMA, no barrier and no vmcnt wait inside the walk.
 template <int D8, bool TWO, int QT, bool FOLD, bool RES = false>
-__global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : (RES ? 4 : 3)) void attn2_kernel(Attn2Params p) {
+#ifndef A2_LB4_TWO
+#define A2_LB4_TWO 1       // 4 waves per SIMD also for the 32-query cross-view form (128 VGPRs, 9 spilled outside the tile loop): 4147-4215 us vs 4238 at
+                           // 3 waves and 4253 with 64-query waves (576 views, profiles/r04_attn_xview_lb4_ab.log); -DA2_LB4_TWO=0 restores 3 waves
+#endif
+__global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : ((RES || (A2_LB4_TWO && TWO)) ? 4 : 3)) void attn2_kernel(Attn2Params p) {
     static_assert(!RES || (!TWO && QT == 1), "resident K / V^T: one kv source, 32-query waves");
     constexpr int D = D8 * 8;
     static_assert(!FOLD || (D % 16) == 8, "FOLD needs the 8 spare k slots of a head dim that is 8 mod 16");
@@ -644,7 +648,8 @@ int launch_attn2(const Attn2Params& p, hipStream_t st) {
         // FOLD frees the registers / VALU slots of the scale-and-subtract: with it the 32-query form (<= 142 VGPRs: three waves per SIMD)
         // is the faster one for one kv source (768 views, T = 1400: self 3157 vs 3332 us, text context 640 vs 795 us; the two-source
         // cross-view form is equal, 5888 vs 5882 us: profiles/r03_attn_qt_fold_ab.log); ATTN2_QT = 2 keeps 64-query waves everywhere.
-        if (fold) return (two && (qt_forced64 || (p.nsrc == 2 && !p.joint))) ? launch_attn2_d<5, 2, true>(p, st) : launch_attn2_d<5, 1, true>(p, st);
+        // round 4: with the straight-line issue path and four waves per SIMD the 32-query form also wins (by 1-2.5 %) for the two-source launches
+        if (fold) return (two && qt_forced64) ? launch_attn2_d<5, 2, true>(p, st) : launch_attn2_d<5, 1, true>(p, st);
         return two ? launch_attn2_d<5, 2, false>(p, st) : launch_attn2_d<5, 1, false>(p, st);
     }
     return launch_attn2_d<10, 1, false>(p, st);

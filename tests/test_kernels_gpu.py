@@ -773,8 +773,8 @@ def attn2_route(d, Tq, xview=False, pre=False):
     if L.get_option("ATTN2") == 0 or (d == 80 and not (d80 == 1 or (d80 == 2 and xview))):
         return "attn_kernel<"                                       # attention.hip (prefix)
     fold = ",fold" if (pre and d == 40 and L.get_option("ATTN2_FOLD")) else ""
-    qt = L.get_option("ATTN2_QT")                  # 0: automatic = 64-query waves, except one-source FOLD launches (32: three waves per SIMD)
-    q = 64 if (d == 40 and Tq >= 512 and qt != 1 and (qt == 2 or not fold or xview)) else 32
+    qt = L.get_option("ATTN2_QT")                  # 0: automatic = 64-query waves, except FOLD launches (32: four waves per SIMD)
+    q = 64 if (d == 40 and Tq >= 512 and qt != 1 and (qt == 2 or not fold)) else 32
     return f"attn2_kernel<{d},{mode},q{q}{fold}>"
 
 

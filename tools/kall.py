@@ -15,7 +15,7 @@ from magicdrive_amd import _lib as L, ops as O, packing as PK  # noqa: E402
 
 BF = torch.bfloat16
 dev = torch.device("cuda")
-B = int(os.environ.get("KONE_VIEWS", "768"))       # the bench batch: 128 scenes x 6 views
+B = int(os.environ.get("KONE_VIEWS", "576"))       # the bench's plan: 192 scenes per call on two streams = 96 scenes x 6 views per step program
 REPS = int(os.environ.get("KONE_REPS", "3"))
 r = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(BF)
 ws = torch.empty(64 * 1024 * 1024 // 4, dtype=torch.float32, device=dev)
@@ -60,6 +60,11 @@ gemm("qk_L1", B * 350, 1280, 640)
 gemm("geglu_L2", B * 91, 10240, 1280, epi=1)
 attn("attn_self_L0", 1400, 320, False)
 attn("attn_xview_L0", 1400, 320, True)
+# the text-context attention of level 0 (S = 1 + 77 tokens; K / V^T from the prologue): attn2_kernel<40,resident,...>
+_q = r(B, 1400, 320); _kc = r(B, 78, 320); _vt = torch.zeros(B, 320, 80, dtype=BF, device=dev); _vt[:, :, :78] = r(B, 320, 78)
+_q = (_q.float() * (40 ** -0.5 * 1.4426950408889634)).to(BF); _o = torch.empty(B, 1400, 320, dtype=BF, device=dev)
+cases.append(("attn_ctx_L0", O.Attn(_q, _kc, _vt, _o, heads=8, Tk=78, scale=40 ** -0.5, q_prescaled=True), 4.0 * B * 1400 * 78 * 320,
+              dict(read=B * 1400 * 320 * 2 + B * 78 * 320 * 2 * 2, write=B * 1400 * 320 * 2)))
 x = r(B, 1400, 320); y = torch.empty_like(x)
 cases.append(("gn_L0", O.GroupNorm(x, y, torch.ones(320, device=dev), torch.zeros(320, device=dev), 32, 1e-5, True, ws=ws), 0.0,
               dict(read=B * 1400 * 320 * 2 * 2, write=B * 1400 * 320 * 2)))
@@ -77,5 +82,5 @@ for name, op, fl, by in cases:
 out = os.environ.get("KALL_INFO")
 if out:
     with open(out, "w") as f:
-        json.dump(dict(views=B, reps=REPS, cases=info), f, indent=1)
+        json.dump(dict(views=B, reps=REPS, build_id=L.build_id(), cases=info), f, indent=1)
 print(json.dumps(info))

@@ -11,7 +11,7 @@ import os
 import sys
 
 d = sys.argv[1]
-out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_pmc_summary.json")
+out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_pmc_summary.json")
 cases = json.load(open(os.path.join(d, "cases.json")))
 reps = cases["reps"]
 by_kernel = collections.defaultdict(list)        # kernel name prefix -> [case]
@@ -37,7 +37,8 @@ def match(kname, case_kernel):
         return ("true" in kname.split("attn_kernel")[1]) == ("xview" in tag)
     if base == "attn2_kernel":                      # attn2_kernel<D8, TWO, QT, FOLD>: second argument = the two-neighbour (cross-view) form
         args = kname.split("attn2_kernel<")[1].split(">")[0].replace(" ", "").split(",")
-        return (args[1] == "true") == ("xview" in tag) and (args[3] == "true") == ("fold" in tag)
+        res = len(args) > 4 and args[4] == "true"     # (round 4) fifth argument: K / V^T resident in LDS
+        return (args[1] == "true") == ("xview" in tag) and (args[3] == "true") == ("fold" in tag) and res == ("resident" in tag) and (args[0] == tag.split(",")[0].lstrip("<").replace("40", "5").replace("80", "10"))
     if base == "gemm_ws_kernel":
         return ("<true" in kname.replace(" ", "")) == ("geglu" in tag)
     return True
@@ -79,6 +80,7 @@ for f in sorted(glob.glob(os.path.join(d, "**", "stats_kernel_trace.csv"), recur
                     durations[name] = [a + b for a, b in zip(prev, seg)] if (prev and len(prev) == len(seg) and "+" in case_kernel) else seg
 summary = {"note": "rocprofv3 --kernel-trace --pmc <group> (separate passes; tools/pmc_collect.sh over tools/kall.py), %d views, averages over %d launches; "
                    "fetch = FETCH_SIZE x 2 (gfx950 correction), sizes in bytes; *_frac counters are ratios of the SQ sums" % (cases["views"], reps),
+           "build_id": cases.get("build_id"),      # mdx_build_id() of the library the passes ran on: bench.py reports these counters only beside the same build
            "cases": {}, "kernels": {}}
 for name, c in cases["cases"].items():
     cs = {k: sum(v) / len(v) for k, v in counters[name].items()}
