@@ -657,6 +657,27 @@ def test_error_paths(dev):
         O.run_ops([O.Attn(q, q, torch.zeros(1, 12, 8, dtype=BF, device=dev), torch.zeros_like(q), heads=1, Tk=8, scale=1.0)])  # d=12
 
 
+def test_ddim_scheduler_step_device_timestep_hit_and_miss(dev):
+    """DDIMScheduler.step as user code drives it (scheduling_ddim.py:325-445): a DEVICE-side timestep selects its coefficient row without a
+    host sync; a timestep that is not in the scheduler's list cannot raise there, so the kernel poisons the result with NaN (ADVICE r3:
+    round 3 silently used row 0), while a host-side timestep still raises ValueError."""
+    from magicdrive_amd import schedulers
+    from oracle import denoiser as D
+    s = schedulers.DDIMScheduler(); ts = s.set_timesteps(10)
+    o = D.DDIM(); o.set_timesteps(10)
+    x = torch.randn(2, 4, 28, 50, device=dev); e = torch.randn(2, 4, 28, 50, device=dev)
+    t = ts[3]
+    got = s.step(e, t.to(dev), x).prev_sample
+    want = o.step(e.cpu(), int(t), x.cpu())
+    assert rel_l2(got, want) < 1e-6
+    assert rel_l2(s.step(e, int(t), x).prev_sample, want) < 1e-6
+    miss = s.step(e, torch.tensor(int(t) + 1, device=dev), x).prev_sample
+    torch.cuda.synchronize()
+    assert torch.isnan(miss).all()
+    with pytest.raises(ValueError):
+        s.step(e, int(t) + 1, x)
+
+
 def test_cfg_ddim_bf16_padded_model_input(dev):
     # x_in as the channels-last bf16 copy with pixel stride 8 that conv_in's MFMA path reads
     npx, Cc = 6 * 28 * 50, 4
