@@ -1,10 +1,12 @@
-"""AutoencoderKL (decoder side) — drop-in for the `vae` the reference pipeline decodes with
-(pipeline_bev_controlnet.py:100-112 -> diffusers AutoencoderKL.decode, dif:models/autoencoder_kl.py:173-198).
+"""AutoencoderKL — drop-in for the `vae` the reference pipeline decodes with (pipeline_bev_controlnet.py:100-112 -> diffusers
+AutoencoderKL.decode, dif:models/autoencoder_kl.py:173-198) and, round 4, encodes the known views of the given-view demo with
+(demo/run_cond_on_view.py:79-86: `pipe.vae.encode(x).latent_dist.mean * pipe.vae.config.scaling_factor`; dif:models/autoencoder_kl.py:127-171).
 
-Only what the sampler path touches is built: `decode(z).sample`, `.config.scaling_factor`, `.to()`, `.dtype`, `enable_slicing()`
-(accepted: the op program already decodes one scene's views at a time), `from_pretrained` on the reference checkpoint layout
-`<sd15>/vae/{config.json, diffusion_pytorch_model.(safetensors|bin)}` (encoder / quant_conv tensors are ignored).  The arithmetic is
-an op program on libmdx (magicdrive_amd/vae.py); there is no CPU path.
+Only what those callers touch is built: `decode(z).sample`, `encode(x).latent_dist` (`.mean`, `.mode()`, `.sample(generator)`, `.logvar`,
+`.std`), `.config.scaling_factor`, `.to()`, `.dtype`, `enable_slicing()` (accepted: the op programs already run one scene's views at a
+time), `from_pretrained` on the reference checkpoint layout `<sd15>/vae/{config.json, diffusion_pytorch_model.(safetensors|bin)}`.  The
+encoder / quant_conv tensors are optional: a decoder-only state dict still loads and `encode` then raises.  The arithmetic is op programs
+on libmdx (magicdrive_amd/vae.py); there is no CPU path.
 """
 from __future__ import annotations
 
@@ -18,7 +20,7 @@ import torch
 
 from . import spec
 from ..engine import PackedNet
-from ..vae import VaeDecodePlan
+from ..vae import VaeDecodePlan, VaeEncodePlan
 from ..denoiser import PlanCache
 
 CONFIG_NAME = "config.json"
@@ -27,6 +29,29 @@ WEIGHTS_ST, WEIGHTS_BIN = "diffusion_pytorch_model.safetensors", "diffusion_pyto
 
 class DecoderOutput(SimpleNamespace):
     pass
+
+
+class AutoencoderKLOutput(SimpleNamespace):
+    pass
+
+
+class DiagonalGaussianDistribution:
+    """dif:models/vae.py:306-357 on the moments the encode program produced (fp32 [mean | logvar] along dim 1)."""
+
+    def __init__(self, parameters: torch.Tensor):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+
+    def sample(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        gdev = generator.device if isinstance(generator, torch.Generator) else self.mean.device
+        noise = torch.randn(self.mean.shape, generator=generator, device=gdev, dtype=self.mean.dtype).to(self.mean.device)
+        return self.mean + self.std * noise
+
+    def mode(self) -> torch.Tensor:
+        return self.mean
 
 
 class AutoencoderKL:
@@ -40,6 +65,17 @@ class AutoencoderKL:
             if tuple(state_dict[k].shape) != tuple(shp):
                 raise ValueError(f"AutoencoderKL: {k} has shape {tuple(state_dict[k].shape)}, config implies {tuple(shp)}")
         self._sd = OrderedDict((k, state_dict[k].detach()) for k in shapes)
+        # encoder + quant_conv: optional (the sampler only decodes); all of them or none
+        enc = spec.vae_encoder_param_shapes(self.vcfg)
+        have = [k for k in enc if k in state_dict]
+        self.has_encoder = len(have) == len(enc)
+        if have and not self.has_encoder:
+            raise KeyError(f"AutoencoderKL: state dict holds {len(have)} of the {len(enc)} encoder tensors, e.g. lacks {[k for k in enc if k not in state_dict][:3]}")
+        if self.has_encoder:
+            for k, shp in enc.items():
+                if tuple(state_dict[k].shape) != tuple(shp):
+                    raise ValueError(f"AutoencoderKL: {k} has shape {tuple(state_dict[k].shape)}, config implies {tuple(shp)}")
+                self._sd[k] = state_dict[k].detach()
         self._dtype = torch_dtype
         self._device = torch.device("cpu")
         self._packed: Optional[PackedNet] = None
@@ -48,8 +84,11 @@ class AutoencoderKL:
         self.max_images_per_pass = 6          # one scene's views per program run (bounds activation memory: 138 MB per 128-ch 224x400 map)
 
     @classmethod
-    def from_config(cls, vcfg: Dict, seed: int = 0, torch_dtype=torch.bfloat16):
-        return cls(vcfg, spec.random_state_dict(spec.vae_decoder_param_shapes(vcfg), seed), torch_dtype)
+    def from_config(cls, vcfg: Dict, seed: int = 0, torch_dtype=torch.bfloat16, with_encoder: bool = False):
+        sd = spec.random_state_dict(spec.vae_decoder_param_shapes(vcfg), seed)
+        if with_encoder:
+            sd.update(spec.random_state_dict(spec.vae_encoder_param_shapes(vcfg), seed + 1000))
+        return cls(vcfg, sd, torch_dtype)
 
     @classmethod
     def from_pretrained(cls, path: str, torch_dtype=torch.bfloat16, subfolder: Optional[str] = None, **unused):
@@ -142,6 +181,32 @@ class AutoencoderKL:
             # otherwise (incl. fp32 requests: operands are 16-bit on the MFMA path either way, accumulation is fp32)
             self._packed = PackedNet(self._sd, self._device, torch.float16 if self._dtype == torch.float16 else torch.bfloat16)
         return self._packed
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        """x (n, 3, H, W) in [-1, 1], H and W multiples of 8 -> AutoencoderKLOutput(latent_dist=DiagonalGaussianDistribution) over
+        (n, 4, H / 8, W / 8) latents (un-scaled: callers multiply by config.scaling_factor, demo/run_cond_on_view.py:84)."""
+        if not self.has_encoder:
+            raise ValueError("this AutoencoderKL was built from a decoder-only state dict: no encoder / quant_conv tensors to encode with")
+        if self._device.type != "cuda":
+            raise RuntimeError("AutoencoderKL.to('cuda') first: the encoder has no CPU path")
+        n, _, H, W = x.shape
+        if H % 8 or W % 8:
+            raise ValueError(f"image size {H}x{W}: both sides must be multiples of 8 (three stride-2 stages)")
+        outs = []
+        for i0 in range(0, n, self.max_images_per_pass):
+            xi = x[i0:i0 + self.max_images_per_pass]
+            key = ("enc", xi.shape[0], H, W)
+            plan = self._plans.get(key)
+            if plan is None:
+                with torch.cuda.device(self._device):
+                    plan = VaeEncodePlan(self.vcfg, self.packed(), self._device, xi.shape[0], (H, W))
+                    plan.compile()
+                self._plans.put(key, plan)
+            outs.append(plan.run(xi))
+        moments = torch.cat(outs).to(x.dtype if x.dtype.is_floating_point else torch.float32)
+        dist = DiagonalGaussianDistribution(moments)
+        return AutoencoderKLOutput(latent_dist=dist) if return_dict else (dist,)
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True):

@@ -85,6 +85,43 @@ def vae_decoder_param_shapes(vcfg) -> "OrderedDict[str, Tuple[int, ...]]":
     return sh
 
 
+def vae_encoder_param_shapes(vcfg) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Encoder + quant_conv of AutoencoderKL (dif:models/vae.py:38-150, dif:models/autoencoder_kl.py:95-110): conv_in, one DownEncoderBlock2D
+    per level (layers_per_block resnets, a stride-2 conv with (0, 1, 0, 1) zero padding except after the last), mid block (resnet,
+    single-head attention, resnet), GroupNorm + SiLU + conv_out to 2 x latent_channels, quant_conv 1x1.  What the given-view demo calls
+    through `pipe.vae.encode(...).latent_dist.mean` (demo/run_cond_on_view.py:79-86)."""
+    sh: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    boc = vcfg["block_out_channels"]; L = vcfg["layers_per_block"]; zc = vcfg["latent_channels"]
+    cin = vcfg.get("in_channels", 3)
+    sh["encoder.conv_in.weight"] = (boc[0], cin, 3, 3); sh["encoder.conv_in.bias"] = (boc[0],)
+
+    def resnet(pre, ci, co):
+        sh[pre + "norm1.weight"] = (ci,); sh[pre + "norm1.bias"] = (ci,)
+        sh[pre + "conv1.weight"] = (co, ci, 3, 3); sh[pre + "conv1.bias"] = (co,)
+        sh[pre + "norm2.weight"] = (co,); sh[pre + "norm2.bias"] = (co,)
+        sh[pre + "conv2.weight"] = (co, co, 3, 3); sh[pre + "conv2.bias"] = (co,)
+        if ci != co:
+            sh[pre + "conv_shortcut.weight"] = (co, ci, 1, 1); sh[pre + "conv_shortcut.bias"] = (co,)
+    prev = boc[0]
+    for i, c in enumerate(boc):
+        for j in range(L):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}.", prev if j == 0 else c, c)
+        if i != len(boc) - 1:
+            sh[f"encoder.down_blocks.{i}.downsamplers.0.conv.weight"] = (c, c, 3, 3); sh[f"encoder.down_blocks.{i}.downsamplers.0.conv.bias"] = (c,)
+        prev = c
+    top = boc[-1]
+    a = "encoder.mid_block.attentions.0."
+    sh[a + "group_norm.weight"] = (top,); sh[a + "group_norm.bias"] = (top,)
+    for nm in ("to_q", "to_k", "to_v", "to_out.0"):
+        sh[a + nm + ".weight"] = (top, top); sh[a + nm + ".bias"] = (top,)
+    resnet("encoder.mid_block.resnets.0.", top, top)
+    resnet("encoder.mid_block.resnets.1.", top, top)
+    sh["encoder.conv_norm_out.weight"] = (top,); sh["encoder.conv_norm_out.bias"] = (top,)
+    sh["encoder.conv_out.weight"] = (2 * zc, top, 3, 3); sh["encoder.conv_out.bias"] = (2 * zc,)
+    sh["quant_conv.weight"] = (2 * zc, 2 * zc, 1, 1); sh["quant_conv.bias"] = (2 * zc,)
+    return sh
+
+
 PLUS_MAP_EMBEDDER = "magicdrive.networks.map_embedder.BEVControlNetConditioningEmbeddingPlus"   # configs/exp/272x736.yaml:18
 
 

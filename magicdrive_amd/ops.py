@@ -150,6 +150,9 @@ class Conv:
     sel: Optional[torch.Tensor] = None
     stride: tuple = (1, 1)
     pad: tuple = (1, 1)
+    pad_end: Optional[tuple] = None          # zero padding at the bottom / right when it differs from `pad` (Downsample2D with padding=0:
+                                             # F.pad(x, (0, 1, 0, 1)), resnet.py:215-217) — the kernels zero-fill every tap outside the image,
+                                             # so only the output size depends on it
     epilogue: int = L.EPI_NONE
     temb_sel_stride: int = 0
     temb_b_stride: int = 0
@@ -170,7 +173,8 @@ class Conv:
         _chk(B == B2 and Cout == Co2 and Cin == Ci2, f"conv {self.name}: shape mismatch")
         sh, sw = self.stride
         ph, pw = self.pad
-        _chk(Ho == (Hi + 2 * ph - kh) // sh + 1 and Wo == (Wi + 2 * pw - kw) // sw + 1, f"conv {self.name}: output size")
+        phe, pwe = self.pad_end if self.pad_end is not None else self.pad
+        _chk(Ho == (Hi + ph + phe - kh) // sh + 1 and Wo == (Wi + pw + pwe - kw) // sw + 1, f"conv {self.name}: output size")
         d = L.MdxConvDirectDesc() if self.direct else L.MdxConvDesc()
         d.X, d.Wt, d.Y = _p(self.X), _p(self.Wt), _p(self.Y)
         if self.R is not None:

@@ -1,4 +1,5 @@
-"""VAE decode as an op program on the same HIP kernels as the sampler.
+"""VAE decode — and, round 4, VAE encode (what the given-view demo calls on its known views) — as op programs on
+the same HIP kernels as the sampler.
 
 AutoencoderKL.decode = post_quant_conv (1x1) -> Decoder (dif:models/vae.py:152-275): conv_in, mid block (resnet, single-head
 512-channel attention, resnet), four UpDecoderBlock2D (3 resnets + nearest x2 + conv), GroupNorm + SiLU + conv_out.
@@ -21,6 +22,105 @@ from .engine import PackedNet
 
 BF16, F32 = torch.bfloat16, torch.float32
 ZPAD = 8      # latent channels padded 4 -> 8 so conv_in runs on the MFMA path
+
+
+def _vae_attention(plan, net, x, a, G, eps, buf, emit):
+    return VaeDecodePlan._attention(plan, net, x, a, G, eps, buf, emit)
+
+
+class VaeEncodePlan:
+    """AutoencoderKL.encode up to the moments (dif:models/autoencoder_kl.py:127-171: `quant_conv(encoder(x))`): conv_in, four
+    DownEncoderBlock2D (2 resnets + a stride-2 3x3 conv on the input zero-padded by one row / column at the bottom / right,
+    resnet.py:215-217), the mid block (resnet, single-head attention, resnet), GroupNorm + SiLU + conv_out (2 x latent channels) and the
+    1x1 quant_conv — the caller of `pipe.vae.encode(pixel_values).latent_dist.mean` in demo/run_cond_on_view.py:79-86.  Same kernels and
+    the same mid-block attention as the decoder; the image's 3 channels are zero-padded to 8 so conv_in runs on the MFMA path; the last two
+    layers (Cout = 8) run on the direct kernels with fp32 outputs, so the moments never pass through a 16-bit store."""
+
+    def __init__(self, vcfg, net: PackedNet, device, n_img: int, image_hw):
+        self.vcfg, self.device, self.n = vcfg, device, n_img
+        H, W = image_hw
+        G, eps = vcfg["norm_num_groups"], 1e-6
+        zc = vcfg["latent_channels"]
+        cin = vcfg.get("in_channels", 3)
+        self.ops: List[object] = []
+        self.keep: List[torch.Tensor] = []
+        self.ws = torch.empty(64 * 1024 * 1024 // 4, dtype=F32, device=device)
+        emit = self.ops.append
+        H16 = net.dtype
+
+        def buf(*shape, dtype=H16, zero=False):
+            t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=device)
+            self.keep.append(t)
+            return t
+
+        def gn(x, pre, silu):
+            y = buf(*x.shape)
+            n_, h_, w_, C = x.shape
+            emit(O.GroupNorm(x.view(n_, h_ * w_, C), y.view(n_, h_ * w_, C), net.vec(pre + "weight"), net.vec(pre + "bias"), G, eps, silu, ws=self.ws, name="vae." + pre))
+            return y
+
+        def conv3(x, key, R=None):
+            wt = net.conv(key + "weight")
+            y = buf(x.shape[0], x.shape[1], x.shape[2], wt.shape[0])
+            emit(O.Conv(x, wt, y, bias=net.vec(key + "bias"), R=R, ws=self.ws, name="vae." + key))
+            return y
+
+        def resnet(x, pre):
+            a = gn(x, pre + "norm1.", True)
+            hcv = conv3(a, pre + "conv1.")
+            b = gn(hcv, pre + "norm2.", True)
+            sc = x
+            if net.has(pre + "conv_shortcut.weight"):
+                cout = net.sd[pre + "conv_shortcut.weight"].shape[0]
+                sc = buf(x.shape[0], x.shape[1], x.shape[2], cout)
+                emit(O.Gemm(x.view(-1, x.shape[3]), net.lin(pre + "conv_shortcut.weight"), sc.view(-1, cout), bias=net.vec(pre + "conv_shortcut.bias"),
+                            ws=self.ws, name="vae." + pre + "shortcut"))
+            return conv3(b, pre + "conv2.", R=sc)
+
+        # ---- input: image fp32 NCHW in [-1, 1] -> 16-bit NHWC, channels zero-padded 3 -> ZPAD
+        self.x_in = torch.zeros(n_img, cin, H, W, dtype=F32, device=device)
+        xp = buf(n_img, H, W, ZPAD, zero=True)
+        emit(O.Layout(self.x_in, xp[..., :cin], True, name="vae.x.nhwc"))
+        c0 = net.sd["encoder.conv_in.weight"].shape[0]
+        x = buf(n_img, H, W, c0)
+        emit(O.Conv(xp, net.conv_cin_padded("encoder.conv_in.weight", ZPAD), x, bias=net.vec("encoder.conv_in.bias"), ws=self.ws, name="vae.enc.conv_in"))
+        nlev = len(vcfg["block_out_channels"])
+        for i in range(nlev):
+            for j in range(vcfg["layers_per_block"]):
+                x = resnet(x, f"encoder.down_blocks.{i}.resnets.{j}.")
+            if i != nlev - 1:
+                key = f"encoder.down_blocks.{i}.downsamplers.0.conv."
+                Ho, Wo = (x.shape[1] + 1 - 3) // 2 + 1, (x.shape[2] + 1 - 3) // 2 + 1
+                y = buf(n_img, Ho, Wo, x.shape[3])
+                emit(O.Conv(x, net.conv(key + "weight"), y, bias=net.vec(key + "bias"), stride=(2, 2), pad=(0, 0), pad_end=(1, 1), ws=self.ws, name="vae." + key))
+                x = y
+        x = resnet(x, "encoder.mid_block.resnets.0.")
+        x = _vae_attention(self, net, x, "encoder.mid_block.attentions.0.", G, eps, buf, emit)
+        x = resnet(x, "encoder.mid_block.resnets.1.")
+        x = gn(x, "encoder.conv_norm_out.", True)
+        m1 = buf(n_img, x.shape[1], x.shape[2], 2 * zc, dtype=F32)
+        emit(O.Conv(x, net.conv("encoder.conv_out.weight"), m1, bias=net.vec("encoder.conv_out.bias"), direct=True, name="vae.enc.conv_out"))
+        self.moments_nhwc = buf(n_img, x.shape[1], x.shape[2], 2 * zc, dtype=F32)
+        emit(O.Conv(m1, net.conv("quant_conv.weight"), self.moments_nhwc, bias=net.vec("quant_conv.bias"), stride=(1, 1), pad=(0, 0), direct=True, name="vae.quant_conv"))
+        self.program = None
+
+    def compile(self):
+        self.program = O.build_program(self.ops)
+
+    def run(self, x: torch.Tensor) -> torch.Tensor:
+        """x (n_img, 3, H, W) in [-1, 1] -> moments (n_img, 2 * latent_channels, H / 8, W / 8) fp32 = [mean | logvar]."""
+        if self.program is None:
+            self.compile()
+        with torch.cuda.device(self.device):
+            self.x_in.copy_(x.to(self.device, F32))
+            self.program.run(torch.cuda.current_stream(self.device).cuda_stream)
+            return self.moments_nhwc.permute(0, 3, 1, 2).contiguous()
+
+    def release(self):
+        if self.program is not None:
+            self.program.destroy()
+        self.program = None
+        self.ops, self.keep = [], []
 
 
 class VaeDecodePlan:

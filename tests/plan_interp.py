@@ -61,7 +61,11 @@ def run_gemm(op: O.Gemm):
 def run_conv(op: O.Conv):
     x = op.X.float().permute(0, 3, 1, 2)
     w = op.Wt.float().permute(0, 3, 1, 2)
-    y = F.conv2d(x, w, None if op.bias is None else op.bias.float(), stride=op.stride, padding=op.pad)
+    if op.pad_end is not None and tuple(op.pad_end) != tuple(op.pad):       # asymmetric zero padding (Downsample2D with padding = 0)
+        x = F.pad(x, (op.pad[1], op.pad_end[1], op.pad[0], op.pad_end[0]))
+        y = F.conv2d(x, w, None if op.bias is None else op.bias.float(), stride=op.stride, padding=0)
+    else:
+        y = F.conv2d(x, w, None if op.bias is None else op.bias.float(), stride=op.stride, padding=op.pad)
     if op.temb is not None:
         B, Cout = y.shape[0], y.shape[1]
         y = y + _temb_rows(op, B, Cout)[:, :, None, None]

@@ -415,7 +415,7 @@ def test_run_cond_on_view_call_sequence_replayed(tmp_path):
     sc = synthetic.make_scene_batch(1, ctx_dim=tcfg["cross_attention_dim"], max_len=5)
     n_cam = 6
     conditional_latents = [[None] * n_cam]
-    conditional_latents[0][0] = torch.zeros(4, 28, 50)          # stands in for vae.encode(pixel_values).latent_dist.mean * scaling_factor (:79-86; the VAE ENCODER is outside the built path)
+    conditional_latents[0][0] = torch.zeros(4, 28, 50)          # stands in for vae.encode(pixel_values).latent_dist.mean * scaling_factor (:79-86; GPU-only: tests/test_e2e_gpu.py::test_vae_encode_*)
     with pytest.raises(RuntimeError, match="cuda"):             # every argument accepted; the sampler itself has no CPU path
         pipe(prompt=None, image=sc["bev_map"], camera_param=sc["camera_param"], height=224, width=400, conditional_latents=conditional_latents,
              generator=torch.manual_seed(0), bev_controlnet_kwargs={"bboxes_3d_data": sc["bboxes_3d_data"]}, prompt_embeds=sc["prompt_embeds"],

@@ -270,6 +270,28 @@ def test_vae_decode_plan_matches_golden():
     assert rel_l2(img, G["image"].float()) < 3e-2, rel_l2(img, G["image"].float())
 
 
+def test_vae_encode_plan_matches_golden():
+    """Round 4: the VAE ENCODE op program (what demo/run_cond_on_view.py:79-86 calls on its known views: conv_in, four down blocks whose
+    stride-2 convs pad only bottom / right, mid block, conv_out, quant_conv) in the CPU interpreter vs diffusers' AutoencoderKL.encode
+    (tests/golden/tiny_vae_encode.pt, tools/make_golden.py vaeenc): mean and log-variance of the latent distribution."""
+    from magicdrive_amd.vae import VaeEncodePlan
+    G = torch.load(os.path.join(GOLD, "tiny_vae_encode.pt"))
+    vcfg = spec.VAE_TINY_CONFIG
+    sd = spec.random_state_dict(spec.vae_decoder_param_shapes(vcfg), G["weights_seed"])
+    sd.update(spec.random_state_dict(spec.vae_encoder_param_shapes(vcfg), G["weights_seed"] + 1000))
+    assert abs(float(sum(v.double().abs().sum() for v in sd.values())) - G["checksum"]) < 1e-6 * G["checksum"]
+    plan = VaeEncodePlan(vcfg, PackedNet(sd, CPU), CPU, 2, (56, 104))
+    # the three downsampling convs are stride 2, pad 0 at the top / left and 1 at the bottom / right (resnet.py:215-217)
+    downs = [op for op in plan.ops if getattr(op, "name", "").endswith("downsamplers.0.conv.")]
+    assert len(downs) == 3 and all(op.stride == (2, 2) and op.pad == (0, 0) and op.pad_end == (1, 1) for op in downs)
+    plan.x_in.copy_(torch.rand(2, 3, 56, 104, generator=torch.Generator().manual_seed(G["x_seed"])) * 2 - 1)
+    plan_interp.run(plan.ops)
+    mom = plan.moments_nhwc.permute(0, 3, 1, 2)
+    assert tuple(mom.shape) == (2, 8, 7, 13)
+    e_mean, e_lv = rel_l2(mom[:, :4], G["mean"]), rel_l2(mom[:, 4:], G["logvar"])
+    assert e_mean < 3e-2 and e_lv < 3e-2, (e_mean, e_lv)
+
+
 def test_fused_qkv_op_equals_separate_projections():
     """The level-0 fused q/k/v op (engine.self_like_attention) in the CPU interpreter == the q/k GEMM + batched V^T GEMM it replaces."""
     import magicdrive_amd.ops as O

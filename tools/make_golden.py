@@ -32,6 +32,7 @@ Round 4:
   tiny_forward_cxyz.pt `... cxyz`   bbox_embedder mode='cxyz' (the reference class default: 4 points per box), module forwards.
   sd15_loop_given_view.pt `... sd15given`  SD-1.5 size, REAL reference given-view pipeline, camera + 32 boxes + map, CFG 2.0, 10 DDIM
                     steps, views 0 and 3 given: the headline-size loop whose views genuinely differ.
+  tiny_vae_encode.pt `... vaeenc`   diffusers AutoencoderKL.encode (mean / logvar / one sample) of the tiny VAE on two 56x104 images.
   `... cpuref` writes profiles/r04_cpu_reference_vs_port.json (reference vs CPU port seconds per denoise step, same threads).
 
 SD-1.5-SIZE fixtures (round 3; the REAL reference at spec.SD15_CONFIG, fp32 arithmetic on the bf16-rounded seeded weights — the
@@ -235,6 +236,29 @@ def vae_fixture(out_dir):
     print("tiny_vae_decode:", tuple(img.shape), "|x|", img.abs().mean().item())
 
 
+def vae_encode_fixture(out_dir):
+    """diffusers AutoencoderKL.encode (dif:models/autoencoder_kl.py:127-171: quant_conv(encoder(x)) -> DiagonalGaussianDistribution) of the tiny
+    VAE config with seeded weights (decoder seed 5 as in tiny_vae_decode.pt, encoder + quant_conv seed 1005 = what
+    magicdrive_amd AutoencoderKL.from_config(VAE_TINY_CONFIG, 5, with_encoder=True) builds) on two 56x104 images in [-1, 1]: the call
+    demo/run_cond_on_view.py:79-86 makes on its known views."""
+    from oracle import refshim
+    ns = refshim.load()
+    vcfg = spec.VAE_TINY_CONFIG
+    sd = spec.random_state_dict(spec.vae_decoder_param_shapes(vcfg), 5)
+    sd.update(spec.random_state_dict(spec.vae_encoder_param_shapes(vcfg), 1005))
+    vae = ns.diffusers.AutoencoderKL(in_channels=3, out_channels=vcfg["out_channels"], block_out_channels=vcfg["block_out_channels"],
+                                     down_block_types=("DownEncoderBlock2D",) * 4, up_block_types=("UpDecoderBlock2D",) * 4,
+                                     latent_channels=vcfg["latent_channels"], norm_num_groups=vcfg["norm_num_groups"],
+                                     layers_per_block=vcfg["layers_per_block"]).eval()
+    missing, unexpected = vae.load_state_dict(sd, strict=True)
+    x = torch.rand(2, 3, 56, 104, generator=torch.Generator().manual_seed(9)) * 2 - 1
+    with torch.no_grad():
+        dist = vae.encode(x).latent_dist
+    torch.save({"x_seed": 9, "weights_seed": 5, "checksum": checksum(sd), "mean": dist.mean.clone(), "logvar": dist.logvar.clone(),
+                "sample_seed0": dist.sample(torch.Generator().manual_seed(0)).clone()}, os.path.join(out_dir, "tiny_vae_encode.pt"))
+    print("tiny_vae_encode: mean", tuple(dist.mean.shape), "|mean|", dist.mean.abs().mean().item(), "|logvar|", dist.logvar.abs().mean().item())
+
+
 def hires_fixture(out_dir, cfg0, usd, csd, meta, hw=(54, 96)):
     cfg = spec.with_plus_map_embedder(cfg0, hw)
     ns, unet, cnet = ref_models.build_reference(cfg, usd, csd, img_size=(hw[0] * 8, hw[1] * 8))
@@ -387,6 +411,8 @@ def main():
         return cxyz_fixture(out_dir, cfg, usd, meta)
     if sys.argv[1:] == ["vae"]:
         return vae_fixture(out_dir)
+    if sys.argv[1:] == ["vaeenc"]:
+        return vae_encode_fixture(out_dir)
     if sys.argv[1:] == ["nattn"]:
         return nattn_fixture(out_dir, cfg, usd, csd, meta)
     if sys.argv[1:] in (["res272"], ["res424"]):
