@@ -95,10 +95,12 @@ def test_plus_map_embedder_config_roundtrip(tmp_path):
 
 def test_vae_checkpoint_roundtrip_and_legacy_keys(tmp_path):
     from magicdrive_amd.networks.autoencoder_kl import AutoencoderKL
-    v = AutoencoderKL.from_config(spec.VAE_TINY_CONFIG, 5)
+    v = AutoencoderKL.from_config(spec.VAE_TINY_CONFIG, 5, with_encoder=True)     # the real checkpoint holds encoder + quant_conv too
     v.save_pretrained(str(tmp_path / "vae"))
     v2 = AutoencoderKL.from_pretrained(str(tmp_path), subfolder="vae")
     assert all(torch.equal(v.state_dict()[k], v2.state_dict()[k]) for k in v.state_dict()) and v2.config.scaling_factor == 0.18215
+    assert v2.has_encoder and "quant_conv.weight" in v2.state_dict() and "encoder.mid_block.attentions.0.to_q.weight" in v2.state_dict()
+    assert not AutoencoderKL.from_config(spec.VAE_TINY_CONFIG, 5).has_encoder    # decoder-only state dicts still load (encode() then raises)
     # pre-0.17 diffusers checkpoints: attention projections named query/key/value/proj_attn, stored as 1x1 convs or linears
     from safetensors.torch import save_file
     legacy = {}
@@ -106,14 +108,21 @@ def test_vae_checkpoint_roundtrip_and_legacy_keys(tmp_path):
         for new, old in (("to_q", "query"), ("to_k", "key"), ("to_v", "value"), ("to_out.0", "proj_attn")):
             k = k.replace(f".attentions.0.{new}.", f".attentions.0.{old}.")
         legacy[k] = t.contiguous()
-    legacy["encoder.conv_in.weight"] = torch.zeros(4, 3, 3, 3)           # encoder tensors are ignored
     os.makedirs(tmp_path / "old"); save_file(legacy, str(tmp_path / "old" / "diffusion_pytorch_model.safetensors"))
     import json, shutil
     shutil.copy(tmp_path / "vae" / "config.json", tmp_path / "old" / "config.json")
     v3 = AutoencoderKL.from_pretrained(str(tmp_path / "old"))
-    assert all(torch.equal(v.state_dict()[k], v3.state_dict()[k]) for k in v.state_dict())
+    assert v3.has_encoder and all(torch.equal(v.state_dict()[k], v3.state_dict()[k]) for k in v.state_dict())
+    # a checkpoint with only SOME encoder tensors is a broken checkpoint, not a decoder-only one
+    part = {k: t.contiguous() for k, t in v.state_dict().items() if not k.startswith("encoder.down_blocks")}
+    with pytest.raises(KeyError, match="encoder"):
+        AutoencoderKL(spec.VAE_TINY_CONFIG, part)
     with pytest.raises(RuntimeError):
         v.decode(torch.zeros(1, 4, 7, 13))          # no CPU path
+    with pytest.raises(RuntimeError):
+        v.encode(torch.zeros(1, 3, 56, 104))
+    with pytest.raises(ValueError, match="decoder-only"):
+        AutoencoderKL.from_config(spec.VAE_TINY_CONFIG, 5).encode(torch.zeros(1, 3, 56, 104))
 
 
 def test_state_dict_validation():
