@@ -40,10 +40,10 @@ def build_reference(cfg, unet_sd, cn_sd, img_size=(224, 400)):
     return ns, unet.eval(), cnet.eval()
 
 
-def build_reference_pipeline(cfg, unet_sd, cn_sd, scheduler="ddim", given_view=False):
+def build_reference_pipeline(cfg, unet_sd, cn_sd, scheduler="ddim", given_view=False, img_size=None):
     """The reference StableDiffusionBEVControlNetPipeline with a 1-layer random CLIP (only .dtype is read when
     prompt_embeds are given, pipeline_controlnet.py:371) and a generator-free DDIM subclass."""
-    ns, unet, cnet = build_reference(cfg, unet_sd, cn_sd)
+    ns, unet, cnet = build_reference(cfg, unet_sd, cn_sd, **({} if img_size is None else {"img_size": img_size}))
     import transformers
 
     class DDIMNoGen(ns.DDIMScheduler):

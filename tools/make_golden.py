@@ -49,6 +49,7 @@ weights the HIP model holds — so that the fixture measures arithmetic, not wei
   tiny_forward_nattn.pt  the reference UNet forward with neighboring_attn_type = concat and = self (same tiny weights and inputs).
 """
 import copy
+import time
 import os
 import sys
 
@@ -359,6 +360,35 @@ def sd15_hires_fixture(out_dir, hw=(54, 96)):
     print("sd15_forward_hires: eps std", e.std().item(), "mid |x|", m.abs().mean().item())
 
 
+def sd15_hires_loop_fixture(out_dir, hw=(54, 96), steps=6):
+    """BASELINE configs[3] as a LOOP at real width: the REAL reference pipeline's __call__ (pipeline_bev_controlnet.py:349-451) at 432x768
+    (54x96 latents, ...Plus map encoder), camera + 3 boxes + BEV map, CFG 2.0, `steps` DDIM steps -> sd15_loop_hires.pt.  (The 224x400
+    loops pin the sampler / CFG machinery; this one pins it at the geometry whose level-0 sequences are 5184 tokens.)"""
+    from helpers import bf16_round
+    torch.set_num_threads(8)
+    cfg = spec.with_plus_map_embedder(spec.SD15_CONFIG, hw)
+    usd, csd = state_dicts(cfg)
+    usd, csd = bf16_round(usd), bf16_round(csd)
+    meta = {"unet_checksum": checksum(usd), "cn_checksum": checksum(csd), "torch": str(torch.__version__),
+            "weights": "spec.random_state_dict seeds (0, 1), bf16-rounded; reference arithmetic fp32"}
+    ns, pipe = ref_models.build_reference_pipeline(cfg, usd, csd, img_size=(hw[0] * 8, hw[1] * 8))
+    sc = scene(cfg, 1, 3, hw)
+    trace = {}
+    t0 = time.time()
+    with torch.no_grad():
+        out = pipe(prompt=None, image=sc["bev_map"], camera_param=sc["camera_param"], height=hw[0] * 8, width=hw[1] * 8, num_inference_steps=steps,
+                   guidance_scale=2.0, latents=sc["latents"].clone(), prompt_embeds=sc["prompt_embeds"],
+                   negative_prompt_embeds=sc["negative_prompt_embeds"], output_type="latent", callback=_trace_cb(trace, 2), callback_steps=1,
+                   bev_controlnet_kwargs={"bboxes_3d_data": sc["bboxes_3d_data"]}).images
+    dt = time.time() - t0
+    meta["reference_seconds"] = dt; meta["reference_threads"] = torch.get_num_threads()
+    name = "sd15_loop_hires.pt"
+    torch.save({"meta": meta, "steps": steps, "guidance": 2.0, "hw": hw, "latents": out.half().clone(), "trace": trace,
+                "absmean": out.abs().mean().item()}, os.path.join(out_dir, name))
+    print(name, "|x|", out.abs().mean().item(), f"reference: {dt:.1f} s for {steps} steps = {dt / steps:.2f} s/step on {torch.get_num_threads()} threads",
+          os.path.getsize(os.path.join(out_dir, name)) // 1024, "KiB")
+
+
 def resolution_fixture(out_dir, cfg0, usd, meta, which):
     """The reference's two other shipped resolutions at tiny width (module forwards of the REAL reference)."""
     if which == "272x736":
@@ -392,6 +422,8 @@ def main():
         return sd15_loop_fixture(out_dir, True)
     if sys.argv[1:] == ["sd15hires"]:
         return sd15_hires_fixture(out_dir)
+    if sys.argv[1:] == ["sd15hiresloop"]:
+        return sd15_hires_loop_fixture(out_dir)
     if sys.argv[1:] == ["sd15given"]:
         return sd15_given_view_fixture(out_dir)
     if sys.argv[1:] == ["cpuref"]:

@@ -1,0 +1,583 @@
+// gemm_dw.hip — experiment for the XL main loop after round 4: ONE operand bypasses the LDS.
+//
+// Where gemm4w.hip left off (profiles/r03_ubench_gemm4w.log): the plain 8-wave 256 x 256 loop loses 11 % to its fragment reads, 4 % to
+// the barrier and another 16 % once the LDS-DMA of the operands runs inside the loop.  Per 64-deep unit the LDS array serves 192 KB of
+// ds_read_b128 (256 B/clk) and takes 64 KB of DMA writes (the slow direction) against 2048 cycles of MFMA: the operand stream and the
+// fragment reads share one port that is busy most of the time.
+//
+// Here the W operand (the weights: packed once on the host, any layout is free) goes global -> VGPR directly:
+//   * host layout Wp[n / 32][k / 16][lane][8]: the 64 lanes' 16-byte fragments of one 32 x 16 MFMA operand block are ONE contiguous KiB,
+//     so a wave's fragment load is a fully coalesced buffer_load_dwordx4 (no swizzle, no LDS write, no ds_read);
+//   * a wave (128 x 64 of the tile) holds the 2 x 4 W fragments of the current unit in 32 VGPRs and refills the pair of a k-step for
+//     the NEXT unit right behind the MFMAs that consumed it (one unit = 2048 MFMA cycles of lead, what the A ring has too);
+//   * the LDS only carries A: 32 KB per unit, so the ring can be 3-4 units deep in 96-128 KB; LDS traffic per unit drops from
+//     64 KB written + 192 KB read to 32 KB + 128 KB.
+// Cost: the two waves that share a column block (wm = 0 / 1) fetch the same W fragments: 64 KB of W per unit per CU through the vector
+// L1 instead of 32 KB through the DMA — whether the 32-KB L1 turns that into hits or the L2 port takes it is what this measures.
+//
+// VMEM bookkeeping (everything returns in order): per k-step a wave issues {W, W, A-piece}; the W pair of (unit t, k-step s) was issued
+// at k-step s of unit t - 1 and has 1 + 3 * 3 = 10 younger instructions behind it: `s_waitcnt vmcnt(10)` in front of every k-step's
+// MFMAs.  The A pieces of unit t were issued during unit t - (NSTG - 1) <= t - 2, i.e. they are older than that: one wait serves both.
+//
+// Build:  hipcc --offload-arch=gfx950 -O3 -o gemm_dw gemm_dw.hip
+// Run:    ./gemm_dw           TFLOP/s per shape: this loop (3 and 4 A stages) and its ablations, next to gemm4w's 8-wave loop
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+union Frag8 { uint4 u; bf16x8_t v; u32x4_t r; };
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
+    const unsigned long long a = (unsigned long long)p;
+    rsrc_t r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    r.z = 0xfffffff0u;
+    r.w = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void glds(const rsrc_t rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds"
+        :
+        : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
+        : "memory", "m0");
+}
+// global -> VGPR, asynchronous: the consumer waits with vmcnt (the compiler does not know; every user below is a volatile asm in source order)
+__device__ __forceinline__ void gload(u32x4_t& dst, const rsrc_t rs, unsigned voff, unsigned soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+#define MFMA_32x32x16(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    bf2 v = {(__bf16)lo, (__bf16)hi};
+    return *reinterpret_cast<unsigned*>(&v);
+}
+
+// 8 waves, 2 (M) x 4 (N), 128 x 64 each.  ABL: 1 = no A DMA in the loop, 2 = no barrier, 4 = no A fragment reads, 8 = no W loads in the loop
+// (results wrong, timing only).  WDUP = false: waves with wm = 1 do not load W (they compute on stale registers): what the loop would
+// do if the W fetch were not duplicated (timing only).
+template <int NSTG, bool STORE, int ABL, bool WDUP = true>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_dw_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wp, bf16_t* __restrict__ C, int M, int N, int K, int nt) {
+    constexpr int BK = 64, ROWB = 128, CPR = 8, RPP = 8;
+    constexpr int UNIT = 256 * ROWB;             // 32 KB: the A rows of a unit
+    constexpr int PPW = 4;                       // A pieces per wave per unit = one per k-step
+    constexpr int KS = 4, NN = 2;
+    static_assert(NSTG >= 3, "the A pieces of a unit must be older than one unit of VMEM issues");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int frow = lane & 31, half = lane >> 5;
+    const int nblk = gridDim.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
+    const int bid = xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3);
+    const int tm = bid / nt, tn = bid - tm * nt;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const rsrc_t rsA = make_rsrc(A);
+    rsrc_t rsW = make_rsrc(Wp);
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+    auto swz = [](int row) { return (row >> 1) & 7; };
+
+    unsigned src_off[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int piece = wave * PPW + j;                         // 32 pieces of 8 rows
+        const int row = piece * RPP + lane / CPR;
+        const int c = (lane % CPR) ^ swz(row);
+        src_off[j] = (unsigned)((long)(m0 + row) * (long)K * 2 + c * 16);
+    }
+    const int T = K / BK;
+    auto issue_piece = [&](int t, int j) {
+        rsrc_t r = rsA;
+        r.z = t < T ? 0xfffffff0u : 0u;
+        glds(r, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(t % NSTG) * UNIT + (wave * PPW + j) * 1024), src_off[j], (unsigned)t * ROWB);
+    };
+    // W fragment (column block n of this wave, k-step s of unit t): KiB number ((n0 / 32 + wn * 2 + n) * (K / 16) + t * 4 + s)
+    const unsigned w_voff = (unsigned)lane * 16u;
+    const unsigned w_kib0 = (unsigned)((n0 >> 5) + wn * NN) * (unsigned)(K >> 4);
+    const unsigned w_kibn = (unsigned)(K >> 4);
+    Frag8 wf[KS][NN];
+    auto issue_w = [&](int t, int s) {
+        if (!WDUP && wm) return;
+#pragma unroll
+        for (int n = 0; n < NN; ++n) {
+            rsrc_t r = rsW;
+            r.z = t < T ? 0xfffffff0u : 0u;
+            gload(wf[s][n].r, r, w_voff, __builtin_amdgcn_readfirstlane((w_kib0 + n * w_kibn + (unsigned)(t * KS + s)) << 10));
+        }
+    };
+
+    f32x16_t acc[4][NN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int n = 0; n < NN; ++n) wf[s][n].u = make_uint4(0, 0, 0, 0);
+
+    // prologue = "unit -1" in the loop's issue pattern: the older A units first, then {W, W, A} per k-step
+#pragma unroll
+    for (int t = 0; t < NSTG - 2; ++t)
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) issue_piece(t, j);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        issue_w(0, s);
+        issue_piece(NSTG - 2, s);
+    }
+    if (ABL & 9) { wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); }
+
+    const int x0 = half ^ swz(frow);
+    const unsigned a_rd = (unsigned)((wm * 128 + frow) * ROWB);
+    Frag8 af[2][4];
+    if (ABL & 4) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[b][i].u = *(const uint4*)(smem + a_rd + i * 32 * ROWB + (x0 << 4));
+    }
+
+    for (int t = 0; t < T; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* ub = smem + (t % NSTG) * UNIT;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            // W pair of (t, ks) landed; everything older too (incl. this wave's A pieces of unit t)
+            if ((ABL & 9) != 9) {
+                if ((ABL & 9) == 0) wait_vmcnt<10>();
+                else if (ABL & 8) wait_vmcnt<3>();                         // A pieces only: 1 per k-step, the unit's own are > 4 back
+                else wait_vmcnt<6>();                                      // W pairs only: 2 per k-step, 3 k-steps younger
+            }
+            if (ks == 0) {
+                if (!(ABL & 2)) __builtin_amdgcn_s_barrier();              // everyone's A pieces of unit t; everyone done reading unit t - 1
+                asm volatile("" ::: "memory");
+                if (!(ABL & 4)) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[0][i].u = *(const uint4*)(ub + a_rd + i * 32 * ROWB + (x0 << 4));
+                }
+            }
+            if (ks + 1 < KS && !(ABL & 4)) {
+                const int co = (x0 ^ ((ks + 1) << 1)) << 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[(ks + 1) & 1][i].u = *(const uint4*)(ub + a_rd + i * 32 * ROWB + co);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int n = 0; n < NN; ++n) MFMA_32x32x16(acc[i][n], wf[ks][n].v, af[ks & 1][i].v);
+            if (!(ABL & 8)) issue_w(t + 1, ks);                            // refill the pair just consumed, for the next unit
+            if (!(ABL & 1)) issue_piece(t + NSTG - 1, ks);
+        }
+    }
+    wait_vmcnt<0>();
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (STORE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long m = m0 + wm * 128 + i * 32 + frow;
+#pragma unroll
+            for (int n = 0; n < NN; ++n) {
+                bf16_t* crow = C + m * (long)N + n0 + wn * 32 * NN + n * 32 + 4 * half;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 o;
+                    o.x = pack2bf(acc[i][n][4 * g], acc[i][n][4 * g + 1]);
+                    o.y = pack2bf(acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]);
+                    *(uint2*)(crow + 8 * g) = o;
+                }
+            }
+        }
+    } else {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int n = 0; n < NN; ++n) s += acc[i][n][0] + acc[i][n][15];
+        if (s == 12345.678f) C[threadIdx.x] = 1;
+    }
+}
+
+// ---- variant 2: the waves form a 1 x NW row (each owns ALL 256 rows of the tile and 256 / NW columns), so no two waves need the same W
+// fragment: W goes through the vector L1 exactly once (32 KB per unit per CU, as through the DMA before).  Price: every wave reads the
+// whole A tile from the LDS (NW x 32 KB per unit: 256 KB with 8 waves — two waves per SIMD —, 128 KB with 4 — one per SIMD, 256 accumulators).
+template <int NW, int NSTG, bool STORE, int ABL>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
+void gemm_dw1_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wp, bf16_t* __restrict__ C, int M, int N, int K, int nt) {
+    constexpr int BK = 64, ROWB = 128, CPR = 8, RPP = 8;
+    constexpr int UNIT = 256 * ROWB;
+    constexpr int PPW = 32 / NW;                 // A pieces per wave per unit (4 / 8)
+    constexpr int PPK = PPW / 4;                 // ... per k-step (1 / 2)
+    constexpr int KS = 4, NN = 8 / NW, MI = 8;
+    constexpr int YOUNGER = PPK + 3 * (NN + PPK);   // VMEM instructions issued behind the W fragments of a k-step before they are needed
+    static_assert(NSTG >= 3, "the A pieces of a unit must be older than one unit of VMEM issues");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int frow = lane & 31, half = lane >> 5;
+    const int nblk = gridDim.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
+    const int bid = xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3);
+    const int tm = bid / nt, tn = bid - tm * nt;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const rsrc_t rsA = make_rsrc(A);
+    const rsrc_t rsW = make_rsrc(Wp);
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+    auto swz = [](int row) { return (row >> 1) & 7; };
+
+    unsigned src_off[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int piece = wave * PPW + j;
+        const int row = piece * RPP + lane / CPR;
+        const int c = (lane % CPR) ^ swz(row);
+        src_off[j] = (unsigned)((long)(m0 + row) * (long)K * 2 + c * 16);
+    }
+    const int T = K / BK;
+    auto issue_piece = [&](int t, int j) {
+        rsrc_t r = rsA;
+        r.z = t < T ? 0xfffffff0u : 0u;
+        glds(r, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(t % NSTG) * UNIT + (wave * PPW + j) * 1024), src_off[j], (unsigned)t * ROWB);
+    };
+    const unsigned w_voff = (unsigned)lane * 16u;
+    const unsigned w_kib0 = (unsigned)((n0 >> 5) + wave * NN) * (unsigned)(K >> 4);
+    const unsigned w_kibn = (unsigned)(K >> 4);
+    Frag8 wf[KS][NN];
+    auto issue_w = [&](int t, int s) {
+#pragma unroll
+        for (int n = 0; n < NN; ++n) {
+            rsrc_t r = rsW;
+            r.z = t < T ? 0xfffffff0u : 0u;
+            gload(wf[s][n].r, r, w_voff, __builtin_amdgcn_readfirstlane((w_kib0 + n * w_kibn + (unsigned)(t * KS + s)) << 10));
+        }
+    };
+
+    f32x16_t acc[MI][NN];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int n = 0; n < NN; ++n) wf[s][n].u = make_uint4(0, 0, 0, 0);
+
+#pragma unroll
+    for (int t = 0; t < NSTG - 2; ++t)
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) issue_piece(t, j);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        issue_w(0, s);
+#pragma unroll
+        for (int j = 0; j < PPK; ++j) issue_piece(NSTG - 2, s * PPK + j);
+    }
+    if (ABL & 9) { wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); }
+
+    const int x0 = half ^ swz(frow);
+    const unsigned a_rd = (unsigned)(frow * ROWB);
+    Frag8 af[2][MI];
+    if (ABL & 4) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[b][i].u = *(const uint4*)(smem + a_rd + i * 32 * ROWB + (x0 << 4));
+    }
+
+    for (int t = 0; t < T; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* ub = smem + (t % NSTG) * UNIT;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if ((ABL & 9) == 0) wait_vmcnt<YOUNGER>();
+            else if ((ABL & 9) == 8) wait_vmcnt<3 * PPK>();
+            else if ((ABL & 9) == 1) wait_vmcnt<3 * NN>();
+            if (ks == 0) {
+                if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (!(ABL & 4)) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) af[0][i].u = *(const uint4*)(ub + a_rd + i * 32 * ROWB + (x0 << 4));
+                }
+            }
+            if (ks + 1 < KS && !(ABL & 4)) {
+                const int co = (x0 ^ ((ks + 1) << 1)) << 4;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[(ks + 1) & 1][i].u = *(const uint4*)(ub + a_rd + i * 32 * ROWB + co);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int n = 0; n < NN; ++n) MFMA_32x32x16(acc[i][n], wf[ks][n].v, af[ks & 1][i].v);
+            if (!(ABL & 8)) issue_w(t + 1, ks);
+            if (!(ABL & 1)) {
+#pragma unroll
+                for (int j = 0; j < PPK; ++j) issue_piece(t + NSTG - 1, ks * PPK + j);
+            }
+        }
+    }
+    wait_vmcnt<0>();
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (STORE) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const long m = m0 + i * 32 + frow;
+#pragma unroll
+            for (int n = 0; n < NN; ++n) {
+                bf16_t* crow = C + m * (long)N + n0 + wave * 32 * NN + n * 32 + 4 * half;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 o;
+                    o.x = pack2bf(acc[i][n][4 * g], acc[i][n][4 * g + 1]);
+                    o.y = pack2bf(acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]);
+                    *(uint2*)(crow + 8 * g) = o;
+                }
+            }
+        }
+    } else {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int n = 0; n < NN; ++n) s += acc[i][n][0] + acc[i][n][15];
+        if (s == 12345.678f) C[threadIdx.x] = 1;
+    }
+}
+
+// ---- gemm4w.hip's plain 8-wave loop (both operands through the LDS ring), for the same-binary comparison ----
+template <bool STORE, int ABL>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_lds_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* __restrict__ C, int M, int N, int K, int nt) {
+    constexpr int NW = 8, BK = 64, NSTG = 2;
+    constexpr int ROWB = BK * 2, CPR = BK / 8, RPP = 1024 / ROWB, REG = 256 * ROWB, UNIT = 2 * REG, PPW = UNIT / 1024 / NW, KS = BK / 16;
+    constexpr int WNC = NW / 2, NN = 2, SLOTS = KS * 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WNC, wn = wave % WNC;
+    const int frow = lane & 31, half = lane >> 5;
+    const int nblk = gridDim.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
+    const int bid = xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3);
+    const int tm = bid / nt, tn = bid - tm * nt;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const bool loadsA = wave < NW / 2;
+    rsrc_t rs = make_rsrc(loadsA ? (const void*)A : (const void*)W);
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+    auto swz = [](int row) { return (row >> 1) & 7; };
+    unsigned src_off[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int piece = (wave % (NW / 2)) * PPW + j;
+        const int row = piece * RPP + lane / CPR;
+        const int c = (lane % CPR) ^ swz(row);
+        const long grow = (loadsA ? m0 : n0) + row;
+        src_off[j] = (unsigned)(grow * (long)K * 2 + c * 16);
+    }
+    const unsigned dst_reg = (loadsA ? 0 : REG) + (wave % (NW / 2)) * PPW * 1024;
+    const int T = K / BK;
+    auto issue_piece = [&](int t, int j) {
+        rsrc_t r = rs;
+        r.z = t < T ? 0xfffffff0u : 0u;
+        glds(r, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(t % NSTG) * UNIT + dst_reg + j * 1024), src_off[j], (unsigned)t * ROWB);
+    };
+    f32x16_t acc[4][NN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NSTG - 1 + (ABL & 1); ++t)
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) issue_piece(t, j);
+    if (ABL & 1) { wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); }
+    const int x0 = half ^ swz(frow);
+    const unsigned a_rd = (unsigned)((wm * 128 + frow) * ROWB);
+    const unsigned w_rd = (unsigned)(REG + (wn * 32 * NN + frow) * ROWB);
+    Frag8 af[2][4], wf[2][NN];
+    for (int t = 0; t < T; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 1)) wait_vmcnt<(NSTG - 2) * PPW>();
+        if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* ub = smem + (t % NSTG) * UNIT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[0][i].u = *(const uint4*)(ub + a_rd + i * 32 * ROWB + (x0 << 4));
+#pragma unroll
+        for (int n = 0; n < NN; ++n) wf[0][n].u = *(const uint4*)(ub + w_rd + n * 32 * ROWB + (x0 << 4));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+                const int co = (x0 ^ ((ks + 1) << 1)) << 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[(ks + 1) & 1][i].u = *(const uint4*)(ub + a_rd + i * 32 * ROWB + co);
+#pragma unroll
+                for (int n = 0; n < NN; ++n) wf[(ks + 1) & 1][n].u = *(const uint4*)(ub + w_rd + n * 32 * ROWB + co);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int n = 0; n < NN; ++n) MFMA_32x32x16(acc[i][n], wf[ks & 1][n].v, af[ks & 1][i].v);
+                const int slot = ks * 4 + i;
+                if (!(ABL & 1) && slot % (SLOTS / PPW) == 0) issue_piece(t + NSTG - 1, slot / (SLOTS / PPW));
+            }
+        }
+    }
+    wait_vmcnt<0>();
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (STORE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long m = m0 + wm * 128 + i * 32 + frow;
+#pragma unroll
+            for (int n = 0; n < NN; ++n) {
+                bf16_t* crow = C + m * (long)N + n0 + wn * 32 * NN + n * 32 + 4 * half;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 o;
+                    o.x = pack2bf(acc[i][n][4 * g], acc[i][n][4 * g + 1]);
+                    o.y = pack2bf(acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]);
+                    *(uint2*)(crow + 8 * g) = o;
+                }
+            }
+        }
+    } else {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int n = 0; n < NN; ++n) s += acc[i][n][0] + acc[i][n][15];
+        if (s == 12345.678f) C[threadIdx.x] = 1;
+    }
+}
+
+static float bf2f(bf16_t v) { unsigned u = (unsigned)v << 16; float f; memcpy(&f, &u, 4); return f; }
+static bf16_t f2bf(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (bf16_t)(u >> 16); }
+
+template <typename Kern>
+static double time_kernel(Kern kern, size_t smem, const bf16_t* dA, const bf16_t* dW, bf16_t* dC, int M, int N, int K, int reps, int nthr = 512) {
+    const int mt = M / 256, nt = N / 256, nblk = mt * nt;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(nthr), smem, 0, dA, dW, dC, M, N, K, nt);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(nblk), dim3(nthr), smem, 0, dA, dW, dC, M, N, K, nt);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { printf("launch error: %s\n", hipGetErrorString(e)); return 0; }
+    return 2.0 * M * N * (double)K / (ms / reps * 1e-3) / 1e12;
+}
+template <int NSTG, bool STORE, int ABL = 0, bool WDUP = true>
+static double run_dw(const bf16_t* dA, const bf16_t* dWp, bf16_t* dC, int M, int N, int K, int reps) {
+    return time_kernel(gemm_dw_kernel<NSTG, STORE, ABL, WDUP>, (size_t)NSTG * 256 * 128, dA, dWp, dC, M, N, K, reps);
+}
+template <int NW, int NSTG, bool STORE, int ABL = 0>
+static double run_dw1(const bf16_t* dA, const bf16_t* dWp, bf16_t* dC, int M, int N, int K, int reps) {
+    return time_kernel(gemm_dw1_kernel<NW, NSTG, STORE, ABL>, (size_t)NSTG * 256 * 128, dA, dWp, dC, M, N, K, reps, NW * 64);
+}
+template <bool STORE, int ABL = 0>
+static double run_lds(const bf16_t* dA, const bf16_t* dW, bf16_t* dC, int M, int N, int K, int reps) {
+    return time_kernel(gemm_lds_kernel<STORE, ABL>, (size_t)2 * 2 * 256 * 128, dA, dW, dC, M, N, K, reps);
+}
+
+int main() {
+    struct Shape { int M, N, K; const char* what; };
+    const Shape shapes[] = {
+        {268800, 1280, 640, "qk L1 (768 views)"}, {69888, 2560, 1280, "qk L2"}, {69888, 1280, 5120, "ff.out L2"}, {8192, 8192, 8192, "square 8k"},
+    };
+    size_t maxA = 0, maxW = 0, maxC = 0;
+    for (auto& s : shapes) {
+        maxA = std::max(maxA, (size_t)s.M * s.K); maxW = std::max(maxW, (size_t)s.N * s.K); maxC = std::max(maxC, (size_t)s.M * s.N);
+        if ((size_t)s.M * s.K * 2 >= 0xfffffff0ull || (size_t)s.N * s.K * 2 >= 0xfffffff0ull || (s.M % 256) || (s.N % 256) || (s.K % 64)) { printf("bad shape %s\n", s.what); return 1; }
+    }
+    std::vector<bf16_t> hA(maxA), hW(maxW), hWp(maxW);
+    unsigned seed = 12345u;
+    auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return ((seed >> 9) & 0xffff) / 65536.0f - 0.5f; };
+    for (auto& v : hA) v = f2bf(rnd());
+    for (auto& v : hW) v = f2bf(rnd() * 0.25f);
+    bf16_t *dA, *dW, *dWp, *dC;
+    (void)hipMalloc(&dA, maxA * 2); (void)hipMalloc(&dW, maxW * 2); (void)hipMalloc(&dWp, maxW * 2); (void)hipMalloc(&dC, maxC * 2);
+    (void)hipMemcpy(dA, hA.data(), maxA * 2, hipMemcpyHostToDevice);
+    for (auto& s : shapes) {
+        const int reps = 4;
+        // the shape's W is the leading N x K elements of hW (row-major [n][k]); fragment-order copy: Wp[n / 32][k / 16][lane = (k % 16) / 8 * 32 + n % 32][k % 8]
+        for (long n = 0; n < s.N; ++n)
+            for (long k = 0; k < s.K; ++k)
+                hWp[(((n >> 5) * (s.K >> 4) + (k >> 4)) * 64 + ((k & 15) >> 3) * 32 + (n & 31)) * 8 + (k & 7)] = hW[n * s.K + k];
+        (void)hipMemcpy(dW, hW.data(), (size_t)s.N * s.K * 2, hipMemcpyHostToDevice);
+        (void)hipMemcpy(dWp, hWp.data(), (size_t)s.N * s.K * 2, hipMemcpyHostToDevice);
+        for (int variant = 0; variant < 5; ++variant) {
+            (void)hipMemset(dC, 0xff, (size_t)s.M * s.N * 2);
+            if (variant == 0) run_dw<3, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
+            else if (variant == 1) run_dw<4, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
+            else if (variant == 3) run_dw1<8, 4, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
+            else if (variant == 4) run_dw1<4, 4, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
+            else run_lds<true>(dA, dW, dC, s.M, s.N, s.K, 1);
+            double worst = 0;
+            for (int q = 0; q < 64; ++q) {
+                const long m = ((long)q * 7919 + (q % 3 == 0 ? s.M - 1 - q : 0)) % s.M, n = ((long)q * 104729 + (q % 5 == 0 ? s.N - 1 : 0)) % s.N;
+                bf16_t got; (void)hipMemcpy(&got, dC + m * (long)s.N + n, 2, hipMemcpyDeviceToHost);
+                double ref = 0;
+                for (int k = 0; k < s.K; ++k) ref += (double)bf2f(hA[m * (long)s.K + k]) * bf2f(hW[n * (long)s.K + k]);
+                const double err = fabs(bf2f(got) - ref) / (fabs(ref) + 0.05 * sqrt((double)s.K) * 0.07);
+                worst = std::max(worst, err);
+            }
+            printf("%-20s %s: worst sampled relative error %.4f %s\n", s.what, variant == 0 ? "W direct, 3 A stages" : variant == 1 ? "W direct, 4 A stages" : variant == 3 ? "W direct, 1 x 8 waves" : variant == 4 ? "W direct, 1 x 4 waves" : "both via LDS (gemm4w)",
+                   worst, worst < 2e-2 ? "ok" : "MISMATCH");
+        }
+        printf("%-20s M=%6d N=%5d K=%5d  TFLOP/s\n", s.what, s.M, s.N, s.K);
+        printf("    both via LDS, 2 stages : full %7.1f | no stores %7.1f | + no DMA %7.1f | + no barrier %7.1f\n",
+               run_lds<true, 0>(dA, dW, dC, s.M, s.N, s.K, reps), run_lds<false, 0>(dA, dW, dC, s.M, s.N, s.K, reps),
+               run_lds<false, 1>(dA, dW, dC, s.M, s.N, s.K, reps), run_lds<false, 3>(dA, dW, dC, s.M, s.N, s.K, reps));
+#define ROW(NS_)                                                                                                                              \
+        printf("    W direct, %d A stages   : full %7.1f | no stores %7.1f | W not duplicated %7.1f | no W loads %7.1f | no A DMA %7.1f | neither %7.1f | + no barrier %7.1f | + no A reads %7.1f\n", NS_, \
+               run_dw<NS_, true, 0>(dA, dWp, dC, s.M, s.N, s.K, reps), run_dw<NS_, false, 0>(dA, dWp, dC, s.M, s.N, s.K, reps),                \
+               run_dw<NS_, false, 0, false>(dA, dWp, dC, s.M, s.N, s.K, reps), run_dw<NS_, false, 8>(dA, dWp, dC, s.M, s.N, s.K, reps),       \
+               run_dw<NS_, false, 1>(dA, dWp, dC, s.M, s.N, s.K, reps), run_dw<NS_, false, 9>(dA, dWp, dC, s.M, s.N, s.K, reps),              \
+               run_dw<NS_, false, 11>(dA, dWp, dC, s.M, s.N, s.K, reps), run_dw<NS_, false, 15>(dA, dWp, dC, s.M, s.N, s.K, reps));
+        ROW(3) ROW(4)
+#undef ROW
+#define ROW1(NW_, NS_)                                                                                                                        \
+        printf("    W direct, 1 x %d waves, %d A stages : full %7.1f | no stores %7.1f | no W loads %7.1f | no A DMA %7.1f | neither %7.1f | + no barrier %7.1f | + no A reads %7.1f\n", NW_, NS_, \
+               run_dw1<NW_, NS_, true, 0>(dA, dWp, dC, s.M, s.N, s.K, reps), run_dw1<NW_, NS_, false, 0>(dA, dWp, dC, s.M, s.N, s.K, reps),    \
+               run_dw1<NW_, NS_, false, 8>(dA, dWp, dC, s.M, s.N, s.K, reps), run_dw1<NW_, NS_, false, 1>(dA, dWp, dC, s.M, s.N, s.K, reps),   \
+               run_dw1<NW_, NS_, false, 9>(dA, dWp, dC, s.M, s.N, s.K, reps), run_dw1<NW_, NS_, false, 11>(dA, dWp, dC, s.M, s.N, s.K, reps),  \
+               run_dw1<NW_, NS_, false, 15>(dA, dWp, dC, s.M, s.N, s.K, reps));
+        ROW1(8, 3) ROW1(8, 4) ROW1(4, 3) ROW1(4, 4)
+#undef ROW1
+    }
+    return 0;
+}
