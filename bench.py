@@ -435,7 +435,8 @@ def main():
             c = pmc_traffic(k, 1e3 * v["ms"] / v["launches"])   # counters of a representative launch of this kernel (committed PMC passes)
             if c:
                 row.update(mfma_util=c.get("mfma_util"), hbm_gbps=c.get("hbm_gbps"), l2_hit_rate=c.get("l2_hit_rate"),
-                           traffic_over_algorithmic=c.get("traffic_over_algorithmic"), pmc_case=c.get("case"))
+                           traffic_over_algorithmic=c.get("traffic_over_algorithmic"), pmc_case=c.get("case"),
+                           pmc_build=(pmc_summary() or {}).get("build_id"))      # == library_build_id below, or the counters were dropped
             return row
         out["roofline"]["per_kernel"] = {k: pk(k, v) for k, v in top}
         out["roofline"]["pmc_status"] = _PMC.get("status")
