@@ -27,6 +27,7 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
+#include <type_traits>
 
 typedef unsigned short bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -57,6 +58,13 @@ __device__ __forceinline__ void glds(const rsrc_t rs, unsigned lds_addr, unsigne
 // global -> VGPR, asynchronous: the consumer waits with vmcnt (the compiler does not know; every user below is a volatile asm in source order)
 __device__ __forceinline__ void gload(u32x4_t& dst, const rsrc_t rs, unsigned voff, unsigned soff) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+// timing-only narrow forms (ABL 32): the same instruction count with a quarter of the bytes
+__device__ __forceinline__ void glds1(const rsrc_t rs, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ void gload1(unsigned& dst, const rsrc_t rs, unsigned voff, unsigned soff) {
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 #define MFMA_32x32x16(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
 template <int N>
@@ -371,6 +379,187 @@ void gemm_dw1_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wp
     }
 }
 
+// ---- variant 3: variant 2 with the W fragments of the NEXT unit in a second register set, so that their loads (and the A pieces) can
+// sit anywhere among the MFMAs of a k-step instead of in one burst behind them: {MI*NN/VPK MFMAs, one VMEM} x VPK per k-step, order
+// W0 A0 [W1 A1].  The loop is unrolled by two units (register set = unit parity); K must be a multiple of 128.
+// ABL 16: every unit fetches the SAME source addresses (k offset frozen): the VMEM instruction stream without its L2 / HBM traffic.
+template <int NW, int NSTG, bool STORE, int ABL>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
+void gemm_dw2_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wp, bf16_t* __restrict__ C, int M, int N, int K, int nt) {
+    constexpr int ROWB = 128, CPR = 8, RPP = 8;
+    constexpr int UNIT = 256 * ROWB;
+    constexpr int PPW = 32 / NW, PPK = PPW / 4;
+    constexpr int KS = 4, NN = 8 / NW, MI = 8;
+    constexpr int VPK = NN + PPK;                   // VMEM instructions per k-step (2 / 4)
+    constexpr int GRP = MI * NN / VPK;              // MFMAs in front of each of them (4)
+    constexpr int YOUNGER = 1 + 3 * VPK;            // behind the last W fragment of a k-step when its MFMAs come up, one unit later
+    static_assert(NSTG >= 3 && (MI * NN) % VPK == 0, "");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int frow = lane & 31, half = lane >> 5;
+    const int nblk = gridDim.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
+    const int bid = xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3);
+    const int tm = bid / nt, tn = bid - tm * nt;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    // block 0 stamps its life in core-clock (s_memtime) and 100-MHz (s_memrealtime) ticks: the effective clock under this variant's load
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    const rsrc_t rsA = make_rsrc(A);
+    const rsrc_t rsW = make_rsrc(Wp);
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+    auto swz = [](int row) { return (row >> 1) & 7; };
+
+    unsigned src_off[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int piece = wave * PPW + j;
+        const int row = piece * RPP + lane / CPR;
+        const int c = (lane % CPR) ^ swz(row);
+        src_off[j] = (unsigned)((long)(m0 + row) * (long)K * 2 + c * 16);
+    }
+    const int T = K / 64;
+    auto issue_piece = [&](int t, int j) {
+        rsrc_t r = rsA;
+        r.z = t < T ? 0xfffffff0u : 0u;
+        if (ABL & 32) glds1(r, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(t % NSTG) * UNIT + (wave * PPW + j) * 1024), src_off[j], (ABL & 16) ? 0u : (unsigned)t * ROWB);
+        else glds(r, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(t % NSTG) * UNIT + (wave * PPW + j) * 1024), src_off[j], (ABL & 16) ? 0u : (unsigned)t * ROWB);
+    };
+    const unsigned w_voff = (unsigned)lane * 16u;
+    const unsigned w_kib0 = (unsigned)((n0 >> 5) + wave * NN) * (unsigned)(K >> 4);
+    const unsigned w_kibn = (unsigned)(K >> 4);
+    Frag8 wf[2][KS][NN];
+    auto issue_w = [&](auto B, int t, int s, int n) {
+        constexpr int b = decltype(B)::value;
+        rsrc_t r = rsW;
+        r.z = t < T ? 0xfffffff0u : 0u;
+        if (ABL & 32) gload1(*reinterpret_cast<unsigned*>(&wf[b][s][n]), r, w_voff, __builtin_amdgcn_readfirstlane((w_kib0 + n * w_kibn + (unsigned)(((ABL & 16) ? 0 : t) * KS + s)) << 10));
+        else gload(wf[b][s][n].r, r, w_voff, __builtin_amdgcn_readfirstlane((w_kib0 + n * w_kibn + (unsigned)(((ABL & 16) ? 0 : t) * KS + s)) << 10));
+    };
+    // the VMEM instruction number v (0 .. VPK-1) of k-step s while unit t runs: W fragments of unit t + 1 (into the other register set), A pieces of unit t + NSTG - 1
+    auto issue_v = [&](auto BN, int t, int s, int v) {
+        if (NN == 2) {                                                     // W0 A0 W1 A1
+            if ((v & 1) == 0) { if (!(ABL & 8)) issue_w(BN, t + 1, s, v >> 1); }
+            else if (!(ABL & 1)) issue_piece(t + NSTG - 1, s * PPK + (v >> 1));
+        } else {                                                           // W0 A0
+            if (v == 0) { if (!(ABL & 8)) issue_w(BN, t + 1, s, 0); }
+            else if (!(ABL & 1)) issue_piece(t + NSTG - 1, s);
+        }
+    };
+
+    f32x16_t acc[MI][NN];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int n = 0; n < NN; ++n) wf[b][s][n].u = make_uint4(0, 0, 0, 0);
+
+    typedef std::integral_constant<int, 0> B0;
+    typedef std::integral_constant<int, 1> B1;
+#pragma unroll
+    for (int t = 0; t < NSTG - 2; ++t)
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) issue_piece(t, j);
+    {   // "unit -1": the loop's issue pattern with t = -1 (W of unit 0 into set 0, A pieces of unit NSTG - 2)
+        const int abl_keep = ABL;
+        (void)abl_keep;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int v = 0; v < VPK; ++v) {
+                if (NN == 2) { if ((v & 1) == 0) issue_w(B0{}, 0, s, v >> 1); else issue_piece(NSTG - 2, s * PPK + (v >> 1)); }
+                else { if (v == 0) issue_w(B0{}, 0, s, 0); else issue_piece(NSTG - 2, s); }
+            }
+    }
+    if (ABL & 9) { wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); }
+
+    const int x0 = half ^ swz(frow);
+    const unsigned a_rd = (unsigned)(frow * ROWB);
+    Frag8 af[2][MI];
+    if (ABL & 4) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[b][i].u = *(const uint4*)(smem + a_rd + i * 32 * ROWB + (x0 << 4));
+    }
+
+    auto unit = [&](auto B, auto BN, int t) {
+        constexpr int b = decltype(B)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* ub = smem + (t % NSTG) * UNIT;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if ((ABL & 9) == 0) wait_vmcnt<YOUNGER>();
+            else if ((ABL & 9) == 8) wait_vmcnt<3 * PPK>();
+            else if ((ABL & 9) == 1) wait_vmcnt<3 * NN>();
+            if (ks == 0) {
+                if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (!(ABL & 4)) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) af[0][i].u = *(const uint4*)(ub + a_rd + i * 32 * ROWB + (x0 << 4));
+                }
+            }
+            if (ks + 1 < KS && !(ABL & 4)) {
+                const int co = (x0 ^ ((ks + 1) << 1)) << 4;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[(ks + 1) & 1][i].u = *(const uint4*)(ub + a_rd + i * 32 * ROWB + co);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < MI * NN; ++q) {
+                const int i = q / NN, n = q % NN;
+                MFMA_32x32x16(acc[i][n], wf[b][ks][n].v, af[ks & 1][i].v);
+                if ((q + 1) % GRP == 0) issue_v(BN, t, ks, q / GRP);
+            }
+        }
+    };
+    for (int t = 0; t < T; t += 2) {
+        unit(B0{}, B1{}, t);
+        unit(B1{}, B0{}, t + 1);
+    }
+    wait_vmcnt<0>();
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (STORE) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const long m = m0 + i * 32 + frow;
+#pragma unroll
+            for (int n = 0; n < NN; ++n) {
+                bf16_t* crow = C + m * (long)N + n0 + wave * 32 * NN + n * 32 + 4 * half;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 o;
+                    o.x = pack2bf(acc[i][n][4 * g], acc[i][n][4 * g + 1]);
+                    o.y = pack2bf(acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]);
+                    *(uint2*)(crow + 8 * g) = o;
+                }
+            }
+        }
+    } else {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int n = 0; n < NN; ++n) s += acc[i][n][0] + acc[i][n][15];
+        if (s == 12345.678f) C[threadIdx.x] = 1;
+    }
+    if (!STORE && blockIdx.x == 0 && threadIdx.x == 0) {                   // just past the M x N outputs (the host allocates 64 bytes more)
+        unsigned long long* stamp = reinterpret_cast<unsigned long long*>(C + (size_t)M * N);
+        stamp[0] = __builtin_amdgcn_s_memtime() - c0;
+        stamp[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+}
+
 // ---- gemm4w.hip's plain 8-wave loop (both operands through the LDS ring), for the same-binary comparison ----
 template <bool STORE, int ABL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -508,6 +697,16 @@ template <int NW, int NSTG, bool STORE, int ABL = 0>
 static double run_dw1(const bf16_t* dA, const bf16_t* dWp, bf16_t* dC, int M, int N, int K, int reps) {
     return time_kernel(gemm_dw1_kernel<NW, NSTG, STORE, ABL>, (size_t)NSTG * 256 * 128, dA, dWp, dC, M, N, K, reps, NW * 64);
 }
+template <int NW, int NSTG, bool STORE, int ABL = 0>
+static double run_dw2(const bf16_t* dA, const bf16_t* dWp, bf16_t* dC, int M, int N, int K, int reps) {
+    return time_kernel(gemm_dw2_kernel<NW, NSTG, STORE, ABL>, (size_t)NSTG * 256 * 128, dA, dWp, dC, M, N, K, reps, NW * 64);
+}
+// effective core clock (GHz) of block 0 of the LAST gemm_dw2 launch: s_memtime ticks per 100-MHz s_memrealtime tick
+static double last_clock_ghz(const bf16_t* dC, int M, int N) {
+    unsigned long long h[2] = {0, 0};
+    (void)hipMemcpy(h, dC + (size_t)M * N, sizeof(h), hipMemcpyDeviceToHost);
+    return h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
+}
 template <bool STORE, int ABL = 0>
 static double run_lds(const bf16_t* dA, const bf16_t* dW, bf16_t* dC, int M, int N, int K, int reps) {
     return time_kernel(gemm_lds_kernel<STORE, ABL>, (size_t)2 * 2 * 256 * 128, dA, dW, dC, M, N, K, reps);
@@ -529,7 +728,7 @@ int main() {
     for (auto& v : hA) v = f2bf(rnd());
     for (auto& v : hW) v = f2bf(rnd() * 0.25f);
     bf16_t *dA, *dW, *dWp, *dC;
-    (void)hipMalloc(&dA, maxA * 2); (void)hipMalloc(&dW, maxW * 2); (void)hipMalloc(&dWp, maxW * 2); (void)hipMalloc(&dC, maxC * 2);
+    (void)hipMalloc(&dA, maxA * 2); (void)hipMalloc(&dW, maxW * 2); (void)hipMalloc(&dWp, maxW * 2); (void)hipMalloc(&dC, maxC * 2 + 64);
     (void)hipMemcpy(dA, hA.data(), maxA * 2, hipMemcpyHostToDevice);
     for (auto& s : shapes) {
         const int reps = 4;
@@ -539,12 +738,14 @@ int main() {
                 hWp[(((n >> 5) * (s.K >> 4) + (k >> 4)) * 64 + ((k & 15) >> 3) * 32 + (n & 31)) * 8 + (k & 7)] = hW[n * s.K + k];
         (void)hipMemcpy(dW, hW.data(), (size_t)s.N * s.K * 2, hipMemcpyHostToDevice);
         (void)hipMemcpy(dWp, hWp.data(), (size_t)s.N * s.K * 2, hipMemcpyHostToDevice);
-        for (int variant = 0; variant < 5; ++variant) {
+        for (int variant = 0; variant < 7; ++variant) {
             (void)hipMemset(dC, 0xff, (size_t)s.M * s.N * 2);
             if (variant == 0) run_dw<3, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
             else if (variant == 1) run_dw<4, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
             else if (variant == 3) run_dw1<8, 4, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
             else if (variant == 4) run_dw1<4, 4, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
+            else if (variant == 5) run_dw2<8, 3, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
+            else if (variant == 6) run_dw2<4, 3, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
             else run_lds<true>(dA, dW, dC, s.M, s.N, s.K, 1);
             double worst = 0;
             for (int q = 0; q < 64; ++q) {
@@ -555,7 +756,7 @@ int main() {
                 const double err = fabs(bf2f(got) - ref) / (fabs(ref) + 0.05 * sqrt((double)s.K) * 0.07);
                 worst = std::max(worst, err);
             }
-            printf("%-20s %s: worst sampled relative error %.4f %s\n", s.what, variant == 0 ? "W direct, 3 A stages" : variant == 1 ? "W direct, 4 A stages" : variant == 3 ? "W direct, 1 x 8 waves" : variant == 4 ? "W direct, 1 x 4 waves" : "both via LDS (gemm4w)",
+            printf("%-20s %s: worst sampled relative error %.4f %s\n", s.what, variant == 0 ? "W direct, 3 A stages" : variant == 1 ? "W direct, 4 A stages" : variant == 3 ? "W direct, 1 x 8 waves" : variant == 4 ? "W direct, 1 x 4 waves" : variant == 5 ? "W direct x2 sets, 1 x 8" : variant == 6 ? "W direct x2 sets, 1 x 4" : "both via LDS (gemm4w)",
                    worst, worst < 2e-2 ? "ok" : "MISMATCH");
         }
         printf("%-20s M=%6d N=%5d K=%5d  TFLOP/s\n", s.what, s.M, s.N, s.K);
@@ -568,7 +769,7 @@ int main() {
                run_dw<NS_, false, 0, false>(dA, dWp, dC, s.M, s.N, s.K, reps), run_dw<NS_, false, 8>(dA, dWp, dC, s.M, s.N, s.K, reps),       \
                run_dw<NS_, false, 1>(dA, dWp, dC, s.M, s.N, s.K, reps), run_dw<NS_, false, 9>(dA, dWp, dC, s.M, s.N, s.K, reps),              \
                run_dw<NS_, false, 11>(dA, dWp, dC, s.M, s.N, s.K, reps), run_dw<NS_, false, 15>(dA, dWp, dC, s.M, s.N, s.K, reps));
-        ROW(3) ROW(4)
+        ROW(3)
 #undef ROW
 #define ROW1(NW_, NS_)                                                                                                                        \
         printf("    W direct, 1 x %d waves, %d A stages : full %7.1f | no stores %7.1f | no W loads %7.1f | no A DMA %7.1f | neither %7.1f | + no barrier %7.1f | + no A reads %7.1f\n", NW_, NS_, \
@@ -576,8 +777,14 @@ int main() {
                run_dw1<NW_, NS_, false, 8>(dA, dWp, dC, s.M, s.N, s.K, reps), run_dw1<NW_, NS_, false, 1>(dA, dWp, dC, s.M, s.N, s.K, reps),   \
                run_dw1<NW_, NS_, false, 9>(dA, dWp, dC, s.M, s.N, s.K, reps), run_dw1<NW_, NS_, false, 11>(dA, dWp, dC, s.M, s.N, s.K, reps),  \
                run_dw1<NW_, NS_, false, 15>(dA, dWp, dC, s.M, s.N, s.K, reps));
-        ROW1(8, 3) ROW1(8, 4) ROW1(4, 3) ROW1(4, 4)
 #undef ROW1
+#define CELL(NW_, NS_, ABL_) { const double tf = run_dw2<NW_, NS_, false, ABL_>(dA, dWp, dC, s.M, s.N, s.K, reps); const double g = last_clock_ghz(dC, s.M, s.N); \
+                              printf(" %7.1f @ %.2f GHz (MFMA busy %.2f) |", tf, g, tf * 1e12 / (256.0 * 4096.0 * g * 1e9)); }
+#define ROW2(NW_, NS_)                                                                                                                        \
+        printf("    W direct x2 sets, spread, 1 x %d waves, %d A stages: no stores | frozen addresses | dword loads | no W loads | no A DMA | neither | + no barrier | + no A reads (MFMA only)\n       ", NW_, NS_); \
+        CELL(NW_, NS_, 0) CELL(NW_, NS_, 16) CELL(NW_, NS_, 32) CELL(NW_, NS_, 8) CELL(NW_, NS_, 1) CELL(NW_, NS_, 9) CELL(NW_, NS_, 11) CELL(NW_, NS_, 15) printf("\n");
+        ROW2(8, 3) ROW2(4, 3)
+#undef ROW2
     }
     return 0;
 }
