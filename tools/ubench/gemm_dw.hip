@@ -70,6 +70,38 @@ __device__ __forceinline__ void gload1(unsigned& dst, const rsrc_t rs, unsigned 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// count known only after unrolling: the switch folds to one s_waitcnt
+__device__ __forceinline__ void wait_vmcnt_n(int n) {
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;
+        case 7: wait_vmcnt<7>(); break;
+        case 8: wait_vmcnt<8>(); break;
+        case 9: wait_vmcnt<9>(); break;
+        case 10: wait_vmcnt<10>(); break;
+        case 11: wait_vmcnt<11>(); break;
+        case 12: wait_vmcnt<12>(); break;
+        case 13: wait_vmcnt<13>(); break;
+        case 14: wait_vmcnt<14>(); break;
+        case 15: wait_vmcnt<15>(); break;
+        case 16: wait_vmcnt<16>(); break;
+        case 17: wait_vmcnt<17>(); break;
+        case 18: wait_vmcnt<18>(); break;
+        case 19: wait_vmcnt<19>(); break;
+        case 20: wait_vmcnt<20>(); break;
+        case 21: wait_vmcnt<21>(); break;
+        case 22: wait_vmcnt<22>(); break;
+        case 23: wait_vmcnt<23>(); break;
+        case 24: wait_vmcnt<24>(); break;
+        default: wait_vmcnt<0>(); break;
+    }
+}
+
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
     typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
     bf2 v = {(__bf16)lo, (__bf16)hi};
@@ -560,6 +592,193 @@ void gemm_dw2_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wp
     }
 }
 
+// ---- variant 4 = variant 3 with ONE barrier per TWO units: a 4-stage ring read pairwise; the A pieces of the next pair are all issued during
+// the first unit of the current one (its stages were read by the previous pair: free once this pair's barrier is passed), so they are a
+// unit old at the next barrier.  VMEM per k-step: first unit of a pair NN W + 2 PPK A, second unit NN W.  ABL in {0, 9, 11, 15} only.
+// (variant 3: variant 2 with the W fragments of the NEXT unit in a second register set, so that their loads (and the A pieces) can
+// sit anywhere among the MFMAs of a k-step instead of in one burst behind them: {MI*NN/VPK MFMAs, one VMEM} x VPK per k-step, order
+// W0 A0 [W1 A1].  The loop is unrolled by two units (register set = unit parity); K must be a multiple of 128.)
+// ABL 16: every unit fetches the SAME source addresses (k offset frozen): the VMEM instruction stream without its L2 / HBM traffic.
+template <int NW, int NSTG, bool STORE, int ABL>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
+void gemm_dw3_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wp, bf16_t* __restrict__ C, int M, int N, int K, int nt) {
+    constexpr int ROWB = 128, CPR = 8, RPP = 8;
+    constexpr int UNIT = 256 * ROWB;
+    constexpr int PPW = 32 / NW, PPK = PPW / 4;
+    constexpr int KS = 4, NN = 8 / NW, MI = 8;
+    constexpr int VE = NN + 2 * PPK, VO = NN, TAIL = 2;   // VMEM per k-step in the first / second unit of a pair; A pieces behind the last W of a first-unit k-step
+    // NW = 4 only: the 1 x 8 form of this schedule produced wrong results on the GPU (profiles/r04_ubench_gemm_dw_pair.log) and was not debugged —
+    // the schedule buys nothing either way (see the log: MFMA-busy rises, the clock falls by as much).
+    static_assert(NW == 4 && NSTG == 4 && (ABL == 0 || (ABL & 9) == 9), "");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int frow = lane & 31, half = lane >> 5;
+    const int nblk = gridDim.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
+    const int bid = xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3);
+    const int tm = bid / nt, tn = bid - tm * nt;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    // block 0 stamps its life in core-clock (s_memtime) and 100-MHz (s_memrealtime) ticks: the effective clock under this variant's load
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    const rsrc_t rsA = make_rsrc(A);
+    const rsrc_t rsW = make_rsrc(Wp);
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+    auto swz = [](int row) { return (row >> 1) & 7; };
+
+    unsigned src_off[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int piece = wave * PPW + j;
+        const int row = piece * RPP + lane / CPR;
+        const int c = (lane % CPR) ^ swz(row);
+        src_off[j] = (unsigned)((long)(m0 + row) * (long)K * 2 + c * 16);
+    }
+    const int T = K / 64;
+    auto issue_piece = [&](int t, int j) {
+        rsrc_t r = rsA;
+        r.z = t < T ? 0xfffffff0u : 0u;
+        if (ABL & 32) glds1(r, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(t % NSTG) * UNIT + (wave * PPW + j) * 1024), src_off[j], (ABL & 16) ? 0u : (unsigned)t * ROWB);
+        else glds(r, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(t % NSTG) * UNIT + (wave * PPW + j) * 1024), src_off[j], (ABL & 16) ? 0u : (unsigned)t * ROWB);
+    };
+    const unsigned w_voff = (unsigned)lane * 16u;
+    const unsigned w_kib0 = (unsigned)((n0 >> 5) + wave * NN) * (unsigned)(K >> 4);
+    const unsigned w_kibn = (unsigned)(K >> 4);
+    Frag8 wf[2][KS][NN];
+    auto issue_w = [&](auto B, int t, int s, int n) {
+        constexpr int b = decltype(B)::value;
+        rsrc_t r = rsW;
+        r.z = t < T ? 0xfffffff0u : 0u;
+        if (ABL & 32) gload1(*reinterpret_cast<unsigned*>(&wf[b][s][n]), r, w_voff, __builtin_amdgcn_readfirstlane((w_kib0 + n * w_kibn + (unsigned)(((ABL & 16) ? 0 : t) * KS + s)) << 10));
+        else gload(wf[b][s][n].r, r, w_voff, __builtin_amdgcn_readfirstlane((w_kib0 + n * w_kibn + (unsigned)(((ABL & 16) ? 0 : t) * KS + s)) << 10));
+    };
+    // first unit of a pair (EVEN): after MFMA q of k-step s.  1 x 8: W0 | A(t+2) | A(t+3) behind MFMAs 3, 6, 8;  1 x 4: W0 A A W1 A A behind 3, 6, 8, 11, 14, 16.
+    // second unit: W only, at the same positions.
+    auto issue_q = [&](auto BN, auto EVEN, int t, int s, int q) {
+        constexpr bool even = decltype(EVEN)::value;
+        if (ABL & 9) return;
+        if (NN == 1) {
+            if (q == 2) issue_w(BN, t + 1, s, 0);
+            if (even && q == 5) issue_piece(t + 2, s);
+            if (even && q == 7) issue_piece(t + 3, s);
+        } else {
+            if (q == 2) issue_w(BN, t + 1, s, 0);
+            if (even && q == 5) issue_piece(t + 2, 2 * s);
+            if (even && q == 7) issue_piece(t + 2, 2 * s + 1);
+            if (q == 10) issue_w(BN, t + 1, s, 1);
+            if (even && q == 13) issue_piece(t + 3, 2 * s);
+            if (even && q == 15) issue_piece(t + 3, 2 * s + 1);
+        }
+    };
+
+    f32x16_t acc[MI][NN];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int n = 0; n < NN; ++n) wf[b][s][n].u = make_uint4(0, 0, 0, 0);
+
+    typedef std::integral_constant<int, 0> B0;
+    typedef std::integral_constant<int, 1> B1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) issue_piece(t, j);
+#pragma unroll
+    for (int s = 0; s < KS; ++s)                                           // "unit -1" = a second unit: W of unit 0 only
+#pragma unroll
+        for (int n = 0; n < NN; ++n) issue_w(B0{}, 0, s, n);
+    if (ABL & 9) { wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); }
+
+    const int x0 = half ^ swz(frow);
+    const unsigned a_rd = (unsigned)(frow * ROWB);
+    Frag8 af[2][MI];
+    if (ABL & 4) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[b][i].u = *(const uint4*)(smem + a_rd + i * 32 * ROWB + (x0 << 4));
+    }
+
+    auto unit = [&](auto B, auto BN, auto EVEN, int t) {
+        constexpr int b = decltype(B)::value;
+        constexpr bool even = decltype(EVEN)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* ub = smem + (t % NSTG) * UNIT;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ABL == 0) {                                                // W of (t, ks) was issued at k-step ks of unit t - 1
+                if (even) wait_vmcnt_n((3 - ks) * VO + ks * VE);
+                else wait_vmcnt_n(TAIL + (3 - ks) * VE + ks * VO);
+            }
+            if (ks == 0) {
+                if (even && !(ABL & 2)) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (!(ABL & 4)) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) af[0][i].u = *(const uint4*)(ub + a_rd + i * 32 * ROWB + (x0 << 4));
+                }
+            }
+            if (ks + 1 < KS && !(ABL & 4)) {
+                const int co = (x0 ^ ((ks + 1) << 1)) << 4;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[(ks + 1) & 1][i].u = *(const uint4*)(ub + a_rd + i * 32 * ROWB + co);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < MI * NN; ++q) {
+                const int i = q / NN, n = q % NN;
+                MFMA_32x32x16(acc[i][n], wf[b][ks][n].v, af[ks & 1][i].v);
+                issue_q(BN, EVEN, t, ks, q);
+            }
+        }
+    };
+    for (int t = 0; t < T; t += 2) {
+        unit(B0{}, B1{}, std::true_type{}, t);
+        unit(B1{}, B0{}, std::false_type{}, t + 1);
+    }
+    wait_vmcnt<0>();
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (STORE) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const long m = m0 + i * 32 + frow;
+#pragma unroll
+            for (int n = 0; n < NN; ++n) {
+                bf16_t* crow = C + m * (long)N + n0 + wave * 32 * NN + n * 32 + 4 * half;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 o;
+                    o.x = pack2bf(acc[i][n][4 * g], acc[i][n][4 * g + 1]);
+                    o.y = pack2bf(acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]);
+                    *(uint2*)(crow + 8 * g) = o;
+                }
+            }
+        }
+    } else {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int n = 0; n < NN; ++n) s += acc[i][n][0] + acc[i][n][15];
+        if (s == 12345.678f) C[threadIdx.x] = 1;
+    }
+    if (!STORE && blockIdx.x == 0 && threadIdx.x == 0) {                   // just past the M x N outputs (the host allocates 64 bytes more)
+        unsigned long long* stamp = reinterpret_cast<unsigned long long*>(C + (size_t)M * N);
+        stamp[0] = __builtin_amdgcn_s_memtime() - c0;
+        stamp[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+}
+
 // ---- gemm4w.hip's plain 8-wave loop (both operands through the LDS ring), for the same-binary comparison ----
 template <bool STORE, int ABL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -707,6 +926,10 @@ static double last_clock_ghz(const bf16_t* dC, int M, int N) {
     (void)hipMemcpy(h, dC + (size_t)M * N, sizeof(h), hipMemcpyDeviceToHost);
     return h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
 }
+template <int NW, bool STORE, int ABL = 0>
+static double run_dw3(const bf16_t* dA, const bf16_t* dWp, bf16_t* dC, int M, int N, int K, int reps) {
+    return time_kernel(gemm_dw3_kernel<NW, 4, STORE, ABL>, (size_t)4 * 256 * 128, dA, dWp, dC, M, N, K, reps, NW * 64);
+}
 template <bool STORE, int ABL = 0>
 static double run_lds(const bf16_t* dA, const bf16_t* dW, bf16_t* dC, int M, int N, int K, int reps) {
     return time_kernel(gemm_lds_kernel<STORE, ABL>, (size_t)2 * 2 * 256 * 128, dA, dW, dC, M, N, K, reps);
@@ -738,7 +961,7 @@ int main() {
                 hWp[(((n >> 5) * (s.K >> 4) + (k >> 4)) * 64 + ((k & 15) >> 3) * 32 + (n & 31)) * 8 + (k & 7)] = hW[n * s.K + k];
         (void)hipMemcpy(dW, hW.data(), (size_t)s.N * s.K * 2, hipMemcpyHostToDevice);
         (void)hipMemcpy(dWp, hWp.data(), (size_t)s.N * s.K * 2, hipMemcpyHostToDevice);
-        for (int variant = 0; variant < 7; ++variant) {
+        for (int variant = 0; variant < 9; ++variant) {
             (void)hipMemset(dC, 0xff, (size_t)s.M * s.N * 2);
             if (variant == 0) run_dw<3, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
             else if (variant == 1) run_dw<4, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
@@ -746,6 +969,8 @@ int main() {
             else if (variant == 4) run_dw1<4, 4, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
             else if (variant == 5) run_dw2<8, 3, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
             else if (variant == 6) run_dw2<4, 3, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
+            else if (variant == 7) continue;
+            else if (variant == 8) run_dw3<4, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
             else run_lds<true>(dA, dW, dC, s.M, s.N, s.K, 1);
             double worst = 0;
             for (int q = 0; q < 64; ++q) {
@@ -756,7 +981,7 @@ int main() {
                 const double err = fabs(bf2f(got) - ref) / (fabs(ref) + 0.05 * sqrt((double)s.K) * 0.07);
                 worst = std::max(worst, err);
             }
-            printf("%-20s %s: worst sampled relative error %.4f %s\n", s.what, variant == 0 ? "W direct, 3 A stages" : variant == 1 ? "W direct, 4 A stages" : variant == 3 ? "W direct, 1 x 8 waves" : variant == 4 ? "W direct, 1 x 4 waves" : variant == 5 ? "W direct x2 sets, 1 x 8" : variant == 6 ? "W direct x2 sets, 1 x 4" : "both via LDS (gemm4w)",
+            printf("%-20s %s: worst sampled relative error %.4f %s\n", s.what, variant == 0 ? "W direct, 3 A stages" : variant == 1 ? "W direct, 4 A stages" : variant == 3 ? "W direct, 1 x 8 waves" : variant == 4 ? "W direct, 1 x 4 waves" : variant == 5 ? "W direct x2 sets, 1 x 8" : variant == 6 ? "W direct x2 sets, 1 x 4" : variant == 7 ? "... barrier per 2 units, 1 x 8" : variant == 8 ? "... barrier per 2 units, 1 x 4" : "both via LDS (gemm4w)",
                    worst, worst < 2e-2 ? "ok" : "MISMATCH");
         }
         printf("%-20s M=%6d N=%5d K=%5d  TFLOP/s\n", s.what, s.M, s.N, s.K);
@@ -784,6 +1009,11 @@ int main() {
         printf("    W direct x2 sets, spread, 1 x %d waves, %d A stages: no stores | frozen addresses | dword loads | no W loads | no A DMA | neither | + no barrier | + no A reads (MFMA only)\n       ", NW_, NS_); \
         CELL(NW_, NS_, 0) CELL(NW_, NS_, 16) CELL(NW_, NS_, 32) CELL(NW_, NS_, 8) CELL(NW_, NS_, 1) CELL(NW_, NS_, 9) CELL(NW_, NS_, 11) CELL(NW_, NS_, 15) printf("\n");
         ROW2(8, 3) ROW2(4, 3)
+#define CELL3(NW_, ABL_) { const double tf = run_dw3<NW_, false, ABL_>(dA, dWp, dC, s.M, s.N, s.K, reps); const double g = last_clock_ghz(dC, s.M, s.N); \
+                          printf(" %7.1f @ %.2f GHz (MFMA busy %.2f) |", tf, g, tf * 1e12 / (256.0 * 4096.0 * g * 1e9)); }
+        printf("    ... one barrier per TWO units (1 x 4 waves, 4 A stages): no stores | neither | + no barrier ; full with stores %7.1f\n       ",
+               run_dw3<4, true, 0>(dA, dWp, dC, s.M, s.N, s.K, reps));
+        CELL3(4, 0) CELL3(4, 9) CELL3(4, 11) printf("\n");
 #undef ROW2
     }
     return 0;
