@@ -499,6 +499,75 @@ def test_batch_consistency_sd15(dev):
         check(f"batch consistency scene {k}", e, 1e-2)
 
 
+def test_sample_driver_cond_on_view_end_to_end(dev, tmp_path):
+    """tools/sample.py --cond-on-view = demo/run_cond_on_view.py on the GPU: the given-view pipeline class, UniPC (what build_pipe installs),
+    the ground-truth views encoded by the HIP VAE encoder, generation ti with view ti given.  Checks: files, that the driver's generation 0 is
+    bit-identical to encoding + calling the given-view pipeline by hand, and that generations differ."""
+    import importlib.util
+    import os
+    import yaml
+    from PIL import Image
+    from magicdrive_amd.networks.autoencoder_kl import AutoencoderKL
+    from magicdrive_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiview
+    from magicdrive_amd.networks.unet_addon_rawbox import BEVControlNetModel
+    here = os.path.dirname(os.path.abspath(__file__))
+    sp = importlib.util.spec_from_file_location("mdx_tools_sample_cv", os.path.join(os.path.dirname(here), "tools", "sample.py"))
+    sample = importlib.util.module_from_spec(sp); sp.loader.exec_module(sample)
+    cfg = spec.TINY_CONFIG
+    ckpt = tmp_path / "ckpt"
+    UNet2DConditionModelMultiview.from_config(cfg, seed=0).save_pretrained(str(ckpt / "unet"))
+    BEVControlNetModel.from_config(cfg, seed=1).save_pretrained(str(ckpt / "controlnet"))
+    os.makedirs(ckpt / "hydra")
+    with open(ckpt / "hydra" / "overrides.yaml", "w") as f:
+        yaml.safe_dump(["+exp=224x400", "runner.validation_times=3", "seed=7"], f)
+    sd15 = tmp_path / "sd15"
+    os.makedirs(sd15 / "scheduler")
+    with open(sd15 / "scheduler" / "scheduler_config.json", "w") as f:
+        f.write('{"_class_name": "PNDMScheduler", "beta_end": 0.012, "beta_schedule": "scaled_linear", "beta_start": 0.00085, '
+                '"num_train_timesteps": 1000, "set_alpha_to_one": false, "skip_prk_steps": true, "steps_offset": 1, "clip_sample": false}')
+    AutoencoderKL.from_config(spec.VAE_TINY_CONFIG, 5, with_encoder=True).save_pretrained(str(sd15 / "vae"))
+    data = tmp_path / "data"; os.makedirs(data)
+    G = torch.load(os.path.join(here, "golden", "sample_preprocess.pt"), weights_only=False)
+    imgs = []
+    for i, case in enumerate(G["cases"][:2]):
+        smp = dict(case["sample"])
+        m = smp["gt_masks_bev"]
+        smp["gt_masks_bev"] = m.repeat_interleave(10, 1).repeat_interleave(10, 2) if isinstance(m, torch.Tensor) else np.repeat(np.repeat(m, 10, 1), 10, 2)
+        smp["img"] = torch.rand(6, 3, 224, 400, generator=torch.Generator().manual_seed(40 + i)) * 2 - 1     # the ground-truth views, [-1, 1]
+        imgs.append(smp["img"])
+        torch.save(smp, data / f"tok{i}.pth")
+    out = tmp_path / "out"
+    sample.main(["--ckpt", str(ckpt), "--sd15", str(sd15), "--data", str(data), "--out", str(out), "--scheduler", "unipc", "--batch-size", "2",
+                 "--prompt-embeds", "--device", str(dev), "--cond-on-view", "runner.pipeline_param.num_inference_steps=3"])
+    files = sorted(os.listdir(out))
+    assert len(files) == 2 * 2 * 6, files[:8]                    # validation_times - 1 = 2 generations per scene
+    # the driver == composing the pieces by hand: encode the ground-truth views, give view 0, same seed -> the same six images for generation 0
+    # (with random weights a given view does NOT come out as its ground truth: UniPC's last step leaves t = 333 with this network's epsilon,
+    # exactly as in the reference — so the check is equality with the direct call, not closeness to the input image)
+    pipe = sample.build_pipe(str(ckpt), str(sd15), "unipc", dev, given_view=True)
+    run = sample.resolve_run_config(str(ckpt), ["runner.pipeline_param.num_inference_steps=3"])
+    from magicdrive_amd.dataset import FolderSet
+    (kw, px), = list(sample.iter_pipe_kwargs(FolderSet(str(data)), run, 2, with_pixels=True))
+    assert torch.equal(px, torch.stack(imgs))
+    lat = sample.encode_given_views(pipe, px)
+    assert tuple(lat.shape) == (2, 6, 4, 28, 50)
+    ref_vae = AutoencoderKL.from_pretrained(str(sd15 / "vae"), torch_dtype=torch.float16).to(dev)      # build_pipe loads everything in fp16 (test_utils.py:95)
+    ref_mean = ref_vae.encode(px[0].to(dev)).latent_dist.mean * 0.18215
+    assert rel_l2(lat[0], ref_mean) < 1e-3, rel_l2(lat[0], ref_mean)
+    D = cfg["cross_attention_dim"]
+    kw.update(prompt=None, prompt_embeds=torch.zeros(2, 77, D), negative_prompt_embeds=torch.zeros(2, 77, D))
+    cl = [[None] * 6 for _ in range(2)]
+    for b in range(2):
+        cl[b][0] = lat[b, 0]
+    direct = pipe(conditional_latents=cl, generator=torch.Generator().manual_seed(7), **kw).images
+    for b in range(2):
+        for v in range(6):
+            assert (np.asarray(direct[b][v]) == np.asarray(Image.open(out / f"{b}_gen0_view{v}.png"))).all(), (b, v)
+    # and giving a view matters: the given view of generation 0 differs from that view in generation 1 (where view 1 is given instead)
+    a, c = np.asarray(Image.open(out / "0_gen0_view0.png")), np.asarray(Image.open(out / "0_gen1_view0.png"))
+    assert (a != c).any()
+
+
 def test_sample_driver_end_to_end(dev, tmp_path):
     """tools/sample.py = the reference's tools/test.py flow on the GPU: a tiny checkpoint in the reference layout with
     its hydra overrides, a tiny SD-1.5-layout directory (scheduler config + VAE, no text encoder), five `.pth` samples in the demo format
