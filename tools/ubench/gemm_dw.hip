@@ -779,6 +779,153 @@ void gemm_dw3_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wp
     }
 }
 
+// ---- variant 5: variant 3 (1 x 8 waves, W in two register sets, VMEM spread) on v_mfma_f32_16x16x32_bf16 — the shape gemm_xl.hip runs and the one a
+// pure MFMA stream clocks 14 % higher on (profiles/r04_ubench_mfma_shape.log).  Wave tile 256 x 32 = 16 x 2 tiles of 16 x 16 (128 accumulators);
+// a 64-deep unit = 2 k-steps of 32; a k-step is processed in two halves of 8 A fragments (two register sets of 8, as before); W host layout
+// Wq[n / 16][k / 32][lane][8] (lane = (k % 32) / 8 * 16 + n % 16).  Per half: {8 MFMAs, W load, 8 MFMAs, A piece}; the pair of W fragments of a
+// k-step was issued in the two halves of that k-step one unit earlier: 1 + 2 * 2 = 5 younger VMEM instructions.
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+#define MFMA_16x16x32(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+template <int NSTG, bool STORE, int ABL>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_dw16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wq, bf16_t* __restrict__ C, int M, int N, int K, int nt) {
+    constexpr int ROWB = 128, CPR = 8, RPP = 8, UNIT = 256 * ROWB, PPW = 4;
+    static_assert(NSTG >= 3 && (ABL == 0 || (ABL & 9) == 9), "");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int frow = lane & 15, kq = lane >> 4;
+    const int nblk = gridDim.x;
+    const int xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
+    const int bid = xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3);
+    const int tm = bid / nt, tn = bid - tm * nt;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    const rsrc_t rsA = make_rsrc(A);
+    const rsrc_t rsW = make_rsrc(Wq);
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+    auto swz = [](int row) { return (row >> 1) & 7; };
+    unsigned src_off[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int piece = wave * PPW + j;
+        const int row = piece * RPP + lane / CPR;
+        const int c = (lane % CPR) ^ swz(row);
+        src_off[j] = (unsigned)((long)(m0 + row) * (long)K * 2 + c * 16);
+    }
+    const int T = K / 64;
+    auto issue_piece = [&](int t, int j) {
+        rsrc_t r = rsA;
+        r.z = t < T ? 0xfffffff0u : 0u;
+        glds(r, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(t % NSTG) * UNIT + (wave * PPW + j) * 1024), src_off[j], (unsigned)t * ROWB);
+    };
+    // W fragment (16-column block n of this wave, k-step ks of unit t): KiB number ((n0 / 16 + wave * 2 + n) * (K / 32) + t * 2 + ks)
+    const unsigned w_voff = (unsigned)lane * 16u;
+    const unsigned w_kib0 = (unsigned)((n0 >> 4) + wave * 2) * (unsigned)(K >> 5);
+    const unsigned w_kibn = (unsigned)(K >> 5);
+    Frag8 wf[2][2][2];                                                     // [register set][k-step][column block]
+    auto issue_w = [&](auto B, int t, int v) {                             // v = 2 ks + n
+        constexpr int b = decltype(B)::value;
+        rsrc_t r = rsW;
+        r.z = t < T ? 0xfffffff0u : 0u;
+        gload(wf[b][v >> 1][v & 1].r, r, w_voff, __builtin_amdgcn_readfirstlane((w_kib0 + (v & 1) * w_kibn + (unsigned)(t * 2 + (v >> 1))) << 10));
+    };
+    f32x4_t acc[16][2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][n][r] = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) wf[b][v >> 1][v & 1].u = make_uint4(0, 0, 0, 0);
+    typedef std::integral_constant<int, 0> B0;
+    typedef std::integral_constant<int, 1> B1;
+#pragma unroll
+    for (int t = 0; t < NSTG - 2; ++t)
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) issue_piece(t, j);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { issue_w(B0{}, 0, v); issue_piece(NSTG - 2, v); }      // "unit -1" in the loop's pattern
+    if (ABL & 9) { wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); }
+
+    // A fragment of row block i (16 rows), k-step ks: logical chunk 4 ks + kq of row i * 16 + frow
+    const unsigned a_rd = (unsigned)(frow * ROWB);
+    const int sw = swz(frow);                                              // rows i * 16 + frow: (row >> 1) & 7 = (frow >> 1) & 7 for every i
+    Frag8 af[2][8];
+    if (ABL & 4) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[b][i].u = *(const uint4*)(smem + a_rd + i * 16 * ROWB + ((kq ^ sw) << 4));
+    }
+    auto unit = [&](auto B, auto BN, int t) {
+        constexpr int b = decltype(B)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* ub = smem + (t % NSTG) * UNIT;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {                                      // half h: k-step h >> 1, row blocks (h & 1) * 8 .. + 8
+            const int ks = h >> 1;
+            if (ABL == 0 && (h & 1) == 0) wait_vmcnt<5>();
+            if (h == 0) {
+                if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (!(ABL & 4)) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) af[0][i].u = *(const uint4*)(ub + a_rd + i * 16 * ROWB + ((kq ^ sw) << 4));
+                }
+            }
+            if (h + 1 < 4 && !(ABL & 4)) {
+                const int ks1 = (h + 1) >> 1, i0 = ((h + 1) & 1) * 8;
+                const int co = (((4 * ks1 + kq) ^ sw) & 7) << 4;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) af[(h + 1) & 1][i].u = *(const uint4*)(ub + a_rd + (i0 + i) * 16 * ROWB + co);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = q >> 1, n = q & 1;
+                MFMA_16x16x32(acc[(h & 1) * 8 + i][n], wf[b][ks][n].v, af[h & 1][i].v);
+                if (ABL == 0 && q == 7) issue_w(BN, t + 1, h);
+                if (ABL == 0 && q == 15) issue_piece(t + NSTG - 1, h);
+            }
+        }
+    };
+    for (int t = 0; t < T; t += 2) {
+        unit(B0{}, B1{}, t);
+        unit(B1{}, B0{}, t + 1);
+    }
+    wait_vmcnt<0>();
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (STORE) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long m = m0 + i * 16 + frow;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                uint2 o;
+                o.x = pack2bf(acc[i][n][0], acc[i][n][1]);
+                o.y = pack2bf(acc[i][n][2], acc[i][n][3]);
+                *(uint2*)(C + m * (long)N + n0 + wave * 32 + n * 16 + 4 * kq) = o;
+            }
+        }
+    } else {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) s += acc[i][n][0] + acc[i][n][3];
+        if (s == 12345.678f) C[threadIdx.x] = 1;
+    }
+    if (!STORE && blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long* stamp = reinterpret_cast<unsigned long long*>(C + (size_t)M * N);
+        stamp[0] = __builtin_amdgcn_s_memtime() - c0;
+        stamp[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+}
+
 // ---- gemm4w.hip's plain 8-wave loop (both operands through the LDS ring), for the same-binary comparison ----
 template <bool STORE, int ABL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -930,6 +1077,10 @@ template <int NW, bool STORE, int ABL = 0>
 static double run_dw3(const bf16_t* dA, const bf16_t* dWp, bf16_t* dC, int M, int N, int K, int reps) {
     return time_kernel(gemm_dw3_kernel<NW, 4, STORE, ABL>, (size_t)4 * 256 * 128, dA, dWp, dC, M, N, K, reps, NW * 64);
 }
+template <int NSTG, bool STORE, int ABL = 0>
+static double run_dw16(const bf16_t* dA, const bf16_t* dWq, bf16_t* dC, int M, int N, int K, int reps) {
+    return time_kernel(gemm_dw16_kernel<NSTG, STORE, ABL>, (size_t)NSTG * 256 * 128, dA, dWq, dC, M, N, K, reps, 512);
+}
 template <bool STORE, int ABL = 0>
 static double run_lds(const bf16_t* dA, const bf16_t* dW, bf16_t* dC, int M, int N, int K, int reps) {
     return time_kernel(gemm_lds_kernel<STORE, ABL>, (size_t)2 * 2 * 256 * 128, dA, dW, dC, M, N, K, reps);
@@ -945,13 +1096,13 @@ int main() {
         maxA = std::max(maxA, (size_t)s.M * s.K); maxW = std::max(maxW, (size_t)s.N * s.K); maxC = std::max(maxC, (size_t)s.M * s.N);
         if ((size_t)s.M * s.K * 2 >= 0xfffffff0ull || (size_t)s.N * s.K * 2 >= 0xfffffff0ull || (s.M % 256) || (s.N % 256) || (s.K % 64)) { printf("bad shape %s\n", s.what); return 1; }
     }
-    std::vector<bf16_t> hA(maxA), hW(maxW), hWp(maxW);
+    std::vector<bf16_t> hA(maxA), hW(maxW), hWp(maxW), hWq(maxW);
     unsigned seed = 12345u;
     auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return ((seed >> 9) & 0xffff) / 65536.0f - 0.5f; };
     for (auto& v : hA) v = f2bf(rnd());
     for (auto& v : hW) v = f2bf(rnd() * 0.25f);
-    bf16_t *dA, *dW, *dWp, *dC;
-    (void)hipMalloc(&dA, maxA * 2); (void)hipMalloc(&dW, maxW * 2); (void)hipMalloc(&dWp, maxW * 2); (void)hipMalloc(&dC, maxC * 2 + 64);
+    bf16_t *dA, *dW, *dWp, *dWq, *dC;
+    (void)hipMalloc(&dA, maxA * 2); (void)hipMalloc(&dW, maxW * 2); (void)hipMalloc(&dWp, maxW * 2); (void)hipMalloc(&dWq, maxW * 2); (void)hipMalloc(&dC, maxC * 2 + 64);
     (void)hipMemcpy(dA, hA.data(), maxA * 2, hipMemcpyHostToDevice);
     for (auto& s : shapes) {
         const int reps = 4;
@@ -961,7 +1112,11 @@ int main() {
                 hWp[(((n >> 5) * (s.K >> 4) + (k >> 4)) * 64 + ((k & 15) >> 3) * 32 + (n & 31)) * 8 + (k & 7)] = hW[n * s.K + k];
         (void)hipMemcpy(dW, hW.data(), (size_t)s.N * s.K * 2, hipMemcpyHostToDevice);
         (void)hipMemcpy(dWp, hWp.data(), (size_t)s.N * s.K * 2, hipMemcpyHostToDevice);
-        for (int variant = 0; variant < 9; ++variant) {
+        for (long n = 0; n < s.N; ++n)                                   // 16 x 32 blocks: Wq[n / 16][k / 32][lane = (k % 32) / 8 * 16 + n % 16][k % 8]
+            for (long k = 0; k < s.K; ++k)
+                hWq[(((n >> 4) * (s.K >> 5) + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (n & 15)) * 8 + (k & 7)] = hW[n * s.K + k];
+        (void)hipMemcpy(dWq, hWq.data(), (size_t)s.N * s.K * 2, hipMemcpyHostToDevice);
+        for (int variant = 0; variant < 10; ++variant) {
             (void)hipMemset(dC, 0xff, (size_t)s.M * s.N * 2);
             if (variant == 0) run_dw<3, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
             else if (variant == 1) run_dw<4, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
@@ -970,6 +1125,7 @@ int main() {
             else if (variant == 5) run_dw2<8, 3, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
             else if (variant == 6) run_dw2<4, 3, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
             else if (variant == 7) continue;
+            else if (variant == 9) run_dw16<3, true>(dA, dWq, dC, s.M, s.N, s.K, 1);
             else if (variant == 8) run_dw3<4, true>(dA, dWp, dC, s.M, s.N, s.K, 1);
             else run_lds<true>(dA, dW, dC, s.M, s.N, s.K, 1);
             double worst = 0;
@@ -981,7 +1137,7 @@ int main() {
                 const double err = fabs(bf2f(got) - ref) / (fabs(ref) + 0.05 * sqrt((double)s.K) * 0.07);
                 worst = std::max(worst, err);
             }
-            printf("%-20s %s: worst sampled relative error %.4f %s\n", s.what, variant == 0 ? "W direct, 3 A stages" : variant == 1 ? "W direct, 4 A stages" : variant == 3 ? "W direct, 1 x 8 waves" : variant == 4 ? "W direct, 1 x 4 waves" : variant == 5 ? "W direct x2 sets, 1 x 8" : variant == 6 ? "W direct x2 sets, 1 x 4" : variant == 7 ? "... barrier per 2 units, 1 x 8" : variant == 8 ? "... barrier per 2 units, 1 x 4" : "both via LDS (gemm4w)",
+            printf("%-20s %s: worst sampled relative error %.4f %s\n", s.what, variant == 0 ? "W direct, 3 A stages" : variant == 1 ? "W direct, 4 A stages" : variant == 3 ? "W direct, 1 x 8 waves" : variant == 4 ? "W direct, 1 x 4 waves" : variant == 5 ? "W direct x2 sets, 1 x 8" : variant == 6 ? "W direct x2 sets, 1 x 4" : variant == 7 ? "... barrier per 2 units, 1 x 8" : variant == 8 ? "... barrier per 2 units, 1 x 4" : variant == 9 ? "W direct, 1 x 8, 16x16x32 MFMA" : "both via LDS (gemm4w)",
                    worst, worst < 2e-2 ? "ok" : "MISMATCH");
         }
         printf("%-20s M=%6d N=%5d K=%5d  TFLOP/s\n", s.what, s.M, s.N, s.K);
@@ -1014,6 +1170,11 @@ int main() {
         printf("    ... one barrier per TWO units (1 x 4 waves, 4 A stages): no stores | neither | + no barrier ; full with stores %7.1f\n       ",
                run_dw3<4, true, 0>(dA, dWp, dC, s.M, s.N, s.K, reps));
         CELL3(4, 0) CELL3(4, 9) CELL3(4, 11) printf("\n");
+#define CELL16(NS_, ABL_) { const double tf = run_dw16<NS_, false, ABL_>(dA, dWq, dC, s.M, s.N, s.K, reps); const double g = last_clock_ghz(dC, s.M, s.N); \
+                           printf(" %7.1f @ %.2f GHz (MFMA busy %.2f) |", tf, g, tf * 1e12 / (256.0 * 4096.0 * g * 1e9)); }
+        printf("    W direct x2 sets, spread, 1 x 8 waves on 16x16x32 MFMAs: 3 A stages no stores | neither | + no barrier | + no A reads || 4 A stages no stores ; full with stores (3 stages) %7.1f\n       ",
+               run_dw16<3, true, 0>(dA, dWq, dC, s.M, s.N, s.K, reps));
+        CELL16(3, 0) CELL16(3, 9) CELL16(3, 11) CELL16(3, 15) CELL16(4, 0) printf("\n");
 #undef ROW2
     }
     return 0;
