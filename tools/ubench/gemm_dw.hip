@@ -19,8 +19,19 @@
 // at k-step s of unit t - 1 and has 1 + 3 * 3 = 10 younger instructions behind it: `s_waitcnt vmcnt(10)` in front of every k-step's
 // MFMAs.  The A pieces of unit t were issued during unit t - (NSTG - 1) <= t - 2, i.e. they are older than that: one wait serves both.
 //
+// Variants in this file (every complete one is checked against the host on sampled outputs; logs: profiles/r04_ubench_gemm_dw*.log):
+//   1  gemm_dw_kernel    2 x 4 waves of 128 x 64 (this header); the two waves of a column block fetch each W fragment twice
+//   2  gemm_dw1_kernel   1 x 8 / 1 x 4 waves: W fetched once, every wave reads the whole A tile
+//   3  gemm_dw2_kernel   + the next unit's W in a second register set: every VMEM instruction alone behind 4 MFMAs; probes: frozen source
+//                        addresses, quarter-width loads, effective clock of each variant (s_memtime / s_memrealtime stamps of block 0)
+//   4  gemm_dw3_kernel   + one barrier per TWO units on a 4-stage ring (1 x 4 only)
+//   5  gemm_dw16_kernel  variant 3 (1 x 8) on v_mfma_f32_16x16x32_bf16: the fastest, 1.32-1.46 PFLOP/s store-free
+//   gemm_lds_kernel      gemm4w.hip's plain 8-wave loop (both operands through the LDS ring), the same-binary baseline
+// What they established: the operand stream costs CLOCK (the bytes delivered into the CU), the barrier and the fragment reads cost MFMA-busy,
+// and busy x clock is pinned by the power budget (profiles/README.md, round-4 ubench section).
+//
 // Build:  hipcc --offload-arch=gfx950 -O3 -o gemm_dw gemm_dw.hip
-// Run:    ./gemm_dw           TFLOP/s per shape: this loop (3 and 4 A stages) and its ablations, next to gemm4w's 8-wave loop
+// Run:    ./gemm_dw           TFLOP/s per shape and variant with ablations
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
