@@ -3,7 +3,9 @@
 time (an --ops-json written by bench.py), summed per kernel.  The step is a mix of MFMA-bound launches (convs, attention, K >= 640
 GEMMs) and HBM-bound ones (norms, the K = 320 projections, residual adds): this is the per-launch roofline the bench line's single
 `roofline` object cannot show.  CPU only: the plan is built on the host at a small batch and its activation bytes are scaled.
-Usage: python tools/sol_table.py profiles/r02e_ops_b128.json [--scenes 128] [--out profiles/r03_sol_table.json]"""
+Usage: python tools/sol_table.py profiles/r02e_ops_b128.json [--scenes 128] [--out profiles/r03_sol_table.json]
+       --practical: the MEASURED roofs instead of the data-sheet ones — the 16x16x32 MFMA stream on random operands at the power budget
+       (2.05 PFLOP/s, profiles/r04_ubench_mfma_shape.log) and the achievable HBM rate (6.3 TB/s, MI355X_MICROARCH.md)."""
 import argparse
 import json
 import os
@@ -41,7 +43,11 @@ def main():
     ap.add_argument("--scenes", type=int, default=128)
     ap.add_argument("--build-scenes", type=int, default=2)
     ap.add_argument("--out", default="")
+    ap.add_argument("--practical", action="store_true")
     a = ap.parse_args()
+    global MFMA_PEAK, HBM_PEAK
+    if a.practical:
+        MFMA_PEAK, HBM_PEAK = 2051e12, 6.3e12
     cfg = spec.SD15_CONFIG
     dev = torch.device("cpu")
     usd = spec.random_state_dict(spec.unet_param_shapes(cfg), 0)
