@@ -16,4 +16,7 @@ struct Attn2Params {
 };
 bool attn2_supported(const Attn2Params& p);
 int launch_attn2(const Attn2Params& p, hipStream_t st);
+// attention3.hip: the pipelined head-dim-40 FOLD form (called from launch_attn2)
+bool attn3_supported(const Attn2Params& p);
+int launch_attn3(const Attn2Params& p, hipStream_t st);
 }  // namespace mdx

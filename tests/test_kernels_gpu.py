@@ -760,7 +760,8 @@ def test_attention_joint_sources(dev, b, heads, T, d, nsrc, expect, pre):
     qref = q
     if pre:                                  # MdxAttnDesc.q_prescaled (every kernel takes it; head dim 40 folds the maximum into the MFMA)
         q = (q.float() * qpre).to(BF); qref = q.float() / qpre
-        if d == 40: expect = expect.replace("q64>", "q32,fold>")      # joint one-softmax launches take the 32-query FOLD form
+        if d == 40:                           # pre-scaled head dim 40: attention3.hip (round 5); with ATTN3 = 0 the 32-query FOLD form of attention2.hip
+            expect = "attn3_kernel<40,joint>" if L.get_option("ATTN3") else expect.replace("q64>", "q32,fold>")
     O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=T, scale=d ** -0.5, kvmap=kvmap, nsrc=nsrc, joint=True, q_prescaled=pre)])
     kern = (L.lib().mdx_last_kernel() or b"").decode()
     torch.cuda.synchronize()
@@ -794,13 +795,16 @@ def attn2_route(d, Tq, xview=False, pre=False):
     if L.get_option("ATTN2") == 0 or (d == 80 and not (d80 == 1 or (d80 == 2 and xview))):
         return "attn_kernel<"                                       # attention.hip (prefix)
     fold = ",fold" if (pre and d == 40 and L.get_option("ATTN2_FOLD")) else ""
+    if fold and L.get_option("ATTN3"):             # round 5: the pipelined, permute-free form takes every head-dim-40 FOLD launch
+        return f"attn3_kernel<40,{mode}>"
     qt = L.get_option("ATTN2_QT")                  # 0: automatic = 64-query waves, except FOLD launches (32: four waves per SIMD)
     q = 64 if (d == 40 and Tq >= 512 and qt != 1 and (qt == 2 or not fold)) else 32
     return f"attn2_kernel<{d},{mode},q{q}{fold}>"
 
 
 ATTN2_CASES = [
-    (6, 8, 1400, 1400, 40),      # 22 tiles, the last one 56 kv wide; 64-query waves: the last workgroup has 2 idle waves and a half wave
+    (6, 8, 1400, 1400, 40),      # 22 tiles, the last one 56 kv wide; 64-query waves: the last workgroup has 2 idle waves and a half wave (attention3: 128-query
+                                 # workgroups, the last one with 3 full waves and one of 24 queries; an odd number of tile pairs + the masked tile)
     (6, 8, 1400, 78, 40),        # context: 2 tiles, pad columns inside a 16-byte chunk (NaN-poisoned below)
     (6, 8, 1400, 64, 40),        # exactly one full tile: no masked tile at all
     (6, 8, 1400, 129, 40),       # last tile 1 kv wide
@@ -808,6 +812,10 @@ ATTN2_CASES = [
     (6, 8, 350, 110, 80),
     (3, 8, 777, 333, 40),        # ragged query block (777 = 3 x 256 + 9 = 6 x 128 + 9)
     (6, 8, 300, 300, 40),        # below 512 queries: 32-query waves
+    (6, 8, 1400, 192, 40),       # three full tiles, no masked tile (attention3: pair loop + a full final tile)
+    (6, 8, 1400, 256, 40),       # four full tiles (attention3: the remainder of two)
+    (6, 8, 1290, 1283, 40),      # a wave with NO query (idle: stages and synchronises only) beside the scrub of a 3-kv last tile
+    (6, 8, 640, 17, 40),         # a lone partial tile: first = final = masked
 ]
 
 
@@ -861,6 +869,42 @@ def test_attention2_resident_short_kv(dev, B, heads, Tq, Tk):
         O.run_ops([O.Attn(q, k, vt, o2, heads=heads, Tk=Tk, scale=d ** -0.5, q_prescaled=True)])
     torch.cuda.synchronize()
     assert rel_l2(o, o2) < 4e-3, rel_l2(o, o2)
+
+
+@pytest.mark.parametrize("wgs", [1, 3, 0])
+@pytest.mark.parametrize("Tq,Tk,xview", [(1290, 150, False), (1290, 150, True), (1400, 64, False), (520, 17, True), (1290, 1283, False)])
+def test_attention3_persistent_items(dev, wgs, Tq, Tk, xview):
+    """attention3.hip is persistent: the workgroups of an XCD walk its (view, head, 128-query block) items, the K / V^T stream continues across
+    an item seam and an item's last step already multiplies the next item's first scores.  Forced here to ONE and to three workgroups per XCD
+    (every workgroup walks many items: 11 blocks x 8 heads per view) and left automatic; partial last tiles (scrub + mask), single-tile items
+    (Tk = 64: first tile = last tile; Tk = 17: one partial tile, two sources), a block whose waves 1-3 have no query (Tq = 1290: they sit the
+    item out and must rejoin the pipeline in the next one), a late score spike in a later item."""
+    B, heads, d = 11, 8, 40
+    Cc = heads * d
+    q = rnd(B, Tq, Cc, seed=1); k = rnd(B, Tk, Cc, seed=2); v = rnd(B, Tk, Cc, seed=3)
+    k[0, Tk - 1, :d] = q[0, Tq // 2, :d] * 6.0
+    k[9, 0, d:2 * d] = q[9, Tq - 1, d:2 * d] * 6.0
+    q, qref = prescale_q(q, d, True)
+    vt = torch.full((B, Cc, PK.round_up(Tk, 8)), float("nan"), dtype=BF, device=dev); vt[:, :, :Tk] = v.transpose(1, 2)
+    o = torch.full((B, Tq, Cc), float("nan"), dtype=BF, device=dev)
+    srcs = lambda i: [(i + 10) % B, (i + 1) % B]
+    kw = dict(kvmap=torch.tensor([j for i in range(B) for j in srcs(i)], dtype=torch.int32, device=dev), nsrc=2) if xview else {}
+    with L.options(ATTN3_WGS=wgs, ATTN2_RES=0):
+        O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=Tk, scale=d ** -0.5, q_prescaled=True, **kw)])
+        kern = (L.lib().mdx_last_kernel() or b"").decode()
+    torch.cuda.synchronize()
+    if not L.get_option("ATTN3"):
+        pytest.skip("ATTN3 off")
+    assert kern == f"attn3_kernel<40,{'xview' if xview else 'self'}>", kern
+    qc, kc, vc = qref.double().cpu(), k.double().cpu(), v.double().cpu()
+    if xview:
+        ref = torch.zeros(B, Tq, Cc, dtype=torch.float64)
+        for i in range(B):
+            for j in srcs(i):
+                ref[i] += ref_attention(qc[i:i + 1], kc[j:j + 1], vc[j:j + 1], heads, d ** -0.5)[0]
+    else:
+        ref = ref_attention(qc, kc, vc, heads, d ** -0.5)
+    close(o, ref, name=f"attn3 persistent wgs={wgs} {Tq},{Tk}{' xview' if xview else ''}")
 
 
 @pytest.mark.parametrize("pre", [False, True])
