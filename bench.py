@@ -201,9 +201,9 @@ def main():
     ap.add_argument("--scenes-per-gpu", type=int, default=192,
                     help="scenes sampled per rank per pipe() call (throughput grows with the batch — fewer partial rounds of tiles: 6.33 / 6.46 / 6.53 "
                          "scenes/s at 64 / 96 / 128 in round 2; round 4, two streams: 7.21 / 7.23 / 7.18 at 128 / 192 / 256; a 192-scene call takes 27 s)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("MDX_STREAMS", "2")),
+    ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams a pipe() call spreads its scenes over (pipeline.streams: contiguous scene chunks, one plan + hipGraph each, "
-                         "replayed concurrently; fills the tail / boundary gaps of whole-CU kernels)")
+                         "replayed concurrently; fills the tail / boundary gaps of whole-CU kernels); 0 = the library option STREAMS (csrc/options.h: 2)")
     ap.add_argument("--side-runs", action="store_true",
                     help="with --gpus > 1: also run the side measurements (configs[2], configs[3], VAE decode); by default a multi-GPU run does the "
                          "timed region only, so that N = 1, 2, 4, 8 back to back stay inside the driver's limit")
@@ -273,7 +273,8 @@ def main():
     else:
         pipe, unet, cn = build_pipeline(cfg, dev, args.scheduler, tdt)
     pipe.use_graph = not args.no_graph
-    pipe.streams = max(1, args.streams)
+    from magicdrive_amd import _lib as _L
+    pipe.streams = max(1, args.streams if args.streams > 0 else int(_L.get_option("STREAMS")) if hasattr(_L, "get_option") else 2)
     b = args.scenes_per_gpu
     n_total = b * world
     mine = DD.shard_scenes(n_total, rank, world)

@@ -52,6 +52,8 @@ namespace mdx {
     X(GN_TWO_STAGE, 1, "streaming two-stage GroupNorm for maps >= 32768 elements") \
     X(XL_PERSIST, 1, "256x256 XL GEMMs (plain / GEGLU, optional residual) on the persistent kernel gemm_xlp_kernel") \
     X(XL_RASTER, 2, "XL tile order: 0 row-major, 1 XCD-strided M-tiles, 2 XCD-blocked (M-group x N-group panels per XCD)") \
+    X(STREAMS, 2, "host side (pipeline): HIP streams a pipe() call spreads its scene chunks over (chunks of >= 16 scenes, one plan + hipGraph each)") \
+    X(PLAN_CACHE, 6, "host side (pipeline): sampler plans (captured graphs + buffers) kept per pipeline (LRU); a multi-stream call pins one plan per chunk") \
     X(LN_FUSE, 1, "MdxGemmDesc.ln_eps: 1 = gemm_ws.hip normalises the rows in-kernel, 0 = always normalise into ln_scratch first (A/B)")
 
 enum Opt : int {

@@ -49,12 +49,12 @@ class PlanCache:
     """Small LRU of plans keyed by batch geometry.  A plan owns a 64 MB workspace, its activation pool, K/V and temb tables and a
     captured hipGraph; the reference's validation flow changes the padded box count (and with it the plan key) almost every batch,
     so an unbounded dict would accumulate ~100 plans per batch size.  Evicted plans release their graph and device buffers.
-    Size: MDX_PLAN_CACHE (default 6: a multi-stream call holds one plan per scene chunk)."""
+    Size: the library option PLAN_CACHE (csrc/options.h, default 6: a multi-stream call holds one plan per scene chunk)."""
 
     def __init__(self, maxsize: Optional[int] = None):
-        import os
         from collections import OrderedDict
-        self.maxsize = maxsize if maxsize is not None else max(1, int(os.environ.get("MDX_PLAN_CACHE", "6")))
+        from . import _lib
+        self.maxsize = maxsize if maxsize is not None else max(1, int(_lib.get_option("PLAN_CACHE")))
         self._d = OrderedDict()
 
     def get(self, key):

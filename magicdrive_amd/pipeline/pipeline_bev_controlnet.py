@@ -23,6 +23,7 @@ from typing import Any, Callable, Dict, List, Optional, Union
 import numpy as np
 import torch
 
+from .. import _lib
 from ..denoiser import PlanCache, SamplerPlan, device_stream
 from ..schedulers import DDIMScheduler, UniPCMultistepScheduler
 
@@ -59,10 +60,10 @@ class StableDiffusionBEVControlNetPipeline:
         # the cache is a small LRU and an evicted plan releases its graph and buffers.
         self._plans = PlanCache()
         self.use_graph = True
-        # Scene chunks replayed concurrently on separate HIP streams (see __call__): MDX_STREAMS overrides; chunks hold at least
-        # `min_scenes_per_stream` scenes (below that a launch has too few tiles to fill the chip even alone).
-        # Measured on one box (profiles/r04_streams_ab.log, configs[1]): 128 scenes 7.02 -> 7.21 scenes/s, 192 scenes 7.14 -> 7.23.
-        self.streams = max(1, int(os.environ.get("MDX_STREAMS", "2")))
+        # Scene chunks replayed concurrently on separate HIP streams (see __call__): the library option STREAMS (csrc/options.h; `pipe.streams = n`
+        # overrides per pipeline); chunks hold at least `min_scenes_per_stream` scenes (below that a launch has too few tiles to fill the chip
+        # even alone).  Measured on one box (profiles/r04_streams_ab.log, configs[1]): 128 scenes 7.02 -> 7.21 scenes/s, 192 scenes 7.14 -> 7.23.
+        self.streams = None                                   # None: follow the option
         self.min_scenes_per_stream = 16
         self._side: Dict[Any, List[Any]] = {}
 
@@ -304,8 +305,11 @@ class StableDiffusionBEVControlNetPipeline:
         # fill those gaps with the other half's kernels (profiles/r04_streams_ab.log).  Callbacks need the whole
         # batch at a step boundary, so they keep the single-stream path.
         n_chunk = 1
-        if self.streams > 1 and callback is None and b >= 2 * self.min_scenes_per_stream:
-            n_chunk = min(int(self.streams), b // self.min_scenes_per_stream)
+        n_streams = max(1, int(self.streams if self.streams is not None else _lib.get_option("STREAMS")))
+        if n_streams > 1 and callback is None and b >= 2 * self.min_scenes_per_stream:
+            # every chunk's plan must stay cached for the whole call: the LRU evicts (and RELEASES) the oldest plan when it overflows, which
+            # with a cache smaller than the chunk count would be chunk 0's, still held in `plans` below
+            n_chunk = min(n_streams, b // self.min_scenes_per_stream, self._plans.maxsize)
         bounds = [(b * i) // n_chunk for i in range(n_chunk + 1)]
         c_halves = 2 if do_cfg else 1
 

@@ -63,6 +63,7 @@ XF_ATOL = {"bf16": 2e-2, "f16": 4e-3}      # xformers' own forward tolerances (t
 XF_RTOL = {"bf16": 5e-3, "f16": 4e-4}      # atol quoted at unit scale: scaled here by the output's mean magnitude
 
 
+REPORT_ONLY = False         # set by `pytest --parity-report` (tests/conftest.py): close() / check() record, do not assert; the session then fails by design
 DEFAULT_KIND = "bf16"       # tests/test_fp16_gpu.py re-runs the kernel tests with fp16 tensors and flips this to "f16"
 
 
@@ -72,8 +73,8 @@ def close(out, ref, rtol=None, atol_rel=None, name="", kind=None, max_rel_l2=Non
     the elements within tol, EVERY element within 1.5 tol, and the whole tensor within max_rel_l2.  Measured on MI355X over all 365
     kernel cases (profiles/r03_parity_measured.jsonl): worst element 1.21 tol (one attention case in 2.7 M elements; GEMM / conv / norm
     <= 0.78), nothing outside tol otherwise, rel L2 <= 2.7e-3 (a bf16 store alone is ~2.3e-3).
-    The measured numbers of every call go to the parity log (helpers.parity_log); MDX_CLOSE_REPORT=1 records without asserting."""
-    import os
+    The measured numbers of every call go to the parity log (helpers.parity_log); `pytest --parity-report` (tests/conftest.py) records
+    without asserting — and makes the session FAIL at the end, so a report run can never pass for a green one."""
     kind = kind or DEFAULT_KIND
     if max_rel_l2 is None:
         max_rel_l2 = 4e-3 if kind == "bf16" else 6e-4      # an fp16 store alone is ~2.8e-4 rel L2 (11-bit mantissa)
@@ -89,17 +90,16 @@ def close(out, ref, rtol=None, atol_rel=None, name="", kind=None, max_rel_l2=Non
     worst = (err / tol).max().item()
     rel = (err.pow(2).sum().sqrt() / (ref.pow(2).sum().sqrt() + 1e-12)).item()
     parity_log("close:" + name, kind=kind, rel_l2=rel, worst_err_over_tol=worst, frac_over_tol=bad, max_err=err.max().item(), scale=scale)
-    if os.environ.get("MDX_CLOSE_REPORT"):
+    if REPORT_ONLY:
         return
     assert bad <= 1e-4 and worst <= 1.5 and rel < max_rel_l2, f"{name}: frac_over_tol={bad:.2e} worst err/tol={worst:.2f} rel_l2={rel:.3e} max_err={err.max().item():.3e} scale={scale:.3e}"
 
 
 def check(name, value, limit):
     """assert value < limit, with the measured value recorded in the parity log (limits are <= 2x what MI355X measured: profiles/r03_parity_measured.jsonl)."""
-    import os
     value = float(value)
     parity_log("check:" + name, value=value, limit=limit)
-    if os.environ.get("MDX_CLOSE_REPORT"):
+    if REPORT_ONLY:
         assert value == value and value < 10 * limit, (name, value, limit)      # report mode still refuses garbage
         return
     assert value < limit, f"{name}: {value:.4e} >= {limit:.1e}"

@@ -490,3 +490,31 @@ def test_scene_chunk_rows_keep_cfg_halves_together():
     assert got[0].flatten().tolist() == [0, 1, 5, 6] and got[1].flatten().tolist() == [2, 3, 4, 7, 8, 9]
     src = __import__("inspect").getsource(StableDiffusionBEVControlNetPipeline.__call__)
     assert "t[hf * b + s0:hf * b + s1] for hf in range(c_halves)" in src
+
+
+def test_scene_chunks_never_outnumber_the_plan_cache():
+    """the multi-stream path keeps one plan per scene chunk for the whole call, and PlanCache.put RELEASES what it evicts — with
+    a cache smaller than the chunk count chunk 0's plan was released before it was launched.  The chunk count is clamped to the cache size;
+    the stream count and the cache size come from the library's option table (no environment reads in product code)."""
+    import inspect
+    from magicdrive_amd import _lib as L
+    from magicdrive_amd.denoiser import PlanCache
+    src = inspect.getsource(StableDiffusionBEVControlNetPipeline.__call__)
+    assert "self._plans.maxsize)" in src and "os.environ" not in src
+    assert "os.environ" not in inspect.getsource(StableDiffusionBEVControlNetPipeline.__init__)
+    assert "os.environ" not in inspect.getsource(PlanCache)
+    assert L.get_option("STREAMS") == 2 and L.get_option("PLAN_CACHE") == 6
+    with L.options(PLAN_CACHE=1):
+        c = PlanCache()
+        assert c.maxsize == 1
+
+        class P:
+            released = False
+
+            def release(self):
+                self.released = True
+        a, b_ = P(), P()
+        c.put("a", a); c.put("b", b_)
+        assert a.released and not b_.released and len(c) == 1
+        # the clamp of __call__: 64 scenes, 2 streams, 16 scenes per stream, cache of 1 -> one chunk
+        assert min(2, 64 // 16, c.maxsize) == 1
