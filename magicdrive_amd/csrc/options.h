@@ -54,6 +54,7 @@ namespace mdx {
     X(XL_RASTER, 2, "XL tile order: 0 row-major, 1 XCD-strided M-tiles, 2 XCD-blocked (M-group x N-group panels per XCD)") \
     X(STREAMS, 2, "host side (pipeline): HIP streams a pipe() call spreads its scene chunks over (chunks of >= 16 scenes, one plan + hipGraph each)") \
     X(PLAN_CACHE, 6, "host side (pipeline): sampler plans (captured graphs + buffers) kept per pipeline (LRU); a multi-stream call pins one plan per chunk") \
+    X(CHECK_TIMESTEPS, 0, "host side (schedulers): 1 = a device-resident timestep that is not in the scheduler's list raises (one sync per step) instead of poisoning the sample with NaN") \
     X(LN_FUSE, 1, "MdxGemmDesc.ln_eps: 1 = gemm_ws.hip normalises the rows in-kernel, 0 = always normalise into ln_scratch first (A/B)")
 
 enum Opt : int {

@@ -127,12 +127,17 @@ class DDIMScheduler:
             coef = self._table_dev[dev] = tab.to(dev)
         if isinstance(timestep, torch.Tensor) and timestep.is_cuda:
             # no host round trip: the row index is computed on the device (argmax of the match mask).  A timestep that is not in the list
-            # cannot raise without a sync: its row index becomes -1 and the kernel writes NaN (a loud miss; host timesteps below raise)
+            # cannot raise without a sync: its row index becomes -1 and the kernel writes NaN into the returned sample — on this path the NaN
+            # poison is the ONLY signal (a caller that never looks at the latents sees nothing; host timesteps below raise).  The library
+            # option CHECK_TIMESTEPS = 1 (csrc/options.h; a debugging aid: one device sync per step) turns the miss into a ValueError.
             ts_dev = self._table_dev.get(("timesteps", dev))
             if ts_dev is None:
                 ts_dev = self._table_dev[("timesteps", dev)] = self.timesteps.to(dev, torch.int64)
             hit = ts_dev == timestep.reshape(-1)[0].to(torch.int64)
             step = torch.where(hit.any(), hit.to(torch.int32).argmax(), torch.full((), -1, device=dev, dtype=torch.int64)).reshape(1).to(torch.int32)
+            from . import _lib
+            if _lib.get_option("CHECK_TIMESTEPS") and int(step.item()) < 0:
+                raise ValueError(f"timestep {int(timestep.reshape(-1)[0].item())} is not in this scheduler's timestep list")
         else:
             hits = (self.timesteps == int(timestep)).nonzero()
             if hits.numel() == 0:

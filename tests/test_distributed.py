@@ -125,3 +125,63 @@ def test_bench_two_ranks_gloo_prints_one_json_line(tmp_path):
     assert out["config"]["scenes_per_gpu"] == 3 and out["config"]["parallelism"] == "scene-sharded x2"
     assert out["value"] > 0 and abs(out["value"] - 6 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]      # whole-job scenes / max-over-ranks time
     assert out["config"]["full_cond_scenes_per_s"] is None and out["config"]["hires"] is None and "cpu_baseline" not in out
+
+
+def _run_sample_driver(tmp_path, world, out_name, extra=()):
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, os.path.join(root, "tests"), os.environ.get("PYTHONPATH", "")]),
+               CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS="2")
+    argv = [os.path.join(root, "tools", "sample.py"), "--ckpt", str(tmp_path / "ckpt"), "--sd15", str(tmp_path / "sd15"), "--data", str(tmp_path / "data"),
+            "--out", str(tmp_path / out_name), "--prompt-embeds", "--pipe-factory", "sample_stub:make", "--dist-backend", "gloo", "--device", "cpu",
+            "runner.validation_times=2", *extra]
+    if world == 1:
+        cmd = [sys.executable] + argv
+    else:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + argv
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return r
+
+
+def test_sample_driver_two_ranks_gloo(tmp_path):
+    """`torchrun tools/sample.py` = the reference's val_set_gen.py flow (perception/data_prepare/val_set_gen.py:71-161): batch j ->
+    rank j mod 2, generator seeded `seed + rank`, one all_gather_object per batch, every file written exactly once (by its rank, or — with
+    --gather-images — by rank 0), rank 0's index names rank and seed of every scene.  Five scenes in batches of two: rank 0 takes batches 0 and 2,
+    rank 1 batch 1 and an EMPTY third round (it still has to join the collective)."""
+    import json
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "sample_preprocess.pt"), weights_only=False)
+    os.makedirs(tmp_path / "data"); os.makedirs(tmp_path / "ckpt" / "hydra"); os.makedirs(tmp_path / "sd15")
+    for i, case in enumerate(gold["cases"]):
+        torch.save(case["sample"], tmp_path / "data" / f"tok{i}.pth")
+    with open(tmp_path / "ckpt" / "hydra" / "overrides.yaml", "w") as f:
+        f.write("- +exp=224x400\n- seed=7\n")
+    _run_sample_driver(tmp_path, 1, "one", ["--batch-size", "2"])
+    _run_sample_driver(tmp_path, 2, "two", ["--batch-size", "2"])
+    _run_sample_driver(tmp_path, 2, "two_gathered", ["--batch-size", "2", "--gather-images"])
+    names = {d: sorted(x for x in os.listdir(tmp_path / d) if x.endswith(".png")) for d in ("one", "two", "two_gathered")}
+    assert len(names["one"]) == 5 * 2 * 6 and names["one"] == names["two"] == names["two_gathered"]      # global scene index in the name: each file once
+    idx = {d: json.load(open(tmp_path / d / "index.json")) for d in names}
+    assert idx["one"]["world"] == 1 and idx["two"]["world"] == 2 and idx["two_gathered"]["gather_images"] is True
+    for d in ("two", "two_gathered"):
+        gens = idx[d]["generations"]
+        assert [(g["scene"], g["gen"]) for g in gens] == [(s, t) for s in range(5) for t in range(2)]
+        for g in gens:
+            want_rank = (g["scene"] // 2) % 2
+            assert g["rank"] == want_rank and g["seed"] == 7 + want_rank and len(g["files"]) == 6, g
+            assert all(os.path.exists(tmp_path / d / f) for f in g["files"])
+    assert all(g["rank"] == 0 and g["seed"] == 7 for g in idx["one"]["generations"])
+    # the pixels depend on the seed: rank 0's scenes are identical to the one-process run, rank 1's (seed 8) are not; both exchange modes agree
+    from PIL import Image
+    import numpy as np
+    px = lambda d, n: np.asarray(Image.open(tmp_path / d / n))
+    assert np.array_equal(px("one", "0_gen0_view3.png"), px("two", "0_gen0_view3.png"))
+    assert not np.array_equal(px("one", "2_gen0_view3.png"), px("two", "2_gen0_view3.png"))
+    for n in names["two"]:
+        assert np.array_equal(px("two", n), px("two_gathered", n)), n

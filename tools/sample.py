@@ -17,6 +17,17 @@ keys the sampling loop reads are resolved, in the reference's order (checkpoint 
   fix_seed_within_batch, runner.bbox_max_length.
 Without a text encoder in --sd15 the prompts cannot be embedded; pass --prompt-embeds to sample with zero embeddings (plumbing /
 throughput runs) instead of failing.
+
+Multi-GPU = the reference's FID generator flow (perception/data_prepare/val_set_gen.py:71-161), one process per GPU under torchrun:
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 tools/sample.py --ckpt ... --out ...
+
+batch j of the data goes to rank j mod N (what `accelerator.prepare(dataloader)` does, :79), every rank drives GPU LOCAL_RANK and seeds its
+generator with `seed + rank` (:83-87: `torch.manual_seed(cfg.seed + accelerator.process_index)`), nothing is exchanged inside the sampling loop, and
+per batch the ranks either write their own scenes' files and gather the labels on rank 0 (the reference's single-node branch, :147-150) or —
+`--gather-images`, its multi-node branch :141-146 — gather the uint8 images on rank 0, which writes everything.  File names carry the GLOBAL
+scene index, so a file is written exactly once whatever N is; rank 0 writes `index.json` (scene -> files, rank, seed) at the end
+(perception/common/ddp_utils.py:5-16: one all_gather_object per batch).
 """
 import argparse
 import os
@@ -77,12 +88,21 @@ def resolve_run_config(ckpt_dir: str, cli_overrides: Sequence[str]) -> Dict:
     return run
 
 
-def iter_pipe_kwargs(dataset, run: Dict, batch_size: int = 1, with_pixels: bool = False) -> Iterator[Dict]:
+def iter_batches_index(n: int, batch_size: int) -> Iterator[List[int]]:
+    """Sample indices of batch 0, 1, ... (the order of the reference's sequential val dataloader)."""
+    for i0 in range(0, n, batch_size):
+        yield list(range(i0, min(i0 + batch_size, n)))
+
+
+def iter_pipe_kwargs(dataset, run: Dict, batch_size: int = 1, with_pixels: bool = False, only=None) -> Iterator[Dict]:
     """Batches of samples -> keyword arguments of StableDiffusionBEVControlNetPipeline.__call__, as run_one_batch /
-    run_one_batch_pipe assemble them (magicdrive/misc/test_utils.py:191-255, :258-330).  with_pixels: (kwargs, pixel_values) pairs."""
+    run_one_batch_pipe assemble them (magicdrive/misc/test_utils.py:191-255, :258-330).  with_pixels: (kwargs, pixel_values) pairs.
+    only: the batch indices to produce (a rank's share: rank_batches)."""
     from magicdrive_amd.dataset import collate_samples, preprocess_fn
     extra = {k: v for k, v in run.items() if k not in DEFAULTS or k in ("guidance_scale", "num_inference_steps")}
-    for i0 in range(0, len(dataset), batch_size):
+    for j, i0 in enumerate(range(0, len(dataset), batch_size)):
+        if only is not None and j not in only:                       # another rank's batch: not even loaded
+            continue
         batch = collate_samples([preprocess_fn(dataset[i]) for i in range(i0, min(i0 + batch_size, len(dataset)))])
         kw = dict(prompt=batch["captions"], image=batch["bev_map_with_aux"], camera_param=batch["camera_param"],
                   height=run["image_size"][0], width=run["image_size"][1], bev_controlnet_kwargs=batch["kwargs"],
@@ -136,6 +156,59 @@ def build_pipe(ckpt: str, sd15: str, scheduler: str, device, given_view: bool = 
     return pipe.to(device)
 
 
+def rank_batches(n_batches: int, rank: int, world: int) -> List[int]:
+    """Batch indices of this rank: j -> rank j mod world (accelerate's dataloader sharding, val_set_gen.py:79)."""
+    return list(range(rank, n_batches, world))
+
+
+def rank_seed(seed, rank: int, world: int):
+    """val_set_gen.py:83-87: `cfg.seed + accelerator.process_index`; one process: the seed itself (tools/test.py)."""
+    return None if seed is None else (int(seed) + rank if world > 1 else int(seed))
+
+
+def save_views(out_dir: str, scene: int, gen: int, views) -> List[str]:
+    """One scene's views of one generation -> <scene>_gen<gen>_view<v>.png; `views`: PIL images or uint8 HxWx3 arrays.  Returns the file names."""
+    names = []
+    for vi, im in enumerate(views):
+        if not hasattr(im, "save"):
+            from PIL import Image
+            import numpy as np
+            im = Image.fromarray(np.asarray(im, dtype="uint8"))
+        name = f"{scene}_gen{gen}_view{vi}.png"
+        im.save(os.path.join(out_dir, name))
+        names.append(name)
+    return names
+
+
+def exchange_batch(records: List[Dict], images, rank: int, world: int, gather_images: bool, out_dir: str) -> List[Dict]:
+    """End of a batch on every rank (val_set_gen.py:137-151).  records: this rank's [{scene, gen, rank, seed}], images: the matching
+    [views] lists.  Single-node branch: the rank writes its own files, then the labels are gathered; multi-node branch (gather_images): labels
+    AND uint8 images are gathered and rank 0 writes.  Returns the records with their file names — on rank 0 those of every rank, elsewhere []
+    (ddp_utils.concat_from_everyone).  One all_gather_object per batch; ranks whose shard ran out contribute an empty list."""
+    import numpy as np
+    import torch.distributed as dist
+    if not gather_images:
+        for r_, views in zip(records, images):
+            r_["files"] = save_views(out_dir, r_["scene"], r_["gen"], views)
+        payload = records
+    else:
+        payload = [dict(r_, pixels=[np.asarray(v, dtype="uint8") for v in views]) for r_, views in zip(records, images)]
+    if world == 1:
+        gathered = [payload]
+    else:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, payload)
+    if rank != 0:
+        return []
+    out = []
+    for part in gathered:
+        for r_ in part:
+            if gather_images:
+                r_["files"] = save_views(out_dir, r_["scene"], r_["gen"], r_.pop("pixels"))
+            out.append(r_)
+    return out
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--ckpt", required=True); ap.add_argument("--sd15", required=True)
@@ -143,51 +216,78 @@ def main(argv=None):
     ap.add_argument("--scheduler", choices=["unipc", "ddim"], default="unipc")
     ap.add_argument("--batch-size", type=int, default=1)
     ap.add_argument("--prompt-embeds", action="store_true", help="no text encoder available: sample with zero prompt embeddings")
-    ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--device", default=None, help="default: cuda:<LOCAL_RANK>")
+    ap.add_argument("--gather-images", action="store_true", help="multi-rank: rank 0 writes every file from gathered uint8 images (the reference's multi-node branch); "
+                                                                 "default: each rank writes its own scenes, labels are gathered (its single-node branch)")
+    ap.add_argument("--pipe-factory", default="", help="TESTS: module:function(ckpt, sd15, scheduler, device, given_view) returning the pipeline instead of build_pipe")
+    ap.add_argument("--dist-backend", default=None, help="torch.distributed backend under torchrun (default: nccl = RCCL with a GPU, else gloo)")
     ap.add_argument("--reseed-per-run", action="store_true", help="deviation from the reference: an independent seed per (batch, validation run)")
     ap.add_argument("--cond-on-view", action="store_true", help="demo/run_cond_on_view.py: generation ti is sampled with the encoded ground-truth view ti given")
     ap.add_argument("overrides", nargs="*")
     a = ap.parse_args(argv)
     from magicdrive_amd.dataset import FolderSet
+    from magicdrive_amd import distributed as DD
+    import json
+    rank, world, local = DD.init_from_env(backend=a.dist_backend)
+    device = a.device or (f"cuda:{local}" if torch.cuda.is_available() else "cpu")
     run = resolve_run_config(a.ckpt, a.overrides)
-    pipe = build_pipe(a.ckpt, a.sd15, a.scheduler, a.device, given_view=a.cond_on_view)
+    if a.pipe_factory:
+        import importlib
+        mod, fn = a.pipe_factory.split(":")
+        pipe = getattr(importlib.import_module(mod), fn)(a.ckpt, a.sd15, a.scheduler, device, a.cond_on_view)
+    else:
+        pipe = build_pipe(a.ckpt, a.sd15, a.scheduler, device, given_view=a.cond_on_view)
     data = FolderSet(a.data)
-    os.makedirs(a.out, exist_ok=True)
-    total = 0
-    for item in iter_pipe_kwargs(data, run, a.batch_size, with_pixels=a.cond_on_view):
-        kw, pixel_values = item if a.cond_on_view else (item, None)
-        bs = kw["image"].shape[0]
-        if pipe.text_encoder is None:
-            if not a.prompt_embeds:
-                raise SystemExit(f"{a.sd15} has no text_encoder/: pass --prompt-embeds to sample with zero embeddings")
-            D = pipe.unet.cfg["cross_attention_dim"]
-            kw.update(prompt=None, prompt_embeds=torch.zeros(bs, 77, D), negative_prompt_embeds=torch.zeros(bs, 77, D))
-        # Seeding as the reference entry point does it (tools/test.py passes no global_generator, so run_one_batch_pipe,
-        # magicdrive/misc/test_utils.py:221-237, builds torch.manual_seed(cfg.seed) ONCE per batch, before the validation_times loop: its
-        # state carries across the iterations; with fix_seed_within_batch every scene of the batch gets that same generator object) —
-        # the same seed reproduces the reference's initial latents.  --reseed-per-run (a deviation) draws a fresh seed per (batch, run).
-        if run["seed"] is None:
-            base_gen = None
-        else:
-            base_gen = torch.Generator().manual_seed(run["seed"])
-        if a.cond_on_view:
-            for ti, images in cond_on_view_runs(pipe, kw, pixel_values, run, generator=base_gen):
-                for bi, views in enumerate(images):
-                    for vi, im in enumerate(views):
-                        im.save(os.path.join(a.out, f"{total + bi}_gen{ti}_view{vi}.png"))
-            total += bs
-            continue
-        for ti in range(run["validation_times"]):
-            g = base_gen
-            if a.reseed_per_run and base_gen is not None:
-                g = torch.Generator().manual_seed(int(torch.randint(0x7ffffffffffffff0, [1], generator=base_gen)))
-            gen = None if g is None else ([g] * bs if run["fix_seed_within_batch"] else g)
-            images = pipe(generator=gen, **kw).images                      # List[List[PIL]]: scene x view
-            for bi, views in enumerate(images):
-                for vi, im in enumerate(views):
-                    im.save(os.path.join(a.out, f"{total + bi}_gen{ti}_view{vi}.png"))
-        total += bs
-    print(f"sampled {total} scenes x {run['validation_times'] - (1 if a.cond_on_view else 0)} -> {a.out}")
+    if rank == 0:
+        os.makedirs(a.out, exist_ok=True)
+    DD.barrier()
+    seed = rank_seed(run["seed"], rank, world)
+    batches = list(iter_batches_index(len(data), a.batch_size))
+    mine = set(rank_batches(len(batches), rank, world))
+    n_rounds = (len(batches) + world - 1) // world                  # every rank takes part in every per-batch exchange (a collective)
+    index: List[Dict] = []
+    n_local = 0
+    it = iter_pipe_kwargs(data, run, a.batch_size, with_pixels=a.cond_on_view, only=mine)
+    for rnd in range(n_rounds):
+        j = rnd * world + rank
+        records, images_out = [], []
+        if j < len(batches):
+            item = next(it)
+            kw, pixel_values = item if a.cond_on_view else (item, None)
+            bs = kw["image"].shape[0]
+            scene0 = batches[j][0]
+            if getattr(pipe, "text_encoder", None) is None:
+                if not a.prompt_embeds:
+                    raise SystemExit(f"{a.sd15} has no text_encoder/: pass --prompt-embeds to sample with zero embeddings")
+                D = pipe.unet.cfg["cross_attention_dim"]
+                kw.update(prompt=None, prompt_embeds=torch.zeros(bs, 77, D), negative_prompt_embeds=torch.zeros(bs, 77, D))
+            # Seeding as the reference entry point does it (tools/test.py passes no global_generator, so run_one_batch_pipe,
+            # magicdrive/misc/test_utils.py:221-237, builds torch.manual_seed(cfg.seed) ONCE per batch, before the validation_times loop: its
+            # state carries across the iterations; with fix_seed_within_batch every scene of the batch gets that same generator object) —
+            # the same seed reproduces the reference's initial latents; under torchrun the seed is `seed + rank` (val_set_gen.py:83-87).
+            # --reseed-per-run (a deviation) draws a fresh seed per (batch, run).
+            base_gen = None if seed is None else torch.Generator().manual_seed(seed)
+            if a.cond_on_view:
+                for ti, images in cond_on_view_runs(pipe, kw, pixel_values, run, generator=base_gen):
+                    for bi, views in enumerate(images):
+                        records.append(dict(scene=scene0 + bi, gen=ti, rank=rank, seed=seed)); images_out.append(views)
+            else:
+                for ti in range(run["validation_times"]):
+                    g = base_gen
+                    if a.reseed_per_run and base_gen is not None:
+                        g = torch.Generator().manual_seed(int(torch.randint(0x7ffffffffffffff0, [1], generator=base_gen)))
+                    gen = None if g is None else ([g] * bs if run["fix_seed_within_batch"] else g)
+                    images = pipe(generator=gen, **kw).images                      # List[List[PIL]]: scene x view
+                    for bi, views in enumerate(images):
+                        records.append(dict(scene=scene0 + bi, gen=ti, rank=rank, seed=seed)); images_out.append(views)
+            n_local += bs
+        index += exchange_batch(records, images_out, rank, world, a.gather_images, a.out)
+    if rank == 0:
+        index.sort(key=lambda r_: (r_["scene"], r_["gen"]))
+        with open(os.path.join(a.out, "index.json"), "w") as f:
+            json.dump(dict(world=world, seed=run["seed"], gather_images=bool(a.gather_images), generations=index), f, indent=1)
+        print(f"sampled {len(data)} scenes x {run['validation_times'] - (1 if a.cond_on_view else 0)} on {world} rank(s) -> {a.out}")
+    DD.shutdown()
 
 
 if __name__ == "__main__":
