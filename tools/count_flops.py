@@ -44,6 +44,13 @@ def main():
     print("HIP program, prologue      :", {k: round(v / 1e12, 4) for k, v in fp.items()})
     print(f"F_scene (50 steps, c=1) = {(50*fs['total']+fp['total'])/1e12:.2f} TF ; with CFG (c=2) = {(100*fs['total']+2*fp['total'])/1e12:.2f} TF")
     print(f"launches per step: {len(sp.step_ops)}  prologue: {len(sp.prologue_ops)}")
+    # the VAE decoder (diffusers AutoencoderKL.decode, vae.py:152-281: row a14) — once per scene, outside the denoising loop
+    from magicdrive_amd import vae as V
+    vcfg = spec.VAE_SD15_CONFIG
+    vsd = {k: torch.zeros(s_) for k, s_ in spec.vae_decoder_param_shapes(vcfg).items()}
+    vp = V.VaeDecodePlan(vcfg, PackedNet(vsd, dev), dev, 6, (28, 50))
+    fv = flops.program_flops(vp.ops)
+    print("VAE decode, per 6-view scene:", {k: round(v / 1e12, 4) for k, v in fv.items()}, f"launches: {len(vp.ops)}")
 
 
 if __name__ == "__main__":
