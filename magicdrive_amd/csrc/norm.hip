@@ -153,6 +153,7 @@ struct GN2Params {
     const bf16_t* X; bf16_t* Y; const float* gamma; const float* beta; float* part;   // part: [B][nchunk][G][3]
     int B, HW, C, G, PCH, nchunk; long ldx, ldy; float eps; int silu;
     int rev;      // statistics pass walks images and chunks in DEscending order (see mdx_groupnorm_bf16)
+    const float* stat;   // [B][G][2] (mean, rstd) from gn_finalize_kernel, or nullptr: the apply pass combines the chunk partials itself
 };
 
 constexpr int GN2_NT = 320;       // most threads per workgroup
@@ -224,11 +225,40 @@ __global__ __launch_bounds__(GN2_NT) void gn_stats_kernel(GN2Params p) {
     }
 }
 
+// Many chunks per image (few, large images: the VAE decoder's 6 x 224 x 400 maps split into ~620 chunks each): every apply workgroup combining all
+// of its image's partials itself is 620 dependent L2 round trips per workgroup — the VAE's GroupNorms ran at 0.27-0.46 TB/s, 10 of the
+// decoder's 17.6 ms (round 5, tools/vaeone.py).  Here ONE wave per (image, group) combines them once: lane l takes chunks l, l + 64, ... in
+// ascending order, then the 64 lane results are combined in a fixed tree (Chan) — deterministic — and (mean, rstd) go to a table.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* part, float* stat, int nchunk, int G, float eps) {
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    float na = 0.f, ma = 0.f, qa = 0.f;
+    const float* pp = part + ((long)b * nchunk * G + g) * 3;
+    for (int k = lane; k < nchunk; k += 64) {
+        const float nb = pp[(long)k * G * 3], mb = pp[(long)k * G * 3 + 1], qb = pp[(long)k * G * 3 + 2];
+        if (nb > 0.f) {
+            const float nn = na + nb, dl = mb - ma;
+            ma += dl * nb / nn; qa += qb + dl * dl * na * nb / nn; na = nn;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {                        // lane l absorbs lane l + o (the lower index keeps the result: a fixed order)
+        const float nb = __shfl_down(na, o, 64), mb = __shfl_down(ma, o, 64), qb = __shfl_down(qa, o, 64);
+        if (nb > 0.f) {
+            const float nn = na + nb, dl = mb - ma;
+            ma += dl * nb / nn; qa += qb + dl * dl * na * nb / nn; na = nn;
+        }
+    }
+    if (lane == 0) { stat[((long)b * G + g) * 2] = ma; stat[((long)b * G + g) * 2 + 1] = rsqrtf(qa / na + eps); }
+}
+
 template <int NCV>
 __global__ __launch_bounds__(GN2_NT) void gn_apply_kernel(GN2Params p) {
     __shared__ float gmean[256], grstd[256];
     const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    if (tid < p.G) {
+    if (tid < p.G && p.stat) {
+        gmean[tid] = p.stat[((long)b * p.G + tid) * 2];
+        grstd[tid] = p.stat[((long)b * p.G + tid) * 2 + 1];
+    } else if (tid < p.G) {
         float na = 0.f, ma = 0.f, qa = 0.f;
         const float* pp = p.part + ((long)b * p.nchunk * p.G + tid) * 3;
         for (int k = 0; k < p.nchunk; ++k) {
@@ -416,6 +446,7 @@ extern "C" int mdx_groupnorm_bf16(const MdxGroupNormDesc* d, void* stream) {
         // cached — the statistics pass walks the tensor from the end, and ends at the head, which is where the apply pass (ascending)
         // starts: both passes begin on cached lines instead of on the lines evicted longest ago.  GN_REVERSE = 0 restores ascending.
         q.rev = (int)opt(OPT_GN_REVERSE);
+        q.stat = nullptr;
         // chunks: about 4096 workgroups in the grid, at least GN2_U passes of the workgroup's rows each
         const int C8 = p.C / 8, rows = gn2_rows(C8);
         const int nt = C8 > GN2_NT ? GN2_NT : rows * C8;
@@ -426,12 +457,24 @@ extern "C" int mdx_groupnorm_bf16(const MdxGroupNormDesc* d, void* stream) {
         if (pch > p.HW) pch = p.HW;
         q.PCH = pch;
         q.nchunk = (p.HW + q.PCH - 1) / q.PCH;
-        if ((long)p.B * q.nchunk * p.G * 3 * (long)sizeof(float) <= d->ws_bytes) {
+        const long part_bytes = (long)p.B * q.nchunk * p.G * 3 * (long)sizeof(float);
+        if (part_bytes <= d->ws_bytes) {
             dim3 grid2(q.nchunk, p.B);
             if (C8 > GN2_NT) hipLaunchKernelGGL(gn_stats_kernel<2>, grid2, dim3(nt), 0, st, q);
             else hipLaunchKernelGGL(gn_stats_kernel<1>, grid2, dim3(nt), 0, st, q);
             int rc = check_launch("gn_stats_kernel", false);
             if (rc) return rc;
+            // more than GN_FINALIZE_CHUNKS chunks per image: combine the partials ONCE (gn_finalize_kernel) instead of in every apply workgroup
+            q.stat = nullptr;
+            const long stat_bytes = (long)p.B * p.G * 2 * (long)sizeof(float);
+            const long fin = opt(OPT_GN_FINALIZE_CHUNKS);
+            if (fin > 0 && q.nchunk > fin && part_bytes + stat_bytes <= d->ws_bytes) {
+                float* stat = (float*)((char*)d->ws + part_bytes);
+                hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.G, p.B), dim3(64), 0, st, q.part, stat, q.nchunk, p.G, p.eps);
+                rc = check_launch("gn_finalize_kernel", false);
+                if (rc) return rc;
+                q.stat = stat;
+            }
             if (C8 > GN2_NT) hipLaunchKernelGGL(gn_apply_kernel<2>, grid2, dim3(nt), 0, st, q);
             else hipLaunchKernelGGL(gn_apply_kernel<1>, grid2, dim3(nt), 0, st, q);
             return check_launch("gn_stats_kernel+gn_apply_kernel");

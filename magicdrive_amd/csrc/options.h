@@ -49,6 +49,7 @@ namespace mdx {
     X(XL_TIMING, 0, "per-workgroup s_memtime stamps into the op workspace") \
     X(XL_SCHED, 0, "XL main-loop schedule variant 0..3 (0 = four quadrant phases)") \
     X(GN_REVERSE, 1, "two-stage GroupNorm: statistics pass reads the tensor back to front (Infinity-Cache reuse between producer / passes)") \
+    X(GN_FINALIZE_CHUNKS, 16, "two-stage GroupNorm: with more chunks per image than this the chunk partials are combined once by gn_finalize_kernel (0 = always in the apply pass)") \
     X(GN_TWO_STAGE, 1, "streaming two-stage GroupNorm for maps >= 32768 elements") \
     X(XL_PERSIST, 1, "256x256 XL GEMMs (plain / GEGLU, optional residual) on the persistent kernel gemm_xlp_kernel") \
     X(XL_RASTER, 2, "XL tile order: 0 row-major, 1 XCD-strided M-tiles, 2 XCD-blocked (M-group x N-group panels per XCD)") \

@@ -456,6 +456,28 @@ def test_groupnorm(dev, B, HW, Cc, G, silu, eps):
     close(y2, ref.transpose(1, 2), name="groupnorm two-stage")
 
 
+@pytest.mark.parametrize("B,HW,Cc", [(6, 89600, 128), (3, 22400, 256), (2, 5600, 512)])
+def test_groupnorm_many_chunks_finalize(dev, B, HW, Cc):
+    """Few large images (the VAE decoder's maps): hundreds of chunks per image — the chunk partials are combined ONCE by gn_finalize_kernel (a fixed
+    lane tree) instead of by every apply workgroup.  Against torch, bit-identical across two runs, and the same route with the finalize step
+    switched off agrees to rounding."""
+    G = 32
+    x = (rnd(B, HW, Cc, seed=1).float() * 1.5 + 0.4).to(BF)
+    gam = rnd(Cc, seed=2, dtype=torch.float32); bet = rnd(Cc, seed=3, dtype=torch.float32)
+    ws = ws_buf(dev, 4)
+    ys = []
+    for opts in ({}, {}, {"GN_FINALIZE_CHUNKS": 0}):
+        y = torch.zeros_like(x)
+        with L.options(**opts):
+            O.run_ops([O.GroupNorm(x, y, gam, bet, groups=G, eps=1e-6, silu=True, ws=ws)])
+        torch.cuda.synchronize()
+        ys.append(y)
+    ref = F.silu(F.group_norm(x.float().cpu().transpose(1, 2), G, gam.cpu(), bet.cpu(), 1e-6)).transpose(1, 2)
+    close(ys[0], ref, name=f"groupnorm finalize {B}x{HW}x{Cc}")
+    assert torch.equal(ys[0], ys[1]), "not deterministic"
+    assert rel_l2(ys[0], ys[2]) < 3e-3
+
+
 def test_groupnorm_channel_slice_view(dev):
     big = rnd(2, 50, 96, seed=1)
     x = big[:, :, 32:96]
