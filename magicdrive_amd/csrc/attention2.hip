@@ -26,6 +26,7 @@
 #include "options.h"
 #include "xl_layout.h"
 #include "attn2.h"
+#include "attn3_layout.h"
 
 namespace mdx {
 
@@ -108,13 +109,20 @@ constexpr float A2_DEFER = 4.0f;   // log2 units: the running max is only raised
 // With one workgroup per (view, head, 128-query block) that launch spent more than half of its time on per-workgroup fixed cost (zeroing
 // the LDS image, the DMA round trip of two tiles, launch / drain): 168 TFLOP/s.  Here ONE workgroup per (view, head) stages all
 // ntile <= A2_RING tiles once and then walks the query blocks: no DMA, no barrier and no vmcnt wait inside the walk.
-template <int D8, bool TWO, int QT, bool FOLD, bool RES = false>
+// PF (round 5): "permute-free" P — O^T += V^T P^T on 32x32x16 MFMAs like S^T = K Q^T, with the K fragment of lane (i, h) reading K row swap23(i)
+// of its 32-kv sub-tile (attn3_layout.h; replayed on the host by tests/attn3_layout_check.cpp): the 16 scores a lane receives for its query are
+// then, in register order, the two 8-wide B operands the PV MFMAs want from that very lane.  Gone: the 16 v_permlane swaps per tile (a fifth
+// of the VALU issue time of a kernel that is VALU-bound) and the cross-lane fetch of alpha in the rescale (O lives in the lane of its query);
+// the price: the head dim pads to two 32-row tiles (rows 48..63 alias a zero row of the 48-row V^T tile), 8 MFMAs of 32 cycles per tile instead
+// of 12 of 16.  The same idea as attention3.hip, without its software pipeline (which did not pay: DESIGN.md section 6).
+template <int D8, bool TWO, int QT, bool FOLD, bool RES = false, bool PF = false>
 #ifndef A2_LB4_TWO
 #define A2_LB4_TWO 1       // 4 waves per SIMD also for the 32-query cross-view form (128 VGPRs, 9 spilled outside the tile loop): 4147-4215 us vs 4238 at
                            // 3 waves and 4253 with 64-query waves (576 views, profiles/r04_attn_xview_lb4_ab.log); -DA2_LB4_TWO=0 restores 3 waves
 #endif
-__global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : ((RES || (A2_LB4_TWO && TWO)) ? 4 : 3)) void attn2_kernel(Attn2Params p) {
+__global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : ((RES || (A2_LB4_TWO && TWO && !PF)) ? 4 : 3)) void attn2_kernel(Attn2Params p) {
     static_assert(!RES || (!TWO && QT == 1), "resident K / V^T: one kv source, 32-query waves");
+    static_assert(!PF || (QT == 1 && D8 == 5 && !RES), "permute-free P: head dim 40, 32-query waves, streaming form");
     constexpr int D = D8 * 8;
     static_assert(!FOLD || (D % 16) == 8, "FOLD needs the 8 spare k slots of a head dim that is 8 mod 16");
     constexpr int D16 = (D + 15) / 16;             // QK k-steps of 16 and PV row tiles of 16
@@ -255,7 +263,22 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : ((RES || (A2_LB4_T
     // ---- fragment read offsets ----
     int k_rd[2];                                               // S^T sub-tile s: K rows s * 32 + col, this half's 16 bytes of k-step 0
 #pragma unroll
-    for (int s = 0; s < 2; ++s) k_rd[s] = (s * 32 + col) * KROW + half * 16;
+    for (int s = 0; s < 2; ++s) k_rd[s] = (s * 32 + (PF ? mdx_a3::k_row(lane) : col)) * KROW + half * 16;
+    // PF: V^T fragments of the 32x32x16 PV MFMAs: row tile 0 = rows col, (s, t) = st >> 1, st & 1; row tile 1 = rows 32 + col — only 32..47 exist
+    // in the 48-row tile (40 = the ones row, 41..47 zero): the lanes of rows 48..63 all read zero row 47
+    int vpf[PF ? 2 : 1][PF ? 4 : 1];
+    if (PF) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            vpf[0][PF ? st : 0] = K_BYTES + PAD_TAIL + mdx_a3::vt_off(0, st >> 1, st & 1, lane);
+            vpf[PF ? 1 : 0][PF ? st : 0] = col < 16 ? K_BYTES + PAD_TAIL + mdx_a3::vt_off(1, st >> 1, st & 1, lane) : K_BYTES + PAD_TAIL + 47 * 128;
+        }
+    }
+    f32x16_t oaccp[PF ? 2 : 1];                                  // PF: O^T rows 32 rt + acc_row(r, lane) of query `col`
+#pragma unroll
+    for (int rt = 0; rt < (PF ? 2 : 1); ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oaccp[rt][r] = 0.f;
     const int v_rd0 = K_BYTES + PAD_TAIL + mdx_xl::frag_off(0, lane, 0), v_rd1 = K_BYTES + PAD_TAIL + mdx_xl::frag_off(0, lane, 1);
 
     f32x4_t oacc[QT][D16][2];
@@ -376,6 +399,74 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : ((RES || (A2_LB4_T
                 }                                                                                                      \
             }                                                                                                          \
             if (!ONES) l_run[qt] = l_run[qt] * alpha + psum;                                                           \
+        }                                                                                                              \
+    }
+    // The permute-free tile (PF; one 32-query tile per wave): scores as in A2_TILE (K rows permuted), online softmax with the rescale lane-local,
+    // then per 32-kv sub-tile and k-step the packed probabilities ARE the B operand of two 32x32x16 PV MFMAs.
+#define A2_TILE_PF(LAST, slot_, j0_, FIRST_)                                                                           \
+    {                                                                                                                  \
+        const unsigned char* sb_ = smem + (slot_) * BUF;                                                               \
+        Frag8 kf_[2][D16];                                                                                             \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                  \
+            _Pragma("unroll") for (int ks = 0; ks < D16; ++ks) kf_[s][ks].u = *(const uint4*)(sb_ + k_rd[s] + ks * 32); \
+        if (FOLD) {                                                                                                    \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                            \
+                kf_[s][D16 - 1].u.x = half ? one_slot : kf_[s][D16 - 1].u.x; kf_[s][D16 - 1].u.y = half ? 0u : kf_[s][D16 - 1].u.y; \
+                kf_[s][D16 - 1].u.z = half ? 0u : kf_[s][D16 - 1].u.z; kf_[s][D16 - 1].u.w = half ? 0u : kf_[s][D16 - 1].u.w; \
+            }                                                                                                          \
+        }                                                                                                              \
+        f32x16_t sacc[2];                                                                                              \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                                \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) sacc[s][r] = 0.f;                                           \
+            _Pragma("unroll") for (int ks = 0; ks < D16; ++ks) sacc[s] = MDX_MFMA_32x32x16(kf_[s][ks].v, qf[0][ks].v, sacc[s]); \
+        }                                                                                                              \
+        if (LAST) {                                                                                                    \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                              \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                         \
+                    if ((j0_) + s * 32 + mdx_a3::s_kv(r, lane) >= p.Tk) sacc[s][r] = -INFINITY;                        \
+        }                                                                                                              \
+        float mx = -INFINITY;                                                                                          \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                  \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[s][r]);                                 \
+        {                                                                                                              \
+            const unsigned mu_ = __float_as_uint(mx);                                                                  \
+            auto sw_ = __builtin_amdgcn_permlane32_swap(mu_, mu_, false, false);                                       \
+            mx = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                                              \
+            if (!FOLD) mx *= p.scale_log2;                                                                             \
+        }                                                                                                              \
+        if (FOLD) {                                                                                                    \
+            if ((FIRST_) || __builtin_amdgcn_ballot_w64(mx > A2_DEFER) != 0) {                                         \
+                const float inc_ = (FIRST_) ? mx : fmaxf(mx, 0.f);                                                     \
+                const float m_new = bf2f((bf16_t)(pack2bf(m_run[0] + inc_, 0.f) & 0xffffu));                           \
+                const float delta_ = m_new - m_run[0];                                                                 \
+                const float alpha_ = (FIRST_) ? 0.f : __builtin_amdgcn_exp2f(-delta_);                                 \
+                m_run[0] = m_new;                                                                                      \
+                if (half) qf[0][D16 - 1].u.x = pack2bf(-m_new, 0.f);                                                   \
+                _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                          \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) sacc[s][r] -= delta_;                               \
+                _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                                       \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(oaccp[PF ? rt : 0][r]) : "v"(alpha_)); \
+            }                                                                                                          \
+        } else if (__builtin_amdgcn_ballot_w64(mx > m_run[0] + A2_DEFER) != 0) {                                       \
+            const float m_new = fmaxf(m_run[0], mx);                                                                   \
+            const float alpha_ = __builtin_amdgcn_exp2f(m_run[0] - m_new);                                             \
+            m_run[0] = m_new;                                                                                          \
+            _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                                           \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(oaccp[PF ? rt : 0][r]) : "v"(alpha_)); \
+        }                                                                                                              \
+        const float mneg_ = -m_run[0];                                                                                 \
+        _Pragma("unroll") for (int st = 0; st < 4; ++st) {                                                             \
+            Frag8 b_, v0_, v1_;                                                                                        \
+            v0_.u = *(const uint4*)(sb_ + vpf[0][PF ? st : 0]); v1_.u = *(const uint4*)(sb_ + vpf[PF ? 1 : 0][PF ? st : 0]); \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                            \
+                float p0 = sacc[st >> 1][8 * (st & 1) + 2 * u], p1 = sacc[st >> 1][8 * (st & 1) + 2 * u + 1];          \
+                if (!FOLD) { p0 = __builtin_fmaf(p0, p.scale_log2, mneg_); p1 = __builtin_fmaf(p1, p.scale_log2, mneg_); } \
+                p0 = __builtin_amdgcn_exp2f(p0); p1 = __builtin_amdgcn_exp2f(p1);                                      \
+                const unsigned pk_ = pack2bf(p0, p1);                                                                  \
+                if (u == 0) b_.u.x = pk_; if (u == 1) b_.u.y = pk_; if (u == 2) b_.u.z = pk_; if (u == 3) b_.u.w = pk_; \
+            }                                                                                                          \
+            oaccp[0] = MDX_MFMA_32x32x16(v0_.v, b_.v, oaccp[0]);                                                       \
+            oaccp[PF ? 1 : 0] = MDX_MFMA_32x32x16(v1_.v, b_.v, oaccp[PF ? 1 : 0]);                                      \
         }                                                                                                              \
     }
     if constexpr (RES) {
@@ -499,7 +590,7 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : ((RES || (A2_LB4_T
     {                                                                                                                  \
         for (int t = 0; t < nfull; ++t) {                                                                              \
             tile_sync();                                                                                               \
-            A2_TILE(false, NQ_, slot, t * A2_KV, fresh, 2)                                                                \
+            if constexpr (PF) { if (NQ_) A2_TILE_PF(false, slot, t * A2_KV, fresh) } else A2_TILE(false, NQ_, slot, t * A2_KV, fresh, 2)   \
             tile_done();                                                                                               \
         }                                                                                                              \
         if (nfull < ntile) {                                                                                           \
@@ -514,17 +605,52 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : ((RES || (A2_LB4_T
                 }                                                                                                      \
                 __syncthreads();                                                                                       \
             }                                                                                                          \
-            A2_TILE(true, NQ_, slot, nfull * A2_KV, fresh, 2)                                                          \
+            if constexpr (PF) { if (NQ_) A2_TILE_PF(true, slot, nfull * A2_KV, fresh) } else A2_TILE(true, NQ_, slot, nfull * A2_KV, fresh, 2) \
             tile_done();                                                                                               \
         }                                                                                                              \
     }
 
     for (int src = 0; src < p.nsrc; ++src) {
-        if (QT == 2 && nact == 2) A2_SOURCE((QT == 2 ? 2 : 1))
+        if (QT == 2 && nact == 2) A2_SOURCE(QT)
         else if (nact >= 1) A2_SOURCE(1)
         else A2_SOURCE(0)
         // ---- end of a source: normalise, accumulate (cross-view), reset.  joint: the sources are one kv sequence — only after the last ----
         if (p.joint && src + 1 < p.nsrc) continue;
+        if constexpr (PF) {
+            // row 40 of O^T = sum of the (16-bit) probabilities: row tile 1, local row 8 -> register 4 of the lower half lanes
+            const float inv = 1.0f / __shfl(oaccp[PF ? 1 : 0][4], col, 64);
+            if (TWO && src == 0) {                                // first neighbour done: park it (packed), restart the accumulators
+#pragma unroll
+                for (int u = 0; u < 8; ++u) osum[0][u >> 2][(u >> 1) & 1][u & 1] = pack2bf(oaccp[0][2 * u] * inv, oaccp[0][2 * u + 1] * inv);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) osum[0][TWO ? 2 : 0][0][u] = pack2bf(oaccp[PF ? 1 : 0][2 * u] * inv, oaccp[PF ? 1 : 0][2 * u + 1] * inv);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oaccp[PF ? rt : 0][r] = 0.f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oaccp[0][r] *= inv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oaccp[PF ? 1 : 0][r] *= inv;
+                if (TWO) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const unsigned w = osum[0][u >> 2][(u >> 1) & 1][u & 1];
+                        oaccp[0][2 * u] += bf2f((bf16_t)(w & 0xffffu)); oaccp[0][2 * u + 1] += bf2f((bf16_t)(w >> 16));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const unsigned w = osum[0][TWO ? 2 : 0][0][u];
+                        oaccp[PF ? 1 : 0][2 * u] += bf2f((bf16_t)(w & 0xffffu)); oaccp[PF ? 1 : 0][2 * u + 1] += bf2f((bf16_t)(w >> 16));
+                    }
+                }
+            }
+            m_run[0] = FOLD ? 0.f : -INFINITY;
+            if (FOLD && half) qf[0][D16 - 1].u.x = 0u;
+            fresh = 1;
+            continue;
+        }
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             float inv0, inv1;
@@ -566,6 +692,25 @@ __global__ __launch_bounds__(A2_NT, (QT == 2 || D8 > 5) ? 2 : ((RES || (A2_LB4_T
 #undef A2_TILE
     a2_wait_vmcnt<0>();
 
+    if constexpr (PF) {
+        // ---- store O[q][h * 40 + d]: lane (q, half) holds d = 8 u + 4 half + {0..3} of row tile 0 (u = 0..3) and d = 32 + 4 half + {0..3} ----
+        const int qq = q0w + col;
+        if (qq < p.Tq) {
+            bf16_t* op = p.O + (long)b * p.sO + (long)qq * p.ldo + (long)h * D + 4 * half;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                uint2 ov;
+                ov.x = pack2bf(oaccp[0][4 * u], oaccp[0][4 * u + 1]);
+                ov.y = pack2bf(oaccp[0][4 * u + 2], oaccp[0][4 * u + 3]);
+                *(uint2*)(op + 8 * u) = ov;
+            }
+            uint2 ov;
+            ov.x = pack2bf(oaccp[PF ? 1 : 0][0], oaccp[PF ? 1 : 0][1]);
+            ov.y = pack2bf(oaccp[PF ? 1 : 0][2], oaccp[PF ? 1 : 0][3]);
+            *(uint2*)(op + 32) = ov;
+        }
+        return;
+    }
     // ---- store O[q][h * d + dd]: 16x16 layout: lane -> query 16 t + (lane & 15), rows dd = 16 i + 4 (lane >> 4) + e ----
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
@@ -601,17 +746,17 @@ static int launch_attn2_res(const Attn2Params& p, hipStream_t st) {
     return check_launch(tag);
 }
 
-template <int D8, int QT, bool FOLD>
+template <int D8, int QT, bool FOLD, bool PF = false>
 static int launch_attn2_d(const Attn2Params& p, hipStream_t st) {
     Attn2Params q = p;
     q.qblocks = (p.Tq + A2_NW * 32 * QT - 1) / (A2_NW * 32 * QT);
     q.viewmap = opt(OPT_ATTN2_VIEWMAP) != 0;
     const dim3 grid(q.viewmap ? (unsigned)(((long)p.B + 7) / 8 * 8 * p.H * q.qblocks) : (unsigned)(((long)p.B * p.H + 7) / 8 * 8 * q.qblocks), 1, 1);
     const bool two = p.nsrc == 2 && !p.joint;                   // TWO = the summed two-neighbour form; everything else is one softmax over nsrc sources
-    if (two) hipLaunchKernelGGL((attn2_kernel<D8, true, QT, FOLD>), grid, dim3(A2_NT), 0, st, q);
-    else hipLaunchKernelGGL((attn2_kernel<D8, false, QT, FOLD>), grid, dim3(A2_NT), 0, st, q);
+    if (two) hipLaunchKernelGGL((attn2_kernel<D8, true, QT, FOLD, false, PF>), grid, dim3(A2_NT), 0, st, q);
+    else hipLaunchKernelGGL((attn2_kernel<D8, false, QT, FOLD, false, PF>), grid, dim3(A2_NT), 0, st, q);
     char tag[64];
-    snprintf(tag, sizeof tag, "attn2_kernel<%d,%s,q%d%s>", D8 * 8, two ? "xview" : (p.nsrc > 1 ? "joint" : "self"), 32 * QT, FOLD ? ",fold" : "");
+    snprintf(tag, sizeof tag, "attn2_kernel<%d,%s,q%d%s%s>", D8 * 8, two ? "xview" : (p.nsrc > 1 ? "joint" : "self"), 32 * QT, FOLD ? ",fold" : "", PF ? ",pf" : "");
     return check_launch(tag);
 }
 
@@ -650,6 +795,7 @@ int launch_attn2(const Attn2Params& p, hipStream_t st) {
         // is the faster one for one kv source (768 views, T = 1400: self 3157 vs 3332 us, text context 640 vs 795 us; the two-source
         // cross-view form is equal, 5888 vs 5882 us: profiles/r03_attn_qt_fold_ab.log); ATTN2_QT = 2 keeps 64-query waves everywhere.
         // round 4: with the straight-line issue path and four waves per SIMD the 32-query form also wins (by 1-2.5 %) for the two-source launches
+        if (fold && !(two && qt_forced64) && opt(OPT_ATTN2_PF)) return launch_attn2_d<5, 1, true, true>(p, st);      // round 5: permute-free P
         if (fold) return (two && qt_forced64) ? launch_attn2_d<5, 2, true>(p, st) : launch_attn2_d<5, 1, true>(p, st);
         return two ? launch_attn2_d<5, 2, false>(p, st) : launch_attn2_d<5, 1, false>(p, st);
     }

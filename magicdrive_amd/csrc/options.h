@@ -21,6 +21,7 @@ namespace mdx {
     X(ATTN2, 1, "attention2.hip for head dim 40") \
     X(ATTN3, 0, "attention3.hip (permute-free P, QK of the next kv tile beside this tile's softmax) for the head-dim-40 FOLD launches: self, cross-view, joint") \
     X(ATTN3_WGS, 0, "attention3.hip: persistent workgroups per XCD (0 = automatic: two per CU)") \
+    X(ATTN2_PF, 1, "attention2.hip, head dim 40 FOLD 32-query form: permute-free P (PV on 32x32x16 MFMAs, K rows permuted so that a lane's scores are its PV operand)") \
     X(ATTN2_D80, 2, "attention2.hip for head dim 80: 0 never, 1 always, 2 only the two-source cross-view form") \
     X(ATTN2_FOLD, 1, "attention2.hip: subtract the running maximum inside the QK MFMA when Q is pre-scaled (head dim 40)") \
     X(ATTN2_RES, 1, "attention2.hip: kv sequences of <= 3 tiles (text context) resident in LDS, one workgroup per (view, head) walks the query blocks: 0 off, 1 for launches of >= 1024 (view, head) pairs, 2 whenever supported") \

@@ -783,7 +783,7 @@ def test_attention_joint_sources(dev, b, heads, T, d, nsrc, expect, pre):
     if pre:                                  # MdxAttnDesc.q_prescaled (every kernel takes it; head dim 40 folds the maximum into the MFMA)
         q = (q.float() * qpre).to(BF); qref = q.float() / qpre
         if d == 40:                           # pre-scaled head dim 40: attention3.hip (round 5); with ATTN3 = 0 the 32-query FOLD form of attention2.hip
-            expect = "attn3_kernel<40,joint>" if L.get_option("ATTN3") else expect.replace("q64>", "q32,fold>")
+            expect = "attn3_kernel<40,joint>" if L.get_option("ATTN3") else expect.replace("q64>", "q32,fold,pf>" if L.get_option("ATTN2_PF") else "q32,fold>")
     O.run_ops([O.Attn(q, k, vt, o, heads=heads, Tk=T, scale=d ** -0.5, kvmap=kvmap, nsrc=nsrc, joint=True, q_prescaled=pre)])
     kern = (L.lib().mdx_last_kernel() or b"").decode()
     torch.cuda.synchronize()
@@ -821,6 +821,8 @@ def attn2_route(d, Tq, xview=False, pre=False):
         return f"attn3_kernel<40,{mode}>"
     qt = L.get_option("ATTN2_QT")                  # 0: automatic = 64-query waves, except FOLD launches (32: four waves per SIMD)
     q = 64 if (d == 40 and Tq >= 512 and qt != 1 and (qt == 2 or not fold)) else 32
+    if fold and q == 32 and L.get_option("ATTN2_PF"):      # round 5: the permute-free form takes the 32-query FOLD launches
+        return f"attn2_kernel<{d},{mode},q32,fold,pf>"
     return f"attn2_kernel<{d},{mode},q{q}{fold}>"
 
 
