@@ -539,7 +539,7 @@ def test_sample_driver_cond_on_view_end_to_end(dev, tmp_path):
     out = tmp_path / "out"
     sample.main(["--ckpt", str(ckpt), "--sd15", str(sd15), "--data", str(data), "--out", str(out), "--scheduler", "unipc", "--batch-size", "2",
                  "--prompt-embeds", "--device", str(dev), "--cond-on-view", "runner.pipeline_param.num_inference_steps=3"])
-    files = sorted(os.listdir(out))
+    files = sorted(f_ for f_ in os.listdir(out) if f_.endswith(".png"))      # (+ index.json: the driver's scene -> files / rank / seed table)
     assert len(files) == 2 * 2 * 6, files[:8]                    # validation_times - 1 = 2 generations per scene
     # the driver == composing the pieces by hand: encode the ground-truth views, give view 0, same seed -> the same six images for generation 0
     # (with random weights a given view does NOT come out as its ground truth: UniPC's last step leaves t = 333 with this network's epsilon,
@@ -605,7 +605,7 @@ def test_sample_driver_end_to_end(dev, tmp_path):
     out = tmp_path / "out"
     sample.main(["--ckpt", str(ckpt) + "/", "--sd15", str(sd15), "--data", str(data), "--out", str(out), "--scheduler", "unipc", "--batch-size", "2",
                  "--prompt-embeds", "--device", str(dev), "runner.pipeline_param.num_inference_steps=3", "fix_seed_within_batch=true"])
-    files = sorted(os.listdir(out))
+    files = sorted(f_ for f_ in os.listdir(out) if f_.endswith(".png"))      # (+ index.json: the driver's scene -> files / rank / seed table)
     assert len(files) == 5 * 2 * 6, files[:8]
     im = Image.open(out / "3_gen1_view5.png")
     assert im.size == (400, 224) and np.asarray(im).std() > 0
