@@ -102,6 +102,41 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
 }
 #endif
 
+// Two GELUs at once on packed fp32 (v_pk_mul_f32 / v_pk_fma_f32: one instruction, two lanes' worth of elements each): 15 instructions per PAIR (two
+// clamps + 13 packed) instead of 2 x 14 — the GEGLU epilogues evaluate 1.4 G of these per level-0 launch and are VALU-bound (profiles/README.md round 3).
+// Same polynomial, same operation order per element as gelu_erf_f: bit-identical results.  -DMDX_GELU_PK=0 keeps the scalar form (A/B side builds).
+#ifndef MDX_GELU_PK
+#define MDX_GELU_PK 1
+#endif
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+#ifndef MDX_GELU_AS
+__device__ __forceinline__ f32x2_t gelu_erf_f2(f32x2_t x) {
+#if MDX_GELU_PK
+    const f32x2_t z = x * 0.70710678118654752440f;
+    f32x2_t zc;
+    zc.x = __builtin_amdgcn_fmed3f(z.x, -3.0f, 3.0f); zc.y = __builtin_amdgcn_fmed3f(z.y, -3.0f, 3.0f);
+    const f32x2_t u = zc * zc;
+    auto c2 = [](float c) { return f32x2_t{c, c}; };
+    f32x2_t p = c2(4.074397617e-08f);
+    p = __builtin_elementwise_fma(p, u, c2(-1.944883433e-06f));
+    p = __builtin_elementwise_fma(p, u, c2(4.106127751e-05f));
+    p = __builtin_elementwise_fma(p, u, c2(-5.110412727e-04f));
+    p = __builtin_elementwise_fma(p, u, c2(4.235439367e-03f));
+    p = __builtin_elementwise_fma(p, u, c2(-2.510287440e-02f));
+    p = __builtin_elementwise_fma(p, u, c2(1.110793533e-01f));
+    p = __builtin_elementwise_fma(p, u, c2(-3.753149504e-01f));
+    p = __builtin_elementwise_fma(p, u, c2(1.128268531e+00f));
+    const f32x2_t e = zc * p;
+    const f32x2_t hx = x * 0.5f;
+    return __builtin_elementwise_fma(hx, e, hx);
+#else
+    return f32x2_t{gelu_erf_f(x.x), gelu_erf_f(x.y)};
+#endif
+}
+#else
+__device__ __forceinline__ f32x2_t gelu_erf_f2(f32x2_t x) { return f32x2_t{gelu_erf_f(x.x), gelu_erf_f(x.y)}; }
+#endif
+
 union Frag8 {
     uint4 u;
     bf16x8_t v;

@@ -372,10 +372,11 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
                         const float bgg[4] = {bA[2 + g].x, bA[2 + g].y, bA[2 + g].z, bA[2 + g].w};
                         float o[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float x = acc[i][4 * g + e] + bvv[e];
-                            const float gt = acc[i][8 + 4 * g + e] + bgg[e];
-                            o[e] = no_gelu ? x * gt : x * gelu_erf_f(gt);
+                        for (int e = 0; e < 4; e += 2) {             // pairs: the GELU runs on packed fp32 (common.h: gelu_erf_f2)
+                            const float x0 = acc[i][4 * g + e] + bvv[e], x1 = acc[i][4 * g + e + 1] + bvv[e + 1];
+                            const f32x2_t gt = {acc[i][8 + 4 * g + e] + bgg[e], acc[i][8 + 4 * g + e + 1] + bgg[e + 1]};
+                            const f32x2_t ge = no_gelu ? gt : gelu_erf_f2(gt);
+                            o[e] = x0 * ge.x; o[e + 1] = x1 * ge.y;
                         }
                         uint2 ov; ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]);
                         *(uint2*)(Cs + ml * CSTR + ocol + 8 * g + 4 * half) = ov;

@@ -633,10 +633,11 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
                             if constexpr (HOIST) g4 = g4h[j]; else g4 = *(const float4*)(ad + nl + 32);
                             const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float x = acc[i][j][e] + bb[e];
-                                const float gt = acc[i][(TJ == 4) ? (j | 2) : j][e] + gg[e];
-                                o[e] = x * gelu_erf_f(gt);
+                            for (int e = 0; e < 4; e += 2) {         // pairs: the GELU runs on packed fp32 (common.h: gelu_erf_f2)
+                                const float x0 = acc[i][j][e] + bb[e], x1 = acc[i][j][e + 1] + bb[e + 1];
+                                const f32x2_t gt = {acc[i][(TJ == 4) ? (j | 2) : j][e] + gg[e], acc[i][(TJ == 4) ? (j | 2) : j][e + 1] + gg[e + 1]};
+                                const f32x2_t ge = gelu_erf_f2(gt);
+                                o[e] = x0 * ge.x; o[e + 1] = x1 * ge.y;
                             }
                         } else {
 #pragma unroll
@@ -1064,7 +1065,10 @@ __global__ __launch_bounds__(512, 2) void gemm_xlp_kernel(GCParams p) {
                     if (GEGLU) {
                         const float gg[4] = {bq[j + 2].x, bq[j + 2].y, bq[j + 2].z, bq[j + 2].w};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (acc[i][j][e] + bb[e]) * gelu_erf_f(acc[i][j + 2][e] + gg[e]);
+                        for (int e = 0; e < 4; e += 2) {             // pairs: the GELU runs on packed fp32 (common.h: gelu_erf_f2)
+                            const f32x2_t ge = gelu_erf_f2(f32x2_t{acc[i][j + 2][e] + gg[e], acc[i][j + 2][e + 1] + gg[e + 1]});
+                            o[e] = (acc[i][j][e] + bb[e]) * ge.x; o[e + 1] = (acc[i][j][e + 1] + bb[e + 1]) * ge.y;
+                        }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = acc[i][j][e] + bb[e];
