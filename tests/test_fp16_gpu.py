@@ -61,6 +61,8 @@ def test_fp16_gemm_conv_norm_kernels(dev):
         with L.options(GEMM_XL=0):
             TR.conv_case(16, 28, 50, 320, 320, expect="conv3x3_kernel")
             TR.gemm_case(8736, 1280, 1280, res=True, expect="gemm_conv_kernel<128,128,64")
+        TK.test_gemm_geglu_large_gates(dev, 8400, 1280, 320)               # the clamped polynomial erf against the fp16 table
+        TK.test_gemm_geglu_large_gates(dev, 2100, 2560, 640)
         TK.test_groupnorm(dev, 2, 1400, 320, 32, True, 1e-5)
         TK.test_groupnorm(dev, 3, 91, 1280, 32, False, 1e-6)
         TK.test_gemm_fused_layernorm(dev, 9001, 640, True, "ws")          # LayerNorm inside the weight-stationary GEMM

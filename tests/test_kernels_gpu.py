@@ -260,6 +260,24 @@ def test_gemm_geglu(dev, M, F_, K):
     close(C, h * F.gelu(g), name="geglu")
 
 
+@pytest.mark.parametrize("M,F_,K", [(8400, 1280, 320), (2100, 2560, 640)])
+def test_gemm_geglu_large_gates(dev, M, F_, K):
+    """The erf of the GEGLU epilogues is a degree-8 polynomial clamped at |z| = 3 (csrc/common.h, |error| <= 2.7e-5 against an exact erf): gates far out in
+    both tails (|g| up to ~12, where the clamp acts and gelu(g) is g or 0 to rounding) must still sit inside the storage type's table — this test also
+    runs in the fp16 build (tests/test_fp16_gpu.py), whose table is 5x tighter.  Reference: fp64 x * gelu(g) with the exact erf."""
+    A = rnd(M, K, seed=1); W = rnd(2 * F_, K, scale=K ** -0.5, seed=2, dtype=torch.float32, dev="cpu")
+    b = rnd(2 * F_, seed=3, dtype=torch.float32, dev="cpu")
+    W[F_:] *= 16.0; b[F_:] *= 4.0                              # the gate half: std ~8 instead of ~0.5
+    Wp, bp = PK.pack_geglu(W, b, BF)
+    C = torch.zeros(M, F_, dtype=BF, device=dev)
+    O.run_ops([O.Gemm(A, Wp.to(dev), C, bias=bp.to(dev), epilogue=L.EPI_GEGLU, ws=ws_buf(dev))])
+    torch.cuda.synchronize()
+    proj = A.double().cpu() @ W.to(BF).double().T + b.double()
+    h, g = proj.chunk(2, dim=-1)
+    assert (g.abs() > 4).float().mean() > 0.5 and g.abs().max() > 20
+    close(C, (h * F.gelu(g)).float(), name="geglu large gates")
+
+
 @pytest.mark.parametrize("Bt,T,Cc", [(6, 1400, 320), (6, 350, 640), (3, 91, 1280), (2, 28, 64)])
 def test_gemm_batched_vt(dev, Bt, T, Cc):
     # V^T[b] = Wv @ X[b]^T into a kv-padded buffer
