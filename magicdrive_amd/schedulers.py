@@ -18,6 +18,13 @@ import numpy as np
 import torch
 
 
+
+class SchedulerOutput:
+    """`scheduler.step(...)` result (diffusers' SchedulerOutput: `.prev_sample`)."""
+
+    def __init__(self, prev_sample):
+        self.prev_sample = prev_sample
+
 class DDIMScheduler:
     order = 1
     init_noise_sigma = 1.0
@@ -153,11 +160,7 @@ class DDIMScheduler:
         if not return_dict:
             return (prev,)
 
-        class _Out:
-            pass
-        o = _Out()
-        o.prev_sample = prev
-        return o
+        return SchedulerOutput(prev_sample=prev)
 
 
 class UniPCMultistepScheduler:
@@ -222,6 +225,7 @@ class UniPCMultistepScheduler:
         ts = ts[np.sort(uniq)]
         self.timesteps = torch.from_numpy(ts)
         self.num_inference_steps = len(ts)
+        self._host_state = None                    # step(): a new timestep list starts a new history
         return self.timesteps
 
     def scale_model_input(self, sample, timestep=None):
@@ -298,5 +302,38 @@ class UniPCMultistepScheduler:
         return a * original_samples + sg * noise
 
     def step(self, model_output, timestep, sample, return_dict: bool = True):
-        raise NotImplementedError("UniPC keeps multistep state on the device: it runs inside StableDiffusionBEVControlNetPipeline.__call__ "
-                                  "(fused kernel mdx_cfg_unipc_step); a free-standing step() is not provided")
+        """The host API of scheduling_unipc_multistep.py:518-600 (`scheduler.step(model_output, t, sample).prev_sample`, called once per timestep in
+        order) on the fused kernel the pipeline uses: the multistep history (last sample, the two previous converted model outputs) lives in fp32
+        device buffers owned by this scheduler object — created at the first timestep of the list (or when the sample's shape / device changes),
+        dropped by set_timesteps — and the coefficient row of the timestep carries corrector, predictor, warm-up and lower-order-final.  Inside
+        StableDiffusionBEVControlNetPipeline.__call__ the same kernel runs from the captured step program instead (state in the plan)."""
+        from . import ops as O
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        t = int(timestep.reshape(-1)[0].item()) if isinstance(timestep, torch.Tensor) else int(timestep)
+        hits = (self.timesteps == t).nonzero()
+        if hits.numel() == 0:
+            raise ValueError(f"timestep {t} is not in this scheduler's timestep list")
+        idx = int(hits[0])
+        dev = sample.device
+        st = getattr(self, "_host_state", None)
+        key = (dev, tuple(sample.shape))
+        if idx == 0 or st is None or st["key"] != key:
+            if idx != 0:
+                raise ValueError(f"UniPC.step: timestep {t} is step {idx} of the list but no history exists for a sample of shape {tuple(sample.shape)} on {dev} "
+                                 "(step() must be called for every timestep in order, starting with the first)")
+            n = sample.numel()
+            st = self._host_state = dict(key=key, coef=self.coefficient_table().to(dev), next=0,
+                                         x_last=torch.zeros(n, dtype=torch.float32, device=dev), m1=torch.zeros(n, dtype=torch.float32, device=dev),
+                                         m2=torch.zeros(n, dtype=torch.float32, device=dev))
+        if idx != st["next"]:
+            raise ValueError(f"UniPC.step: expected step {st['next']} of the timestep list next, got {idx} (timestep {t}): the multistep history is sequential")
+        x = sample.detach().to(torch.float32).contiguous().clone()
+        eps = model_output.detach().to(torch.float32).contiguous()
+        step = torch.full((1,), idx, dtype=torch.int32, device=dev)
+        O.run_ops([O.UniPCStep(x.view(-1), eps.view(-1), st["coef"], step, st["x_last"], st["m1"], st["m2"])])
+        st["next"] = idx + 1
+        prev = x.to(sample.dtype)
+        if not return_dict:
+            return (prev,)
+        return SchedulerOutput(prev_sample=prev)

@@ -738,6 +738,23 @@ def test_cfg_ddim_bf16_padded_model_input(dev):
     assert (xin[:, Cc:].float() == 7.0).all(), "pad channels must not be touched"
 
 
+def test_unipc_scheduler_host_step_on_gpu(dev):
+    """`UniPCMultistepScheduler.step()` (the reference's host API, scheduling_unipc_multistep.py:518-600) on the fused kernel: diffusers' full-loop
+    known-answer test (test_scheduler_unipc.py:205-209: mean |x| = 0.2521) and step-by-step agreement with the oracle's restatement."""
+    from magicdrive_amd.schedulers import UniPCMultistepScheduler
+    from oracle import denoiser as D
+    kw = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", solver_order=2, solver_type="bh1")
+    s = UniPCMultistepScheduler(**kw); ref = D.UniPC(**kw); ref.set_timesteps(10)
+    n = 4 * 3 * 8 * 8
+    x_ref = (torch.arange(n).reshape(3, 8, 8, 4) / n).permute(3, 0, 1, 2).contiguous()
+    sample = x_ref.clone().to(dev)
+    for t in s.set_timesteps(10):
+        sample = s.step(sample * t / (t + 1), t, sample).prev_sample
+        x_ref = ref.step(x_ref * t / (t + 1), int(t), x_ref)
+        assert (sample.cpu() - x_ref).abs().max().item() < 2e-5
+    assert abs(sample.abs().mean().item() - 0.2521) < 1e-3
+
+
 @pytest.mark.parametrize("T,Tk,d,expect", [(91, 91, 160, "attn_kernel<10,4,self>"), (28, 28, 160, "attn_kernel<10,4,self>"), (91, 78, 160, "attn_kernel<10,4,self>"),
                                             (28, 78, 80, "attn_kernel<5,4,self>")])
 def test_attention_short_sequences_many_heads(dev, T, Tk, d, expect):
