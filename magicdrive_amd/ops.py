@@ -571,6 +571,8 @@ def run_ops(ops, stream: Optional[int] = None) -> None:
                     break
             if dev is not None:
                 break
+        if dev is None:
+            raise RuntimeError("magicdrive_amd: ops run on the MI355X only (no CPU fallback): none of the operands is a CUDA / HIP tensor")
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             for op in ops:
