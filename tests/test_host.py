@@ -62,8 +62,8 @@ def test_unipc_table_reproduces_oracle_scheduler(n, kw):
         x, xl, m2, m1 = px * xc + pt * mt + p1 * m1, xc, m1, mt
         xo = o.step(eo.float(), t, xo.float()).double()
         assert torch.allclose(x, xo, atol=2e-5, rtol=2e-5), (i, t)
-    with pytest.raises(NotImplementedError):
-        s.step(x, ts[0], x)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):      # the host step() API exists since round 5 — on the GPU only
+        s.step(x.float(), ts[0], x.float())
 
 
 def test_checkpoint_layout_roundtrip(tmp_path):
