@@ -416,7 +416,7 @@ def main():
         vae_ms = 1e3 * (time.perf_counter() - t2) / nv
         assert img.shape == (6 * nv, 224, 400, 3) and torch.isfinite(img).all()
         vplan = next(iter(vae._plans.values()))
-        vae_tf = FL.program_flops(vplan.ops)["total"] / nv / 1e12                      # per 6-view scene (algorithmic, 2 FLOPs per MAC)
+        vae_tf = FL.program_flops(vplan.ops)["total"] / max(vplan.n // 6, 1) / 1e12   # per 6-view scene (algorithmic, 2 FLOPs per MAC); the plan decodes vplan.n images per run
         torch.cuda.synchronize()
         t4 = time.perf_counter()
         vae.decode(zl)
