@@ -19,7 +19,7 @@ from . import _lib as L
 from . import ops as O
 from . import packing as PK
 from .networks import spec
-from .engine import Act, Builder, PackedNet, TembTable, build_context_kv, level_sizes
+from .engine import Act, Builder, PackedNet, Pool, TembTable, build_context_kv, level_sizes
 
 BF16, F32 = torch.bfloat16, torch.float32
 CIN_PAD = 8      # latent channels (4) zero-padded so conv_in meets the MFMA path's Cin % 8 == 0
@@ -258,7 +258,7 @@ class SamplerPlan:
 
     def __init__(self, cfg, unet: PackedNet, cn: PackedNet, device, b: int, do_cfg: bool, L_box: int, latent_hw=(28, 50),
                  num_steps: int = 50, guidance_scale: float = 2.0, conditioning_scale: float = 1.0, n_text: int = 77,
-                 scheduler_kind: str = "ddim", given_view_mode: int = 0):
+                 scheduler_kind: str = "ddim", given_view_mode: int = 0, fork: bool = False):
         self.cfg, self.device = cfg, device
         assert scheduler_kind in ("ddim", "unipc")
         assert given_view_mode in (0, 1, 2)
@@ -302,11 +302,26 @@ class SamplerPlan:
         self.prologue_ops = bld.ops
         bld.ops = []
         # ---------------- one denoising step ----------------
+        # The ControlNet and the UNet encoder of a step are INDEPENDENT until the zero-convs add the one into the other's skips (both read x_in;
+        # unet_addon_rawbox.py:882-910 / unet_2d_condition_multiview.py:464-488).  fork: the two are emitted with SEPARATE buffer pools and workspaces
+        # (the pool's aliasing of freed buffers is only safe for ops that execute in order), so that the pipeline may replay them side by side on
+        # two streams and join before the zero-convs (round 5: the small-batch operating point, where a launch fills a fraction of the chip and
+        # every kernel boundary is a dependency bubble).  The linear program (self.step) stays valid: same ops, same buffers.
         cn_mid, cn_skips = _emit_controlnet(bld, cn, self.x_in, self.cond, self.temb_cn, self.kv_cn, h, w)
+        n_cn = len(bld.ops)
+        if fork:
+            pool_cn = bld.pool
+            bld.pool = Pool(device, self.dtype)
+            bld.ws = torch.empty_like(bld.ws)
         c0 = cfg["block_out_channels"][0]
         u0 = bld.new(B, h, w, c0)
         bld.emit(O.Conv(self.x_in, unet.conv_cin_padded("conv_in.weight", CIN_PAD), u0.bhwc, bias=unet.vec("conv_in.bias"), ws=bld.ws, name="unet.conv_in"))
         u_mid, u_skips = bld.encoder(unet, u0, self.temb_un, self.kv_un, "unet")
+        self.fork_at = (n_cn, len(bld.ops)) if fork else None   # step_ops[:a] ControlNet | [a:b] UNet conv_in + encoder | [b:] zero-convs, decoder, scheduler
+        if fork:                                                # behind the join the tail may reuse what either branch has freed
+            for k_, v_ in pool_cn.free_list.items():
+                bld.pool.free_list.setdefault(k_, []).extend(v_)
+            bld.pool.total_bytes += pool_cn.total_bytes
         # zero-convs accumulate straight into the UNet skips / mid (unet_addon_rawbox.py:882-910 +
         # unet_2d_condition_multiview.py:464-488); the adds happen after the UNet encoder+mid consumed the
         # un-added tensors, exactly like the reference's out-of-place `sample + residual`.
@@ -339,10 +354,31 @@ class SamplerPlan:
         bld.ops = []
         self.prologue: Optional[L.Program] = None
         self.step: Optional[L.Program] = None
+        self.step_cn = self.step_enc = self.step_tail = None    # fork: the three parts of the step as programs of their own
 
     def compile(self):
         self.prologue = O.build_program(self.prologue_ops)
         self.step = O.build_program(self.step_ops)
+        if self.fork_at is not None:
+            a, b_ = self.fork_at
+            self.step_cn = O.build_program(self.step_ops[:a])
+            self.step_enc = O.build_program(self.step_ops[a:b_])
+            self.step_tail = O.build_program(self.step_ops[b_:])
+
+    def launch_step(self, main, side, use_graph: bool = True):
+        """One denoising step.  Without fork (or without a side stream): the linear program on `main`.  With fork: the ControlNet on `side`, the UNet
+        encoder on `main`, joined before the zero-convs — `main` / `side` are torch streams; everything else the caller does stays on `main`."""
+        go = (lambda prog, st: prog.launch(st.cuda_stream)) if use_graph else (lambda prog, st: prog.run(st.cuda_stream))
+        if self.fork_at is None or side is None:
+            go(self.step, main)
+            return
+        ready = torch.cuda.Event(); ready.record(main)          # x_in of this step: written by the previous step's scheduler kernel on main
+        side.wait_event(ready)
+        go(self.step_cn, side)
+        done = torch.cuda.Event(); done.record(side)
+        go(self.step_enc, main)
+        main.wait_event(done)
+        go(self.step_tail, main)
 
     def release(self):
         """Drop the captured graph and every device buffer this plan owns (called on LRU eviction).  The plan's last replay may still
@@ -350,10 +386,10 @@ class SamplerPlan:
         a running graph is not safe, so the device is drained first (evictions are rare: once per new batch geometry)."""
         if self.device is not None and torch.device(self.device).type == "cuda":
             torch.cuda.synchronize(self.device)
-        for prog in (self.prologue, self.step):
+        for prog in (self.prologue, self.step, self.step_cn, self.step_enc, self.step_tail):
             if prog is not None:
                 prog.destroy()
-        self.prologue = self.step = None
+        self.prologue = self.step = self.step_cn = self.step_enc = self.step_tail = None
         self.prologue_ops = self.step_ops = []
         self.bld = None
         self.cond = self.temb_cn = self.temb_un = self.kv_cn = self.kv_un = None

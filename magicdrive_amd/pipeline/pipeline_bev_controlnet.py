@@ -65,6 +65,11 @@ class StableDiffusionBEVControlNetPipeline:
         # even alone).  Measured on one box (profiles/r04_streams_ab.log, configs[1]): 128 scenes 7.02 -> 7.21 scenes/s, 192 scenes 7.14 -> 7.23.
         self.streams = None                                   # None: follow the option
         self.min_scenes_per_stream = 16
+        # The small-batch operating point (the reference's own flows run bs = 1...4): up to this many scenes per call the ControlNet and the UNet
+        # encoder of every step — independent until the zero-convs — replay side by side on two streams (SamplerPlan.launch_step).  Measured
+        # (profiles/r05_fork_ab.log, 50-step DDIM, s per call without / with): 1 scene 0.656 / 0.559 (-15 %), 2: 0.849 / 0.747, 4: 1.196 / 1.071,
+        # 8: 1.810 / 1.661, 16: 2.749 / 2.582 (-6 %).  From 32 scenes a call is split into scene chunks on two streams instead (above).
+        self.fork_max_scenes = 31
         self._side: Dict[Any, List[Any]] = {}
 
     # ---- construction / housekeeping the reference's callers use (misc/test_utils.py:94-138) ----
@@ -319,13 +324,14 @@ class StableDiffusionBEVControlNetPipeline:
             return torch.cat([t[hf * b + s0:hf * b + s1] for hf in range(c_halves)]) if c_halves == 2 else t[s0:s1]
 
         pdt = self.unet.packed().dtype
+        fork = n_chunk == 1 and 0 < b <= int(self.fork_max_scenes)
         plans = []
         for ci in range(n_chunk):
             s0, s1 = bounds[ci], bounds[ci + 1]
             # the packed nets' identity and 16-bit type are part of the key: `pipe.unet.to(torch.float16)` re-packs the weights, and a plan
             # built on the old PackedNet would keep running (and keep alive) the old ones
             key = (s1 - s0, ci, do_cfg, L_box, h, w, n_steps, float(guidance_scale), float(controlnet_conditioning_scale), text.shape[1], sched_kind,
-                   gv_mode, pdt, id(self.unet.packed()), id(self.controlnet.packed()))
+                   gv_mode, pdt, id(self.unet.packed()), id(self.controlnet.packed()), fork)
             plan = self._plans.get(key)
             if plan is None:
                 with torch.cuda.device(device):
@@ -336,7 +342,7 @@ class StableDiffusionBEVControlNetPipeline:
                     plan = SamplerPlan(plan_cfg, self.unet.packed(), self.controlnet.packed(), device, s1 - s0, do_cfg, L_box, (h, w),
                                        num_steps=n_steps, guidance_scale=guidance_scale,
                                        conditioning_scale=float(controlnet_conditioning_scale), n_text=text.shape[1], scheduler_kind=sched_kind,
-                                       given_view_mode=gv_mode)
+                                       given_view_mode=gv_mode, fork=fork)
                     plan.compile()
                 self._plans.put(key, plan)
             plan.load_inputs(latents[s0:s1], rows(camera_param, s0, s1), rows(text, s0, s1), rows(image, s0, s1),
@@ -346,7 +352,7 @@ class StableDiffusionBEVControlNetPipeline:
             plans.append(plan)
         with torch.cuda.device(device):                       # launches, graph replays and torch copies all target the pipeline's device
             main = torch.cuda.current_stream(device)
-            side = self._side_streams(device, n_chunk - 1)
+            side = self._side_streams(device, max(n_chunk - 1, 1 if fork else 0))
             if side:
                 ready = torch.cuda.Event()
                 ready.record(main)                            # the inputs were loaded on the caller's stream
@@ -357,11 +363,14 @@ class StableDiffusionBEVControlNetPipeline:
                 plan.prologue.run(st)
             with self.progress_bar(total=num_inference_steps) as bar:
                 for i, t in enumerate(timesteps):
-                    for plan, st in zip(plans, sts):
-                        if self.use_graph:
-                            plan.step.launch(st)
-                        else:
-                            plan.step.run(st)
+                    if fork:                                  # one chunk, two branches per step (ControlNet on the side stream)
+                        plans[0].launch_step(main, side[0], self.use_graph)
+                    else:
+                        for plan, st in zip(plans, sts):
+                            if self.use_graph:
+                                plan.step.launch(st)
+                            else:
+                                plan.step.run(st)
                     bar.update()
                     if callback is not None and i % callback_steps == 0:
                         callback(i, t, plans[0].latents().to(prompt_embeds.dtype))

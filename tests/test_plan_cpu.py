@@ -394,3 +394,46 @@ def test_fused_layernorm_block_equals_separate_layernorm(monkeypatch, dtype, lim
     assert k1.count("Gemm:ln") == 3 and k1.count("LayerNorm") == 1          # norm3 -> GEGLU keeps its own pass
     assert k0.count("Gemm:ln") == 0 and k0.count("LayerNorm") == 4
     assert rel_l2(y1, y0) < limit, rel_l2(y1, y0)
+
+
+def test_forked_step_branches_share_no_buffer(tiny):
+    """Round 5, the small-batch operating point: with fork=True the ControlNet and the UNet encoder of a step are emitted with separate buffer pools and
+    workspaces so that they may run CONCURRENTLY (SamplerPlan.launch_step: ControlNet on a side stream, joined before the zero-convs).  Checked here on
+    the interpreter: (1) no buffer written by one branch is touched by the other (the shared inputs x_in / context K, V / temb tables are read-only
+    in both), (2) executing the encoder branch BEFORE the ControlNet gives bit-identical latents to the linear order, for several steps, (3) it is the
+    same program as the unforked plan."""
+    cfg, usd, csd, un, cn = tiny
+    sc = one_scene(scene(cfg, 2, 5), 0)
+    steps = 3
+    sch = schedulers.DDIMScheduler(); ts = sch.set_timesteps(steps)
+    cam, text, bev, boxes = cfg_inputs(D, csd, sc)
+    outs = {}
+    for name, fork, order in (("linear", False, None), ("forked_linear", True, None), ("forked_enc_first", True, "enc_first")):
+        sp = DN.SamplerPlan(cfg, un, cn, CPU, 1, True, 5, (28, 50), num_steps=steps, guidance_scale=2.0, fork=fork)
+        sp.load_inputs(torch.stack([sc["latents"]] * 6, 1), cam, text, bev, boxes, ts, sch.coefficient_table())
+        plan_interp.run(sp.prologue_ops)
+        for _ in range(steps):
+            if order is None:
+                plan_interp.run(sp.step_ops, lower_check=False)
+            else:
+                a, b = sp.fork_at
+                plan_interp.run(sp.step_ops[a:b], lower_check=False)
+                plan_interp.run(sp.step_ops[:a], lower_check=False)
+                plan_interp.run(sp.step_ops[b:], lower_check=False)
+        outs[name] = sp.latents().clone()
+        if fork:
+            a, b = sp.fork_at
+            assert 0 < a < b < len(sp.step_ops)
+
+            def storages(ops, written_only):
+                got = set()
+                for op in ops:
+                    outs_ = {"C", "Y", "O", "Vt", "x", "x_in", "eps", "ln_scratch", "ws"}
+                    for k, v in vars(op).items():
+                        if isinstance(v, torch.Tensor) and v.numel() and (not written_only or k in outs_):
+                            got.add(v.untyped_storage().data_ptr())
+                return got
+            w_cn, w_enc = storages(sp.step_ops[:a], True), storages(sp.step_ops[a:b], True)
+            assert not (w_cn & storages(sp.step_ops[a:b], False)), "the encoder branch touches a buffer the ControlNet writes"
+            assert not (w_enc & storages(sp.step_ops[:a], False)), "the ControlNet touches a buffer the encoder branch writes"
+    assert torch.equal(outs["forked_linear"], outs["linear"]) and torch.equal(outs["forked_enc_first"], outs["linear"])
