@@ -70,6 +70,7 @@ class StableDiffusionBEVControlNetPipeline:
         # (profiles/r05_fork_ab.log, 50-step DDIM, s per call without / with): 1 scene 0.656 / 0.559 (-15 %), 2: 0.849 / 0.747, 4: 1.196 / 1.071,
         # 8: 1.810 / 1.661, 16: 2.749 / 2.582 (-6 %).  From 32 scenes a call is split into scene chunks on two streams instead (above).
         self.fork_max_scenes = 31
+        self.fork_chunks = False                              # also fork inside every scene chunk of a multi-stream call (A/B switch: tools/streams_ab.py)
         self._side: Dict[Any, List[Any]] = {}
 
     # ---- construction / housekeeping the reference's callers use (misc/test_utils.py:94-138) ----
@@ -324,7 +325,7 @@ class StableDiffusionBEVControlNetPipeline:
             return torch.cat([t[hf * b + s0:hf * b + s1] for hf in range(c_halves)]) if c_halves == 2 else t[s0:s1]
 
         pdt = self.unet.packed().dtype
-        fork = n_chunk == 1 and 0 < b <= int(self.fork_max_scenes)
+        fork = (n_chunk == 1 and 0 < b <= int(self.fork_max_scenes)) or (n_chunk > 1 and bool(self.fork_chunks))
         plans = []
         for ci in range(n_chunk):
             s0, s1 = bounds[ci], bounds[ci + 1]
@@ -352,7 +353,8 @@ class StableDiffusionBEVControlNetPipeline:
             plans.append(plan)
         with torch.cuda.device(device):                       # launches, graph replays and torch copies all target the pipeline's device
             main = torch.cuda.current_stream(device)
-            side = self._side_streams(device, max(n_chunk - 1, 1 if fork else 0))
+            side_all = self._side_streams(device, (n_chunk - 1) + (n_chunk if fork else 0))
+            side, fside = side_all[:n_chunk - 1], side_all[n_chunk - 1:]      # chunk streams beside the caller's; one fork stream per chunk
             if side:
                 ready = torch.cuda.Event()
                 ready.record(main)                            # the inputs were loaded on the caller's stream
@@ -363,8 +365,9 @@ class StableDiffusionBEVControlNetPipeline:
                 plan.prologue.run(st)
             with self.progress_bar(total=num_inference_steps) as bar:
                 for i, t in enumerate(timesteps):
-                    if fork:                                  # one chunk, two branches per step (ControlNet on the side stream)
-                        plans[0].launch_step(main, side[0], self.use_graph)
+                    if fork:                                  # two branches per step and chunk (ControlNet on the chunk's fork stream)
+                        for plan, cst, fst in zip(plans, [main] + list(side), fside):
+                            plan.launch_step(cst, fst, self.use_graph)
                     else:
                         for plan, st in zip(plans, sts):
                             if self.use_graph:
@@ -374,7 +377,7 @@ class StableDiffusionBEVControlNetPipeline:
                     bar.update()
                     if callback is not None and i % callback_steps == 0:
                         callback(i, t, plans[0].latents().to(prompt_embeds.dtype))
-            for s_ in side:                                   # the caller's stream owns the result: join the side streams into it
+            for s_ in side_all:                               # the caller's stream owns the result: join the side streams into it
                 done = torch.cuda.Event()
                 done.record(s_)
                 main.wait_event(done)

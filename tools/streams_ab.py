@@ -31,8 +31,10 @@ def main():
     cat = lambda k, n: torch.cat([s[k] for s in scenes[:n]]).to(dev)
     ref = None
     for pair in args.pairs.split(","):
-        n, st = (int(x) for x in pair.split(":"))
+        f = pair.split(":")
+        n, st = int(f[0]), int(f[1])
         pipe.streams = st
+        pipe.fork_chunks = len(f) > 2 and f[2] == "f"        # "192:2:f": also fork ControlNet / UNet encoder inside every chunk
         kw = dict(prompt=None, image=cat("bev_map", n), camera_param=None, height=224, width=400, num_inference_steps=args.ddim_steps,
                   guidance_scale=1.0, latents=cat("latents", n), prompt_embeds=cat("prompt_embeds", n),
                   negative_prompt_embeds=cat("negative_prompt_embeds", n), output_type="latent")
@@ -49,7 +51,7 @@ def main():
         if ref is None:
             ref = out[0].float().clone()
         dev_rel = ((out[0].float() - ref).norm() / ref.norm()).item()
-        print(json.dumps({"scenes": n, "streams": st, "scenes_per_s": round(n / min(ts), 4), "seconds_per_call": [round(t, 3) for t in ts],
+        print(json.dumps({"scenes": n, "streams": st, "fork_chunks": pipe.fork_chunks, "scenes_per_s": round(n / min(ts), 4), "seconds_per_call": [round(t, 3) for t in ts],
                           "scene0_vs_first_config_rel": round(dev_rel, 6)}), flush=True)
         pipe._plans.clear()
         torch.cuda.empty_cache()
