@@ -577,10 +577,12 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
         const int mh_ = m0 + hh * HROWS;
         const int c8 = (n0 + rc8 + 8 > p.N) ? (p.N - 8 - n0 < 0 ? 0 : p.N - 8 - n0) : rc8;
         const bf16_t* rb = Rg + n0 + c8;
+        // rows past M read row M - 1: a 320-wide edge tile whose SECOND half starts at or past M has rmax < 0, and mh_ + rmax is still
+        // M - 1 (round 5: a clamp of `row` to 0 here read up to 128 rows past the end of R — a memory fault when R closes its allocation)
         const int rmax = min(HROWS - 1, p.M - 1 - mh_);
 #pragma unroll
         for (int u = 0; u < RIT; ++u) {
-            int row = min(rrow0 + u * RPP, rmax); if (row < 0) row = 0;
+            const int row = min(rrow0 + u * RPP, rmax);
             rpre[u] = *(const uint4*)(rb + (long)(mh_ + row) * p.ldr);
         }
     };

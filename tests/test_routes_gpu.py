@@ -156,6 +156,15 @@ def test_xl_conv(dev, B, H, W, Cin, Cout, stride, res, temb, expect):
     close(y, conv_ref(x, w, b, stride, (1, 1), tb, R), name=f"xl conv {B}x{H}x{W} {Cin}->{Cout}")
 
 
+def test_xl320_edge_tile_reads_no_residual_past_its_buffer():
+    """tests/xl320_edge_case.py in a child process (a GPU memory fault aborts the process that raised it): the 320-wide tile's second
+    128-row half may start past M; its residual prefetch has to stay inside R even when R closes its allocation."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "xl320_edge_case.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok conv_err" in r.stdout, (r.returncode, r.stdout[-400:], r.stderr[-1200:])
+
+
 def geglu_case(M, F_, K, expect=None):
     dev = torch.device("cuda")
     A = rnd(M, K, seed=1); W = rnd(2 * F_, K, scale=K ** -0.5, seed=2, dtype=torch.float32); b = rnd(2 * F_, seed=3, dtype=torch.float32)

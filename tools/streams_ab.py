@@ -35,6 +35,7 @@ def main():
         n, st = int(f[0]), int(f[1])
         pipe.streams = st
         pipe.fork_chunks = len(f) > 2 and f[2] == "f"        # "192:2:f": also fork ControlNet / UNet encoder inside every chunk
+        pipe.fork_max_scenes = (1 << 30) if (len(f) > 2 and f[2] == "F") else 0      # "48:1:F": ONE chunk with the two branches of a step side by side
         kw = dict(prompt=None, image=cat("bev_map", n), camera_param=None, height=224, width=400, num_inference_steps=args.ddim_steps,
                   guidance_scale=1.0, latents=cat("latents", n), prompt_embeds=cat("prompt_embeds", n),
                   negative_prompt_embeds=cat("negative_prompt_embeds", n), output_type="latent")
@@ -51,7 +52,7 @@ def main():
         if ref is None:
             ref = out[0].float().clone()
         dev_rel = ((out[0].float() - ref).norm() / ref.norm()).item()
-        print(json.dumps({"scenes": n, "streams": st, "fork_chunks": pipe.fork_chunks, "scenes_per_s": round(n / min(ts), 4), "seconds_per_call": [round(t, 3) for t in ts],
+        print(json.dumps({"scenes": n, "streams": st, "fork_chunks": pipe.fork_chunks, "fork_one_chunk": pipe.fork_max_scenes > 0, "scenes_per_s": round(n / min(ts), 4), "seconds_per_call": [round(t, 3) for t in ts],
                           "scene0_vs_first_config_rel": round(dev_rel, 6)}), flush=True)
         pipe._plans.clear()
         torch.cuda.empty_cache()
