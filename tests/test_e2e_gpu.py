@@ -499,6 +499,17 @@ def test_batch_consistency_sd15(dev):
         check(f"batch consistency scene {k}", e, 1e-2)
 
 
+def test_batch_size_sweep_scenes_are_independent(dev):
+    """tools/batch_sweep.py in a child process (round 5: a 24-scene call died of a GPU memory fault in an edge tile no other batch size produced —
+    a fault aborts the process, so the sweep must not share ours).  Sizes around the boundaries that move with B: the fork / join policy (<= 31 scenes),
+    two chunks (>= 32), 144 views (51 tiles + 48 rows at the 7 x 13 level) text-only and as 12 scenes x CFG 2."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "batch_sweep.py"), "--sizes", "5,24,31,33", "--full", "3,12", "--steps", "3", "--tol", "2e-2"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and '"swept": "ok"' in r.stdout, (r.returncode, r.stdout[-600:], r.stderr[-1500:])
+
+
 def test_sample_driver_cond_on_view_end_to_end(dev, tmp_path):
     """tools/sample.py --cond-on-view = demo/run_cond_on_view.py on the GPU: the given-view pipeline class, UniPC (what build_pipe installs),
     the ground-truth views encoded by the HIP VAE encoder, generation ti with view ti given.  Checks: files, that the driver's generation 0 is

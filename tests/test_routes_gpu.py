@@ -156,7 +156,7 @@ def test_xl_conv(dev, B, H, W, Cin, Cout, stride, res, temb, expect):
     close(y, conv_ref(x, w, b, stride, (1, 1), tb, R), name=f"xl conv {B}x{H}x{W} {Cin}->{Cout}")
 
 
-def test_xl320_edge_tile_reads_no_residual_past_its_buffer():
+def test_xl320_edge_tile_reads_no_residual_past_its_buffer(dev):
     """tests/xl320_edge_case.py in a child process (a GPU memory fault aborts the process that raised it): the 320-wide tile's second
     128-row half may start past M; its residual prefetch has to stay inside R even when R closes its allocation."""
     import os, subprocess, sys
