@@ -118,11 +118,27 @@ class Pool:
     """Exact-size free-list of device buffers; the program's ops alias freed buffers, which is safe because
     a program executes in order on one stream."""
 
+    # Debugging aid, off in the product (tools/batch_sweep.py --guard sets it): every buffer CLOSES a device segment of its own (the caching
+    # allocator maps a request of >= 10 MiB as one segment of exactly the 2 MiB-rounded size), so a kernel that reads or writes past the end
+    # of a buffer runs into unmapped addresses and faults instead of quietly touching its neighbour.  Round 5's edge-tile over-read
+    # (gemm_xl.hip fetch_residual) sat in the kernel for two rounds because something was always mapped behind the residual.
+    guard = False
+    GUARD_SEGMENT = 12 << 20
+
     def __init__(self, device, dtype=BF16):
         self.device = device
         self.dtype = dtype                 # default element type of a buffer: the plan's 16-bit activation type
         self.free_list: Dict[Tuple, List[torch.Tensor]] = {}
         self.total_bytes = 0
+
+    def _alloc(self, n: int, dtype) -> torch.Tensor:
+        if not Pool.guard:
+            return torch.empty(n, dtype=dtype, device=self.device)
+        nbytes = n * torch.empty(0, dtype=dtype).element_size()
+        seg = max(Pool.GUARD_SEGMENT, -(-nbytes // (2 << 20)) * (2 << 20))
+        raw = torch.empty(seg, dtype=torch.uint8, device=self.device)
+        off = (seg - nbytes) & ~15         # 16-byte aligned start (vector loads, LDS-DMA): at most 15 bytes of slack behind the buffer
+        return raw[off:off + nbytes].view(dtype)
 
     def get(self, shape, dtype=None) -> torch.Tensor:
         dtype = dtype or self.dtype
@@ -134,7 +150,7 @@ class Pool:
         if fl:
             return fl.pop().view(*shape)
         self.total_bytes += n * torch.empty(0, dtype=dtype).element_size()
-        return torch.empty(n, dtype=dtype, device=self.device).view(*shape)
+        return self._alloc(n, dtype).view(*shape)
 
     def put(self, t: Optional[torch.Tensor]):
         if t is None:

@@ -437,3 +437,29 @@ def test_forked_step_branches_share_no_buffer(tiny):
             assert not (w_cn & storages(sp.step_ops[a:b], False)), "the encoder branch touches a buffer the ControlNet writes"
             assert not (w_enc & storages(sp.step_ops[:a], False)), "the ControlNet touches a buffer the encoder branch writes"
     assert torch.equal(outs["forked_linear"], outs["linear"]) and torch.equal(outs["forked_enc_first"], outs["linear"])
+
+
+def test_pool_guard_mode_puts_every_buffer_at_the_end_of_its_own_storage():
+    """engine.Pool.guard (a debugging aid, tools/batch_sweep.py --guard): each buffer ends within 15 bytes of the end of a storage of its own,
+    16-byte aligned, and goes through the free list like any other; off by default."""
+    from magicdrive_amd.engine import Pool
+    assert Pool.guard is False
+    Pool.guard = True
+    try:
+        pool = Pool(torch.device("cpu"))
+        a = pool.get((7, 13, 40))
+        b = pool.get((3, 5), torch.float32)
+        for t in (a, b):
+            es = t.element_size()
+            end = t.storage_offset() * es + t.numel() * es
+            total = t.untyped_storage().nbytes()
+            assert total >= Pool.GUARD_SEGMENT and total % (2 << 20) == 0
+            assert 0 <= total - end < 16 and (t.storage_offset() * es) % 16 == 0
+            assert t.is_contiguous()
+        assert a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr()
+        big = pool.get((16 << 20,))                                  # 32 MiB of bf16: the segment grows with the buffer
+        assert big.untyped_storage().nbytes() == 32 << 20 and big.storage_offset() == 0
+        pool.put(a)
+        assert pool.get((7 * 13 * 40,)).data_ptr() == a.data_ptr()    # recycled, not re-allocated
+    finally:
+        Pool.guard = False
