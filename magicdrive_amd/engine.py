@@ -110,6 +110,15 @@ class PackedNet:
         b = self._get(("foldb", b1_scale), keys, lambda w2, b2, w1, b1: (w2 @ (b1 * b1_scale) + b2).contiguous().to(F32))
         return w, b
 
+    def gated_affine(self, w1key, b1key, alpha_key: Optional[str], b1_scale: float = 1.0):
+        """y = tanh(alpha) * (W1 x + s b1) (GatedConnector, blocks.py:24-32) -> (diag(tanh alpha) W1) x + tanh(alpha) s b1, folded in fp32;
+        alpha_key None = the identity connector (zero_module_type "none"): W1 x + s b1."""
+        keys = [w1key, b1key] + ([alpha_key] if alpha_key else [])
+        gate = lambda a: torch.tanh(a[0].reshape(-1)) if a else None
+        w = self._get(("gatew", b1_scale), keys, lambda w1, b1, *a: (w1 if not a else gate(a)[:, None] * w1).contiguous().to(self.dtype))
+        b = self._get(("gateb", b1_scale), keys, lambda w1, b1, *a: (b1 * b1_scale if not a else gate(a) * b1 * b1_scale).contiguous().to(F32))
+        return w, b
+
     def table(self, key):                              # 2-D bf16 table (class tokens)
         return self._get("table", [key], lambda t: t.contiguous().to(self.dtype))
 
@@ -390,8 +399,12 @@ class Builder:
             self.pool.put(n4)
             # connector(to_out(o_l + o_r) + 2 b_o) is one affine map: fold it at pack time,
             #   W = W_c W_o ,  b = W_c (2 b_o) + b_c     (one GEMM instead of two per block; fp32 fold, bf16 weights)
-            wf, bf_ = net.folded_affine(pre + "connector.weight", pre + "connector.bias", pre + "attn4.to_out.0.weight", pre + "attn4.to_out.0.bias",
-                                        2.0 if self.nattn == "add" else 1.0)      # concat / self: ONE attention per view, its out-bias once
+            bo_scale = 2.0 if self.nattn == "add" else 1.0                        # concat / self: ONE attention per view, its out-bias once
+            if net.has(pre + "connector.weight"):                                 # zero_module_type zero_linear (blocks.py:81-83)
+                wf, bf_ = net.folded_affine(pre + "connector.weight", pre + "connector.bias", pre + "attn4.to_out.0.weight", pre + "attn4.to_out.0.bias", bo_scale)
+            else:                                                                 # gated: tanh(alpha) per channel (blocks.py:24-32, 84-85); none: identity (:86-88)
+                wf, bf_ = net.gated_affine(pre + "attn4.to_out.0.weight", pre + "attn4.to_out.0.bias",
+                                           pre + "connector.alpha" if net.has(pre + "connector.alpha") else None, bo_scale)
             h3 = self.gemm(ao4, wf, C, bias=bf_, R=h2, name=name + ".attn4.out+connector")
             self.pool.put(ao4); self.pool.put(h2)
         else:

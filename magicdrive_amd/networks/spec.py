@@ -167,7 +167,7 @@ def _attn(sh, pre, c, ctx):
     sh[pre + "to_out.0.weight"] = (c, c); sh[pre + "to_out.0.bias"] = (c,)
 
 
-def _transformer(sh, pre, c, cross, multiview):
+def _transformer(sh, pre, c, cross, multiview, zero_module_type="zero_linear"):
     sh[pre + "norm.weight"] = (c,); sh[pre + "norm.bias"] = (c,)
     sh[pre + "proj_in.weight"] = (c, c, 1, 1); sh[pre + "proj_in.bias"] = (c,)
     b = pre + "transformer_blocks.0."
@@ -181,7 +181,14 @@ def _transformer(sh, pre, c, cross, multiview):
     if multiview:
         sh[b + "norm4.weight"] = (c,); sh[b + "norm4.bias"] = (c,)
         _attn(sh, b + "attn4.", c, c)
-        sh[b + "connector.weight"] = (c, c); sh[b + "connector.bias"] = (c,)
+        # BasicMultiviewTransformerBlock.__init__ (blocks.py:81-90): zero_linear -> nn.Linear, gated -> GatedConnector (one alpha per channel,
+        # blocks.py:24-32), none -> identity (no tensors)
+        if zero_module_type == "zero_linear":
+            sh[b + "connector.weight"] = (c, c); sh[b + "connector.bias"] = (c,)
+        elif zero_module_type == "gated":
+            sh[b + "connector.alpha"] = (c,)
+        elif zero_module_type != "none":
+            raise TypeError(f"Unknown zero module type: {zero_module_type}")          # the reference's error (blocks.py:89-90)
     sh[pre + "proj_out.weight"] = (c, c, 1, 1); sh[pre + "proj_out.bias"] = (c,)
 
 
@@ -198,13 +205,13 @@ def _encoder(sh, cfg, multiview: bool):
         for j in range(L):
             _resnet(sh, f"down_blocks.{i}.resnets.{j}.", cin if j == 0 else out, out, temb)
             if typ.startswith("CrossAttn"):
-                _transformer(sh, f"down_blocks.{i}.attentions.{j}.", out, cross, multiview)
+                _transformer(sh, f"down_blocks.{i}.attentions.{j}.", out, cross, multiview, cfg.get("zero_module_type", "zero_linear"))
         if i != len(boc) - 1:
             sh[f"down_blocks.{i}.downsamplers.0.conv.weight"] = (out, out, 3, 3)
             sh[f"down_blocks.{i}.downsamplers.0.conv.bias"] = (out,)
     c = boc[-1]
     _resnet(sh, "mid_block.resnets.0.", c, c, temb)
-    _transformer(sh, "mid_block.attentions.0.", c, cross, multiview)
+    _transformer(sh, "mid_block.attentions.0.", c, cross, multiview, cfg.get("zero_module_type", "zero_linear"))
     _resnet(sh, "mid_block.resnets.1.", c, c, temb)
 
 
@@ -223,7 +230,7 @@ def unet_param_shapes(cfg) -> "OrderedDict[str, Tuple[int, ...]]":
             rin = prev if j == 0 else out
             _resnet(sh, f"up_blocks.{i}.resnets.{j}.", rin + skip, out, temb)
             if typ.startswith("CrossAttn"):
-                _transformer(sh, f"up_blocks.{i}.attentions.{j}.", out, cross, True)
+                _transformer(sh, f"up_blocks.{i}.attentions.{j}.", out, cross, True, cfg.get("zero_module_type", "zero_linear"))
         if i != len(boc) - 1:
             sh[f"up_blocks.{i}.upsamplers.0.conv.weight"] = (out, out, 3, 3)
             sh[f"up_blocks.{i}.upsamplers.0.conv.bias"] = (out,)
@@ -290,8 +297,11 @@ def random_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int, dtype=torch
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     for name, shape in shapes.items():
         g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 31))
-        if any(m in name for m in ZERO_INIT_MARKERS) and not any(name.endswith(m) for m in _FULL_SCALE_ZERO_INIT):
+        if any(m in name for m in ZERO_INIT_MARKERS) and not any(name.endswith(m) for m in _FULL_SCALE_ZERO_INIT) and not name.endswith(".connector.alpha"):
             t = torch.randn(shape, generator=g) * 0.02
+        elif name.endswith(".connector.alpha"):
+            # GatedConnector: tanh(alpha) scales the cross-view branch; the reference's zero init would switch the branch off in a parity test
+            t = (torch.rand(shape, generator=g) * 2 - 1) * 1.5
         elif name.endswith("_class_tokens") or name.startswith("uncond_cam"):
             t = torch.randn(shape, generator=g)
         elif ".norm" in name or "conv_norm_out." in name or name.endswith("norm.weight") or name.endswith("norm.bias"):

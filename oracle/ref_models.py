@@ -16,7 +16,7 @@ def build_reference(cfg, unet_sd, cn_sd, img_size=(224, 400)):
         norm_num_groups=cfg["norm_num_groups"])
     unet = ns.unet_mv.UNet2DConditionModelMultiview.from_unet_2d_condition(
         base, neighboring_view_pair=cfg["neighboring_view_pair"], neighboring_attn_type=cfg.get("neighboring_attn_type", "add"),
-        zero_module_type="zero_linear", img_size=list(img_size))
+        zero_module_type=cfg.get("zero_module_type", "zero_linear"), img_size=list(img_size))
     cn = cfg["controlnet"]; bb = cn["bbox"]
     extra = {}
     if cn.get("map_embedder_cls"):          # configs/exp/272x736.yaml:15-22

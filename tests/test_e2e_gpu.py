@@ -415,6 +415,31 @@ def test_module_api_forward_neighboring_attn_modes(dev, mode):
     assert eo > 2 * e
 
 
+@pytest.mark.parametrize("mode", ["gated", "none"])
+def test_module_api_forward_zero_module_types(dev, mode):
+    """zero_module_type gated (GatedConnector, blocks.py:24-32) / none on the GPU: tanh(alpha) folded into attn4.to_out when the weights are
+    packed; through the reference module signatures vs outputs of the REAL reference UNet (tests/golden/tiny_forward_zmod.pt)."""
+    import os
+    from magicdrive_amd.networks.unet_2d_condition_multiview import UNet2DConditionModelMultiview
+    from magicdrive_amd.networks.unet_addon_rawbox import BEVControlNetModel
+    G = torch.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_forward_zmod.pt"))
+    cfg = dict(spec.TINY_CONFIG); cfg["zero_module_type"] = mode
+    unet = UNet2DConditionModelMultiview.from_config(cfg, 0).to(dev); cn = BEVControlNetModel.from_config(cfg, 1).to(dev)
+    sc = scene(cfg, 1, 3)
+    lat = torch.randn(1, 6, 4, 28, 50, generator=torch.Generator().manual_seed(G["lat_seed"]))
+    t = G["timesteps"]
+    down, mid, ctx = cn(lat.to(dev), t.to(dev), sc["camera_param"].to(dev), {k: v.to(dev) for k, v in sc["bboxes_3d_data"].items()},
+                        sc["prompt_embeds"].to(dev), sc["bev_map"].to(dev), return_dict=False)
+    eps = unet(lat.reshape(-1, 4, 28, 50).to(dev), t.repeat_interleave(6).to(dev), encoder_hidden_states=ctx,
+               down_block_additional_residuals=down, mid_block_additional_residual=mid).sample
+    torch.cuda.synchronize()
+    e = max(rel_l2(eps[i], G["eps_" + mode][i].float()) for i in range(6))
+    eo = min(rel_l2(eps[i], G["eps_" + ("none" if mode == "gated" else "gated")][i].float()) for i in range(6))
+    print(f"[zero_module_type={mode} vs reference golden] eps per-view max rel {e:.4f} (vs the other variant's golden: {eo:.4f})")
+    check(f"zero_module_type={mode}: eps per view", e, 3.6e-2)
+    assert eo > 2 * e
+
+
 def test_real_size_ddim_loop_sd15(dev):
     """SD-1.5-size sampler loop (the bench workload: text-only, camera_param=None => CFG off) through the drop-in
     pipeline vs the CPU oracle on the same bf16-rounded weights.  2 DDIM steps by default (CPU oracle ~5 s/step); the full 50-step

@@ -252,6 +252,27 @@ def test_golden_forward_neighboring_attn_modes(tiny, mode):
     assert rel_l2(e, G["eps_" + other].float()) > 1e-2 and rel_l2(e, e_add) > 1e-2
 
 
+@pytest.mark.parametrize("mode", ["gated", "none"])
+def test_golden_forward_zero_module_types(tiny, mode):
+    """zero_module_type gated (GatedConnector: tanh(alpha) * x, blocks.py:24-32, 84-85) / none (identity, :86-88): the oracle vs the real
+    reference UNet (tools/make_golden.py zmod); the variants differ from each other by far more than the comparison tolerance."""
+    cfg0, _, csd = tiny
+    G = torch.load(os.path.join(GOLD, "tiny_forward_zmod.pt"))
+    cfg = dict(cfg0); cfg["zero_module_type"] = mode
+    usd = spec.random_state_dict(spec.unet_param_shapes(cfg), 0)
+    assert (mode == "gated") == any(k.endswith("connector.alpha") for k in usd) and not any(k.endswith("connector.weight") for k in usd)
+    sc = scene(cfg, 1, 3)
+    lat = torch.randn(1, 6, 4, 28, 50, generator=torch.Generator().manual_seed(G["lat_seed"]))
+    t = G["timesteps"]
+    with torch.no_grad():
+        d, m, ctx = D.controlnet_forward(csd, cfg, lat, t, sc["camera_param"], sc["bboxes_3d_data"], sc["prompt_embeds"], sc["bev_map"])
+        e = D.unet_forward(usd, cfg, lat.reshape(-1, 4, 28, 50), t.repeat_interleave(6), ctx, d, m)
+    assert rel_l2(e, G["eps_" + mode].float()) < 2e-3          # golden eps stored as fp16
+    assert rel_l2(e, G["eps_" + ("none" if mode == "gated" else "gated")].float()) > 1e-2
+    with pytest.raises(TypeError):                              # the reference's error for an unknown type (blocks.py:89-90)
+        spec.unet_param_shapes(dict(cfg0, zero_module_type="bogus"))
+
+
 # ---------------------------------------------------------------- live reference (authoring container only)
 needs_ref = pytest.mark.skipif(not refshim.available(), reason="/root/reference not present")
 

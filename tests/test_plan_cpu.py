@@ -235,6 +235,32 @@ def test_unet_plan_neighboring_attn_modes(tiny, mode):
     assert min(rel_l2(up.out_nchw[i], G["eps_" + other][i].float()) for i in range(6)) > 2 * per_view
 
 
+@pytest.mark.parametrize("mode", ["gated", "none"])
+def test_unet_plan_zero_module_types(tiny, mode):
+    """zero_module_type gated / none: the connector folded into attn4.to_out at pack time (engine.PackedNet.gated_affine), the UNet op graph
+    in the CPU interpreter vs the real reference's output (tests/golden/tiny_forward_zmod.pt)."""
+    cfg0, _, csd, _, cn = tiny
+    G = torch.load(os.path.join(GOLD, "tiny_forward_zmod.pt"))
+    cfg = dict(cfg0); cfg["zero_module_type"] = mode
+    usd = spec.random_state_dict(spec.unet_param_shapes(cfg), 0)
+    un = PackedNet(usd, CPU)
+    sc = scene(cfg, 1, 3)
+    lat = torch.randn(1, 6, 4, 28, 50, generator=torch.Generator().manual_seed(G["lat_seed"]))
+    t = G["timesteps"]
+    with torch.no_grad():
+        d, m, ctx = D.controlnet_forward(csd, cfg, lat, t, sc["camera_param"], sc["bboxes_3d_data"], sc["prompt_embeds"], sc["bev_map"])
+    up = DN.UNetPlan(cfg, un, CPU, 6, ctx.shape[1], (28, 50))
+    up.sample_nchw.copy_(lat.reshape(-1, 4, 28, 50)); up.temb.t.copy_(t.float().repeat_interleave(6)); up.ctx.copy_(ctx)
+    for dst, src in zip(up.res_in, d):
+        dst.copy_(src)
+    up.mid_in.copy_(m)
+    plan_interp.run(up.ops)
+    per_view = max(rel_l2(up.out_nchw[i], G["eps_" + mode][i].float()) for i in range(6))
+    assert per_view < 3e-2, per_view
+    other = "none" if mode == "gated" else "gated"
+    assert min(rel_l2(up.out_nchw[i], G["eps_" + other][i].float()) for i in range(6)) > 2 * per_view
+
+
 def test_module_plans_hires_plus_map_encoder(tiny):
     """configs[3] shape: 54x96 latents + the ...Plus map encoder (adaptive average pool as one GEMM over pixels) through the op
     graphs vs the real reference's outputs."""

@@ -24,7 +24,7 @@ Fixtures
   tiny_vae_decode.pt  diffusers AutoencoderKL.decode (the reference's `vae`, pipeline_bev_controlnet.py:100-112) of a tiny decoder config
                     (spec.VAE_TINY_CONFIG, seeded weights) on 2 latents of 7x13.
 
-`python tools/make_golden.py unipc` / `... hires` / `... given` / `... vae` / `... nattn` regenerate only that fixture.
+`python tools/make_golden.py unipc` / `... hires` / `... given` / `... vae` / `... nattn` / `... zmod` regenerate only that fixture.
 
 Round 4:
   tiny_pipeline_given_view_unipc.pt `... givenunipc`  the given-view pipeline with UniPC — the scheduler demo/run_cond_on_view.py's
@@ -47,6 +47,7 @@ weights the HIP model holds — so that the fixture measures arithmetic, not wei
   tiny_forward_424x800.pt `... res424`   configs/exp/424x800abox0.1_nockpt.yaml:15-17: 53x100 latents, map_size [8, 400, 400] through the
                     plain BEVControlNetConditioningEmbedding (tiny width).
   tiny_forward_nattn.pt  the reference UNet forward with neighboring_attn_type = concat and = self (same tiny weights and inputs).
+  tiny_forward_zmod.pt   the reference UNet forward with zero_module_type = gated (GatedConnector) and = none (identity connector).
 """
 import copy
 import time
@@ -296,6 +297,27 @@ def nattn_fixture(out_dir, cfg0, usd, csd, meta, hw=(28, 50)):
     torch.save(out, os.path.join(out_dir, "tiny_forward_nattn.pt"))
 
 
+def zmod_fixture(out_dir, cfg0, csd, meta, hw=(28, 50)):
+    """zero_module_type "gated" (GatedConnector: tanh(alpha) * x, blocks.py:24-32, 84-85) and "none" (identity connector, :86-88): the UNet
+    forward of the REAL reference; every tensor the three variants share has the same seeded values (spec.random_state_dict seeds per name)."""
+    out = {"meta": meta, "lat_seed": 17, "timesteps": torch.tensor([400])}
+    for mode in ("gated", "none"):
+        cfg = dict(cfg0); cfg["zero_module_type"] = mode
+        usd = spec.random_state_dict(spec.unet_param_shapes(cfg), 0)
+        ns, unet, cnet = ref_models.build_reference(cfg, usd, csd)
+        sc = scene(cfg, 1, 3, hw)
+        lat = torch.randn(1, 6, 4, *hw, generator=torch.Generator().manual_seed(17))
+        t = out["timesteps"]
+        with torch.no_grad():
+            d, m, ctx = cnet(lat, t, sc["camera_param"], sc["bboxes_3d_data"], sc["prompt_embeds"], sc["bev_map"], return_dict=False)
+            e = unet(lat.reshape(-1, 4, *hw), t.repeat_interleave(6), encoder_hidden_states=ctx,
+                     down_block_additional_residuals=d, mid_block_additional_residual=m).sample
+        out["eps_" + mode] = e.half()
+        out["unet_checksum_" + mode] = checksum(usd)
+        print("tiny_forward_zmod", mode, "eps std", e.std().item())
+    torch.save(out, os.path.join(out_dir, "tiny_forward_zmod.pt"))
+
+
 def _trace_cb(store, every):
     def cb(i, t, latents):
         if (i + 1) % every == 0:
@@ -447,6 +469,8 @@ def main():
         return vae_encode_fixture(out_dir)
     if sys.argv[1:] == ["nattn"]:
         return nattn_fixture(out_dir, cfg, usd, csd, meta)
+    if sys.argv[1:] == ["zmod"]:
+        return zmod_fixture(out_dir, cfg, csd, meta)
     if sys.argv[1:] in (["res272"], ["res424"]):
         return resolution_fixture(out_dir, cfg, usd, meta, "272x736" if sys.argv[1] == "res272" else "424x800")
 
