@@ -209,7 +209,14 @@ def cpu_baseline(cfg, n_steps_timed=3):
     rp = os.path.join(ROOT, "profiles", "r04_cpu_reference_vs_port.json")
     if os.path.exists(rp):
         with open(rp) as f:
-            out["reference_vs_port_authoring_container"] = dict(json.load(f), source="profiles/r04_cpu_reference_vs_port.json")
+            rvp = json.load(f)
+        out["reference_vs_port_authoring_container"] = dict(rvp, source="profiles/r04_cpu_reference_vs_port.json")
+        ratio = rvp.get("reference_over_port") or (rvp["port_s_per_step"] / rvp["reference_s_per_step"] if rvp.get("reference_s_per_step") else None)
+        if ratio and ref_dt is None:
+            # DERIVED, not measured here: this host's port rate x the reference / port speed ratio measured once in the authoring container
+            # (same threads, scene and weights) — what the real reference would do on these cores if the ratio carries over
+            out["reference_estimate_scenes_per_s"] = {"value": round(out["value"] * ratio, 6), "derived": True,
+                                                      "how": f"port value x {ratio:.3f} (reference / port speed ratio of profiles/r04_cpu_reference_vs_port.json, authoring container)"}
     return out
 
 
@@ -344,7 +351,8 @@ def main():
             row = (mine[si] if res.shape[0] == n_total else si)
             got = res[row:row + 1].float().to(one.device)
             c_ = max(((got[:, v] - one[:, v]).norm() / (one[:, v].norm() + 1e-20)).item() for v in range(one.shape[1]))
-            assert c_ < 5e-2, f"scene {si} of the {b}-scene batch differs from the 1-scene call by {c_:.3e} (per-view rel L2)"
+            # measured 1.6e-3 after 50 steps (bf16; BENCH_r05 batch_consistency_rel): the limit leaves room for box-to-box route changes, not for a bug
+            assert c_ < 1e-2, f"scene {si} of the {b}-scene batch differs from the 1-scene call by {c_:.3e} (per-view rel L2)"
             consistency = max(consistency, c_)
     latency_1 = None
     if not args.no_consistency_check and side:
@@ -510,6 +518,13 @@ def main():
                                          for k, v in fam.items()}
         tot_ms = sum(v["ms"] for v in compute.values()); tot_fl = sum(v["flops"] for v in compute.values())
         out["roofline"]["attn_conv_gemm_tflops"] = round(tot_fl / (tot_ms * 1e-3) / 1e12, 2)
+        # FLOP-based ("useful") fraction of the dense peak over the attention + 3x3-conv launches: algorithmic FLOPs (no padded MFMA rows: the
+        # d = 40 attention multiplies 48 / 64-row tiles, which the MfmaUtil COUNTER above books as busy) / their time — the north-star's ">= 60 % on
+        # the attention + conv blocks" read against work done, beside the counter figure
+        ac = {k: v for k, v in fam.items() if v["flops"] > 0 and (k.startswith("attn") or k == "gemm_conv_kernel<conv>")}
+        ac_ms = sum(v["ms"] for v in ac.values()); ac_fl = sum(v["flops"] for v in ac.values())
+        out["roofline"]["useful_frac_attn_conv"] = round(ac_fl / (ac_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if ac_ms > 0 else None
+        out["roofline"]["useful_frac_attn_conv_gemm"] = round(tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if tot_ms > 0 else None
         if args.ops_json:
             os.makedirs(os.path.dirname(args.ops_json) or ".", exist_ok=True)
             with open(args.ops_json, "w") as f:

@@ -682,14 +682,19 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
             const int total = HROWS * cpr;
             const int bfirst = n0 / cs;
             const int tfirst = n0 - bfirst * cs;
-            if (NTH % (BN >> 1) == 0 && !geglu) {        // (GEGLU halves the output width: cpr below is BNo >> 1, RPP2 assumes BN >> 1 — xl_supported keeps GEGLU out of col_split, this keeps the branch honest)
+            bool fast_done = false;
+            // compile-time part first: instantiations whose width does not divide the workgroup never carry the fast body; the
+            // run-time !geglu keeps the branch honest (GEGLU halves the output width: cpr below is BNo >> 1, RPP2 assumes BN >> 1 — xl_supported
+            // keeps GEGLU out of col_split anyway)
+            if constexpr (NTH % (BN >> 1) == 0) if (!geglu) {
+                fast_done = true;
                 // (round 4) a thread owns ONE column pair for all its rows: image / token / validity of the pair are resolved once (the
                 // generic walk below divides and searches per element pair: ~3 k scalar-ish instructions per thread and tile beside a 16 us
                 // main loop at K = 640 — the level-1/2 V^T projections ran at 520-690 TFLOP/s, their q/k siblings at 970-1130), then
                 // batches of eight LDS reads followed by eight stores.
-                constexpr int RPP2 = NTH / ((BN >> 1) > NTH ? NTH : (BN >> 1));   // rows per pass (4 at 256 columns)
+                constexpr int RPP2 = NTH / (BN >> 1);                    // rows per pass (4 at 256 columns)
                 constexpr int UB = 8;
-                static_assert(NTH % (BN >> 1) != 0 || (HROWS / RPP2) % UB == 0, "col_split fast epilogue: the row walk has no remainder handling");
+                static_assert((HROWS / RPP2) % UB == 0, "col_split fast epilogue: the row walk has no remainder handling");
                 const int c2 = (tid % cpr) * 2, r0 = tid / cpr;
                 int b = bfirst, t = tfirst + c2;
                 while (t >= cs) { t -= cs; ++b; }
@@ -717,7 +722,8 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
                         }
                     }
                 }
-            } else {
+            }
+            if (!fast_done) {
 #pragma unroll 1
             for (int idx = tid; idx < total; idx += NTH) {
                 const int row = idx / cpr, c2 = (idx - row * cpr) * 2;

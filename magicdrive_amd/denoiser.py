@@ -19,7 +19,7 @@ from . import _lib as L
 from . import ops as O
 from . import packing as PK
 from .networks import spec
-from .engine import Act, Builder, PackedNet, Pool, TembTable, build_context_kv, level_sizes
+from .engine import Act, Builder, PackedNet, Pool, TembTable, build_context_kv, level_sizes, skip_geometry
 
 BF16, F32 = torch.bfloat16, torch.float32
 CIN_PAD = 8      # latent channels (4) zero-padded so conv_in meets the MFMA path's Cin % 8 == 0
@@ -314,26 +314,34 @@ class SamplerPlan:
             bld.pool = Pool(device, self.dtype)
             bld.ws = torch.empty_like(bld.ws)
         c0 = cfg["block_out_channels"][0]
+        # The decoder's concat buffers [x | skip] exist before the UNet encoder runs: the mid block writes its output into the first one's x half,
+        # and each zero-conv below writes `skip + ControlNet residual` straight into its concat's skip half — no concat copy is left in the step
+        # (round 5: 13 per step).  The reference adds the residuals out of place (unet_2d_condition_multiview.py:464-488) and
+        # concatenates in every up-block layer (unet_2d_blocks.py:1948-1951): same values, one pass instead of three.
+        cats = bld.decoder_concats(unet, B, cfg["block_out_channels"][-1], skip_geometry(cfg, h, w))
         u0 = bld.new(B, h, w, c0)
         bld.emit(O.Conv(self.x_in, unet.conv_cin_padded("conv_in.weight", CIN_PAD), u0.bhwc, bias=unet.vec("conv_in.bias"), ws=bld.ws, name="unet.conv_in"))
-        u_mid, u_skips = bld.encoder(unet, u0, self.temb_un, self.kv_un, "unet")
+        u_mid, u_skips = bld.encoder(unet, u0, self.temb_un, self.kv_un, "unet", mid_out=cats[0].channels(0, cfg["block_out_channels"][-1]))
         self.fork_at = (n_cn, len(bld.ops)) if fork else None   # step_ops[:a] ControlNet | [a:b] UNet conv_in + encoder | [b:] zero-convs, decoder, scheduler
         if fork:                                                # behind the join the tail may reuse what either branch has freed
             for k_, v_ in pool_cn.free_list.items():
                 bld.pool.free_list.setdefault(k_, []).extend(v_)
             bld.pool.total_bytes += pool_cn.total_bytes
-        # zero-convs accumulate straight into the UNet skips / mid (unet_addon_rawbox.py:882-910 +
-        # unet_2d_condition_multiview.py:464-488); the adds happen after the UNet encoder+mid consumed the
-        # un-added tensors, exactly like the reference's out-of-place `sample + residual`.
-        assert len(cn_skips) == len(u_skips)
+        # zero-convs (unet_addon_rawbox.py:882-910 + unet_2d_condition_multiview.py:464-488): after the UNet encoder + mid consumed the un-added
+        # tensors, exactly like the reference's out-of-place `sample + residual`; skip k (encoder order) is popped by decoder layer n - 1 - k
+        assert len(cn_skips) == len(u_skips) == len(cats)
         for k, (cs, us) in enumerate(zip(cn_skips, u_skips)):
             key = f"controlnet_down_blocks.{k}."
-            bld.emit(O.Gemm(cs.tok, cn.lin(key + "weight", conditioning_scale), us.tok, bias=cn.vec(key + "bias", conditioning_scale), R=us.tok, name=f"zero_conv.{k}"))
+            cat = cats[len(cats) - 1 - k]
+            assert (cat.H, cat.W) == (us.H, us.W)
+            dst = cat.channels(cat.C - us.C, cat.C)
+            bld.emit(O.Gemm(cs.tok, cn.lin(key + "weight", conditioning_scale), dst.tok, bias=cn.vec(key + "bias", conditioning_scale), R=us.tok, name=f"zero_conv.{k}"))
             bld.free(cs)
+            bld.free(us)
         bld.emit(O.Gemm(cn_mid.tok, cn.lin("controlnet_mid_block.weight", conditioning_scale), u_mid.tok,
                         bias=cn.vec("controlnet_mid_block.bias", conditioning_scale), R=u_mid.tok, name="zero_conv.mid"))
         bld.free(cn_mid)
-        y = bld.decoder(unet, u_mid, u_skips, self.temb_un, self.kv_un, "unet")
+        y = bld.decoder(unet, u_mid, u_skips, self.temb_un, self.kv_un, "unet", cats=cats)
         bld.emit(O.Conv(y.bhwc, unet.conv("conv_out.weight"), self.eps, bias=unet.vec("conv_out.bias"), direct=True, name="unet.conv_out"))
         bld.free(y)
         if scheduler_kind == "ddim":
@@ -355,11 +363,14 @@ class SamplerPlan:
         self.prologue: Optional[L.Program] = None
         self.step: Optional[L.Program] = None
         self.step_cn = self.step_enc = self.step_tail = None    # fork: the three parts of the step as programs of their own
+        self._ev = None                                         # fork: (ready, done) events of launch_step
 
     def compile(self):
         self.prologue = O.build_program(self.prologue_ops)
-        self.step = O.build_program(self.step_ops)
-        if self.fork_at is not None:
+        if self.fork_at is None:
+            self.step = O.build_program(self.step_ops)
+        else:
+            # a forked plan replays its three parts; the linear program (and its hipGraph) is only built if launch_step ever falls back to it
             a, b_ = self.fork_at
             self.step_cn = O.build_program(self.step_ops[:a])
             self.step_enc = O.build_program(self.step_ops[a:b_])
@@ -370,12 +381,17 @@ class SamplerPlan:
         encoder on `main`, joined before the zero-convs — `main` / `side` are torch streams; everything else the caller does stays on `main`."""
         go = (lambda prog, st: prog.launch(st.cuda_stream)) if use_graph else (lambda prog, st: prog.run(st.cuda_stream))
         if self.fork_at is None or side is None:
+            if self.step is None:
+                self.step = O.build_program(self.step_ops)
             go(self.step, main)
             return
-        ready = torch.cuda.Event(); ready.record(main)          # x_in of this step: written by the previous step's scheduler kernel on main
+        if self._ev is None:                                    # two events per plan, re-recorded every step (not two new ones per step)
+            self._ev = (torch.cuda.Event(), torch.cuda.Event())
+        ready, done = self._ev
+        ready.record(main)                                      # x_in of this step: written by the previous step's scheduler kernel on main
         side.wait_event(ready)
         go(self.step_cn, side)
-        done = torch.cuda.Event(); done.record(side)
+        done.record(side)
         go(self.step_enc, main)
         main.wait_event(done)
         go(self.step_tail, main)
@@ -431,6 +447,8 @@ class SamplerPlan:
         """prologue + num_steps denoising steps on the current stream; returns latents (b, n_cam, C, h, w) fp32."""
         if self.prologue is None:
             self.compile()
+        if self.step is None:
+            self.step = O.build_program(self.step_ops)
         st = _stream(self.device)
         self.prologue.run(st)
         for _ in range(self.num_steps):

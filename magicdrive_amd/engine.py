@@ -140,14 +140,20 @@ class Pool:
         self.free_list: Dict[Tuple, List[torch.Tensor]] = {}
         self.total_bytes = 0
 
-    def _alloc(self, n: int, dtype) -> torch.Tensor:
+    @staticmethod
+    def alloc(n: int, dtype, device) -> torch.Tensor:
+        """`n` elements of device memory; under Pool.guard the buffer ENDS at the end of a device segment of its own (the VAE plans, which keep
+        every buffer alive instead of pooling them, allocate through this too)."""
         if not Pool.guard:
-            return torch.empty(n, dtype=dtype, device=self.device)
+            return torch.empty(n, dtype=dtype, device=device)
         nbytes = n * torch.empty(0, dtype=dtype).element_size()
         seg = max(Pool.GUARD_SEGMENT, -(-nbytes // (2 << 20)) * (2 << 20))
-        raw = torch.empty(seg, dtype=torch.uint8, device=self.device)
+        raw = torch.empty(seg, dtype=torch.uint8, device=device)
         off = (seg - nbytes) & ~15         # 16-byte aligned start (vector loads, LDS-DMA): at most 15 bytes of slack behind the buffer
         return raw[off:off + nbytes].view(dtype)
+
+    def _alloc(self, n: int, dtype) -> torch.Tensor:
+        return Pool.alloc(n, dtype, self.device)
 
     def get(self, shape, dtype=None) -> torch.Tensor:
         dtype = dtype or self.dtype
@@ -176,6 +182,19 @@ def level_sizes(h: int, w: int, n_levels: int) -> List[Tuple[int, int]]:
         h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         out.append((h, w))
     return out
+
+
+def skip_geometry(cfg, h: int, w: int) -> List[Tuple[int, int, int]]:
+    """(H, W, C) of the UNet's skip tensors in encoder order (conv_in output, every down-block layer, every downsampler):
+    unet_2d_condition.py:880-905 `down_block_res_samples`."""
+    boc = cfg["block_out_channels"]
+    sizes = level_sizes(h, w, len(boc))
+    geo = [(sizes[0][0], sizes[0][1], boc[0])]
+    for i in range(len(boc)):
+        geo += [(sizes[i][0], sizes[i][1], boc[i])] * cfg["layers_per_block"]
+        if i + 1 < len(boc):
+            geo.append((sizes[i + 1][0], sizes[i + 1][1], boc[i]))
+    return geo
 
 
 class Act:
@@ -436,8 +455,9 @@ class Builder:
         return out
 
     # ---- encoder (shared by ControlNet and UNet) ----------------------------------------------
-    def encoder(self, net, x0: Act, temb, ctx_kv, tag) -> Tuple[Act, List[Act]]:
-        """down blocks + mid block; returns (mid output, skip list incl. conv_in output)."""
+    def encoder(self, net, x0: Act, temb, ctx_kv, tag, mid_out=None) -> Tuple[Act, List[Act]]:
+        """down blocks + mid block; returns (mid output, skip list incl. conv_in output).  `mid_out`: where the mid block's output goes (the x half
+        of the decoder's first concat buffer, decoder_concats)."""
         cfg = self.cfg
         skips = [x0]
         x = x0
@@ -462,13 +482,32 @@ class Builder:
         m = self.resnet(net, "mid_block.resnets.0.", x, temb, f"{tag}.mid.r0")
         m2 = self.transformer2d(net, "mid_block.attentions.0.", m, heads_at(cfg, nblk - 1), ctx_kv, f"{tag}.mid.a0")
         self.free(m)
-        m3 = self.resnet(net, "mid_block.resnets.1.", m2, temb, f"{tag}.mid.r1")
+        m3 = self.resnet(net, "mid_block.resnets.1.", m2, temb, f"{tag}.mid.r1", out=mid_out)
         self.free(m2)
         return m3, skips
 
-    def decoder(self, net, x: Act, skips: List[Act], temb, ctx_kv, tag) -> Act:
+    def decoder_concats(self, net, B: int, x_c: int, skip_geo: Sequence[Tuple[int, int, int]]) -> List[Act]:
+        """The concat buffers [x | skip] of every up-block layer, allocated up front in the order the decoder consumes them.  `skip_geo`: (H, W, C)
+        of the skips in encoder order (the decoder pops from the end); x_c: channels of the mid output.  A caller that owns them lets the PRODUCER of
+        each half write it in place — the mid block / previous layer the x half (as decoder() always does), the ControlNet zero-convs the skip half
+        (SamplerPlan: `skip + residual` lands in the concat, unet_2d_condition_multiview.py:464-488 + unet_2d_blocks.py:1948-1951) — so that the
+        step program holds no concat copy at all (round 5: 13 ew_vec8 copies per step)."""
+        cfg = self.cfg
+        geo = list(skip_geo)
+        cats = []
+        for i in range(len(cfg["block_out_channels"])):
+            for j in range(cfg["layers_per_block"] + 1):
+                H, W, sc = geo.pop()
+                cats.append(self.new(B, H, W, x_c + sc))
+                x_c = net.sd[f"up_blocks.{i}.resnets.{j}.conv1.weight"].shape[0]
+        assert not geo
+        return cats
+
+    def decoder(self, net, x: Act, skips: List[Act], temb, ctx_kv, tag, cats: Optional[List[Act]] = None) -> Act:
         """up blocks (unet_2d_blocks.py:1886-2111) with explicit upsample sizes
-        (unet_2d_condition_multiview.py:491-516), then conv_norm_out + SiLU (:519-521)."""
+        (unet_2d_condition_multiview.py:491-516), then conv_norm_out + SiLU (:519-521).
+        `cats` (decoder_concats): the concat buffers, with every skip half already in place and x = cats[0].channels(0, x.C); `skips` is then only
+        read for its geometry."""
         cfg = self.cfg
         nblk = len(cfg["block_out_channels"])
         rev_heads = [heads_at(cfg, k) for k in reversed(range(nblk))]
@@ -477,7 +516,13 @@ class Builder:
         # x half was a read + write of the whole tensor per layer (round 3: 12 of the step's 24 ew_vec8 launches).  `cat` is allocated
         # before the producer runs; x's only other consumers (the upsampler, conv_norm_out) get a standalone buffer.
         n_layers = cfg["layers_per_block"] + 1
+        placed = cats is not None
+        cats = list(cats) if placed else None
+        skips = list(skips)
         cat = None                                 # concat buffer whose first x.C channels already hold x
+        if placed:
+            cat = cats.pop(0)
+            assert isinstance(x, ActSlice) and x.parent is cat and x.c0 == 0, "with pre-placed concats the mid output must live in cats[0]"
         for i in range(nblk):
             has_attn = cfg["up_block_types"][i].startswith("CrossAttn")
             for j in range(n_layers):
@@ -487,13 +532,15 @@ class Builder:
                     self.emit(O.Ew(L.EW_COPY, x.tok, cat.tok[:, :x.C], name=f"{tag}.u{i}.cat{j}a"))
                     self.free(x)
                 assert cat.C == x.C + s.C and (cat.H, cat.W) == (s.H, s.W)
-                self.emit(O.Ew(L.EW_COPY, s.tok, cat.tok[:, x.C:], name=f"{tag}.u{i}.cat{j}b"))
-                self.free(s)
+                if not placed:
+                    self.emit(O.Ew(L.EW_COPY, s.tok, cat.tok[:, x.C:], name=f"{tag}.u{i}.cat{j}b"))
+                    self.free(s)
                 # where this layer's output goes: into the next layer's concat when that one follows at the same resolution
                 cout = net.sd[f"up_blocks.{i}.resnets.{j}.conv1.weight"].shape[0]
                 nxt = None
                 if j + 1 < n_layers:
-                    nxt = self.new(x.B, x.H, x.W, cout + skips[-1].C)
+                    nxt = cats.pop(0) if placed else self.new(x.B, x.H, x.W, cout + skips[-1].C)
+                    assert (nxt.B, nxt.H, nxt.W, nxt.C) == (x.B, x.H, x.W, cout + skips[-1].C)
                 dst = nxt.channels(0, cout) if nxt is not None else None
                 y = self.resnet(net, f"up_blocks.{i}.resnets.{j}.", cat, temb, f"{tag}.u{i}.r{j}", out=None if has_attn else dst)
                 self.free(cat)
@@ -508,11 +555,13 @@ class Builder:
                 up = self.new(x.B, Ho, Wo, x.C)
                 self.emit(O.Upsample(x.bhwc, up.bhwc, PK.nearest_index(x.H, Ho).to(self.device), PK.nearest_index(x.W, Wo).to(self.device), name=f"{tag}.u{i}.nearest"))
                 self.free(x)
-                cat = self.new(x.B, Ho, Wo, x.C + skips[-1].C)      # the upsampler conv writes the x half of the next block's first concat
+                cat = cats.pop(0) if placed else self.new(x.B, Ho, Wo, x.C + skips[-1].C)      # the upsampler conv writes the x half of the next block's first concat
+                assert (cat.H, cat.W, cat.C) == (Ho, Wo, x.C + skips[-1].C)
                 y = cat.channels(0, x.C)
                 self.emit(O.Conv(up.bhwc, net.conv(uk + "weight"), y.bhwc, bias=net.vec(uk + "bias"), ws=self.ws, name=f"{tag}.u{i}.upconv"))
                 self.free(up)
                 x = y
+        assert not placed or not cats
         y = self.groupnorm(net, "conv_norm_out.", x, self.eps, True, f"{tag}.norm_out")
         self.free(x)
         return y

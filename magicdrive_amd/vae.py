@@ -18,7 +18,7 @@ import torch
 from . import _lib as L
 from . import ops as O
 from . import packing as PK
-from .engine import PackedNet
+from .engine import PackedNet, Pool
 
 BF16, F32 = torch.bfloat16, torch.float32
 ZPAD = 8      # latent channels padded 4 -> 8 so conv_in runs on the MFMA path
@@ -49,7 +49,12 @@ class VaeEncodePlan:
         H16 = net.dtype
 
         def buf(*shape, dtype=H16, zero=False):
-            t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=device)
+            n_ = 1
+            for d_ in shape:
+                n_ *= int(d_)
+            t = Pool.alloc(n_, dtype, device).view(*shape)          # engine.Pool.guard: every buffer closes its own device segment
+            if zero:
+                t.zero_()
             self.keep.append(t)
             return t
 
@@ -137,7 +142,12 @@ class VaeDecodePlan:
         H16 = net.dtype                     # bf16 or fp16: the type the decoder's weights were packed in
 
         def buf(*shape, dtype=H16, zero=False):
-            t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=device)
+            n_ = 1
+            for d_ in shape:
+                n_ *= int(d_)
+            t = Pool.alloc(n_, dtype, device).view(*shape)          # engine.Pool.guard: every buffer closes its own device segment
+            if zero:
+                t.zero_()
             self.keep.append(t)
             return t
 

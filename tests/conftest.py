@@ -21,6 +21,25 @@ def pytest_configure(config):
         helpers.REPORT_ONLY = True
 
 
+@pytest.fixture(autouse=True)
+def _cpu_threads_pinned():
+    """The CPU suite (oracle + op-graph interpreter) is bound by torch's intra-op threads: 91 tests take 3.5 min in one process on an idle
+    8-core box (profiles/r06_cpu_suite_one_process.log) and 20+ when the cores are shared with another job or when torch sizes its pool from a
+    host that has more cores than this container may use.  Pin the pool to the cores this process can run on, and undo whatever a test
+    (or a library it imports) changed before the next one."""
+    import torch
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    want = max(1, min(avail, 16))
+    if torch.get_num_threads() != want:
+        torch.set_num_threads(want)
+    yield
+    if torch.get_num_threads() != want:
+        torch.set_num_threads(want)
+
+
 def pytest_sessionfinish(session, exitstatus):
     if session.config.getoption("--parity-report", default=False):
         print("\n" + "=" * 100 + "\n  --parity-report: tolerance assertions were DISABLED for this session (numbers in the parity log).\n"

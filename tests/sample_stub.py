@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE for tests/test_distributed.py::test_sample_driver_two_ranks_gloo: a stand-in for the HIP pipeline that tools/sample.py loads
-through its --pipe-factory hook, so the driver's multi-rank control flow (batch j -> rank j mod N, seed + rank, the per-batch exchange, rank 0's
+through its --pipe-factory hook, so the driver's multi-rank control flow (batch j -> rank j mod N, the reference's two seeding branches, the per-batch exchange, rank 0's
 index) runs under gloo on a box without GPUs.  It samples nothing: a view's "image" is a 4 x 6 uint8 picture filled with a value derived from
 the generator's seed, the camera index and the scene's BEV map, so a test can tell which rank / seed / scene produced a file."""
 import numpy as np

@@ -152,9 +152,12 @@ def _run_sample_driver(tmp_path, world, out_name, extra=()):
 
 def test_sample_driver_two_ranks_gloo(tmp_path):
     """`torchrun tools/sample.py` = the reference's val_set_gen.py flow (perception/data_prepare/val_set_gen.py:71-161): batch j ->
-    rank j mod 2, generator seeded `seed + rank`, one all_gather_object per batch, every file written exactly once (by its rank, or — with
-    --gather-images — by rank 0), rank 0's index names rank and seed of every scene.  Five scenes in batches of two: rank 0 takes batches 0 and 2,
-    rank 1 batch 1 and an EMPTY third round (it still has to join the collective)."""
+    rank j mod 2, one all_gather_object per batch, every file written exactly once (by its rank, or — with --gather-images — by rank 0), rank 0's
+    index names rank and seed of every scene.  Five scenes in batches of two: rank 0 takes batches 0 and 2, rank 1 batch 1 and an EMPTY third round
+    (it still has to join the collective).
+    Seeding: default = `manual_seed(cfg.seed)` per batch on EVERY rank (magicdrive/misc/test_utils.py:233-238): a scene's pictures must
+    not depend on the world size or on the rank its batch lands on; runner.validation_seed_global=true = one generator per rank seeded seed + rank
+    before the loop, a local seed drawn per batch (val_set_gen.py:83-87, test_utils.py:184-188, 224-232)."""
     import json
     gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "sample_preprocess.pt"), weights_only=False)
     os.makedirs(tmp_path / "data"); os.makedirs(tmp_path / "ckpt" / "hydra"); os.makedirs(tmp_path / "sd15")
@@ -165,23 +168,31 @@ def test_sample_driver_two_ranks_gloo(tmp_path):
     _run_sample_driver(tmp_path, 1, "one", ["--batch-size", "2"])
     _run_sample_driver(tmp_path, 2, "two", ["--batch-size", "2"])
     _run_sample_driver(tmp_path, 2, "two_gathered", ["--batch-size", "2", "--gather-images"])
-    names = {d: sorted(x for x in os.listdir(tmp_path / d) if x.endswith(".png")) for d in ("one", "two", "two_gathered")}
-    assert len(names["one"]) == 5 * 2 * 6 and names["one"] == names["two"] == names["two_gathered"]      # global scene index in the name: each file once
+    _run_sample_driver(tmp_path, 1, "one_global", ["runner.validation_seed_global=true", "--batch-size", "2"])
+    _run_sample_driver(tmp_path, 2, "two_global", ["runner.validation_seed_global=true", "--batch-size", "2"])
+    dirs = ("one", "two", "two_gathered", "one_global", "two_global")
+    names = {d: sorted(x for x in os.listdir(tmp_path / d) if x.endswith(".png")) for d in dirs}
+    assert len(names["one"]) == 5 * 2 * 6 and all(names[d] == names["one"] for d in dirs)      # global scene index in the name: each file once
     idx = {d: json.load(open(tmp_path / d / "index.json")) for d in names}
     assert idx["one"]["world"] == 1 and idx["two"]["world"] == 2 and idx["two_gathered"]["gather_images"] is True
-    for d in ("two", "two_gathered"):
+    for d in ("two", "two_gathered", "two_global"):
         gens = idx[d]["generations"]
         assert [(g["scene"], g["gen"]) for g in gens] == [(s, t) for s in range(5) for t in range(2)]
         for g in gens:
             want_rank = (g["scene"] // 2) % 2
-            assert g["rank"] == want_rank and g["seed"] == 7 + want_rank and len(g["files"]) == 6, g
+            want_seed = 7 + want_rank if d == "two_global" else 7             # the rank offset exists only in the global-generator branch
+            assert g["rank"] == want_rank and g["seed"] == want_seed and len(g["files"]) == 6, g
             assert all(os.path.exists(tmp_path / d / f) for f in g["files"])
     assert all(g["rank"] == 0 and g["seed"] == 7 for g in idx["one"]["generations"])
-    # the pixels depend on the seed: rank 0's scenes are identical to the one-process run, rank 1's (seed 8) are not; both exchange modes agree
     from PIL import Image
     import numpy as np
     px = lambda d, n: np.asarray(Image.open(tmp_path / d / n))
-    assert np.array_equal(px("one", "0_gen0_view3.png"), px("two", "0_gen0_view3.png"))
-    assert not np.array_equal(px("one", "2_gen0_view3.png"), px("two", "2_gen0_view3.png"))
-    for n in names["two"]:
+    # default mode: world = 1 and world = 2 produce the same picture for EVERY scene and generation, in both exchange modes
+    for n in names["one"]:
+        assert np.array_equal(px("one", n), px("two", n)), n
         assert np.array_equal(px("two", n), px("two_gathered", n)), n
+    # global-generator mode: rank 0's first batch draws the same local seed as the one-process run (same generator, same position); rank 1's
+    # batch comes from generator(seed + 1) instead of the second draw of generator(seed): its pictures differ; and the mode differs from the default
+    assert np.array_equal(px("one_global", "0_gen0_view3.png"), px("two_global", "0_gen0_view3.png"))
+    assert not np.array_equal(px("one_global", "2_gen0_view3.png"), px("two_global", "2_gen0_view3.png"))
+    assert not np.array_equal(px("one", "0_gen0_view3.png"), px("one_global", "0_gen0_view3.png"))

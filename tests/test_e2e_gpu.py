@@ -524,15 +524,28 @@ def test_batch_consistency_sd15(dev):
         check(f"batch consistency scene {k}", e, 1e-2)
 
 
-def test_batch_size_sweep_scenes_are_independent(dev):
-    """tools/batch_sweep.py in a child process (round 5: a 24-scene call died of a GPU memory fault in an edge tile no other batch size produced —
-    a fault aborts the process, so the sweep must not share ours).  Sizes around the boundaries that move with B: the fork / join policy (<= 31 scenes),
-    two chunks (>= 32), 144 views (51 tiles + 48 rows at the 7 x 13 level) text-only and as 12 scenes x CFG 2."""
+def _guard_sweep(args, timeout):
+    """tools/guard_sweep.py in a child process: a GPU memory fault aborts the process, so the sweep must not share ours."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "batch_sweep.py"), "--sizes", "5,24,31,33", "--full", "3,12", "--steps", "3", "--tol", "2e-2"],
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and '"swept": "ok"' in r.stdout, (r.returncode, r.stdout[-600:], r.stderr[-1500:])
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "guard_sweep.py")] + args, capture_output=True, text=True, timeout=timeout)
+    print(r.stdout[-2500:])
+    assert r.returncode == 0 and '"swept": "ok"' in r.stdout and '"guard": true' in r.stdout, (r.returncode, r.stdout[-1200:], r.stderr[-2500:])
+
+
+def test_guard_sweep_sampler_plans(dev):
+    """Scenes are independent AND no kernel touches memory outside its buffers: every plan buffer closes a device segment of its own
+    (engine.Pool.guard), B scenes per call vs the 1-scene calls.  Round 5: a 24-scene call died of a GPU memory fault in an edge tile that no
+    other batch size produced, after two rounds of green suites (gemm_xl.hip fetch_residual read up to 128 rows past the residual).  Sizes around
+    the boundaries that move with B: the fork / join policy (<= 31 scenes), two chunks (>= 32), 144 views (51 tiles + 48 rows at the 7 x 13 level)
+    text-only and as 12 scenes x CFG 2, and 96 scenes = the chunk the bench times; plus the given-view pipeline under UniPC (both modes)."""
+    _guard_sweep(["--cases", "text,cfg,unipc_gv", "--sizes", "5,24,31,33,96", "--full", "3,12", "--steps", "2"], 1100)
+
+
+def test_guard_sweep_hires_fp16_vae(dev):
+    """The same net under the plans the sweep above does not build: configs[3] (432x768, ...Plus map encoder, CFG) at 2 scenes, the fp16 build of
+    every kernel (7 scenes: ragged tiles), and the VAE decode / encode plans."""
+    _guard_sweep(["--cases", "hires,fp16,vae", "--hires", "2", "--fp16", "7", "--steps", "2"], 1100)
 
 
 def test_sample_driver_cond_on_view_end_to_end(dev, tmp_path):

@@ -22,8 +22,9 @@ Multi-GPU = the reference's FID generator flow (perception/data_prepare/val_set_
 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 tools/sample.py --ckpt ... --out ...
 
-batch j of the data goes to rank j mod N (what `accelerator.prepare(dataloader)` does, :79), every rank drives GPU LOCAL_RANK and seeds its
-generator with `seed + rank` (:83-87: `torch.manual_seed(cfg.seed + accelerator.process_index)`), nothing is exchanged inside the sampling loop, and
+batch j of the data goes to rank j mod N (what `accelerator.prepare(dataloader)` does, :79), every rank drives GPU LOCAL_RANK; seeding follows
+the reference's two branches — default: `manual_seed(cfg.seed)` per batch on every rank (test_utils.py:233-238: a scene's latents do not depend on N);
+runner.validation_seed_global=true: one generator per rank seeded `seed + rank` (:83-87), a local seed drawn per batch, nothing is exchanged inside the sampling loop, and
 per batch the ranks either write their own scenes' files and gather the labels on rank 0 (the reference's single-node branch, :147-150) or —
 `--gather-images`, its multi-node branch :141-146 — gather the uint8 images on rank 0, which writes everything.  File names carry the GLOBAL
 scene index, so a file is written exactly once whatever N is; rank 0 writes `index.json` (scene -> files, rank, seed) at the end
@@ -41,7 +42,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 DEFAULTS = dict(seed=42, validation_times=4, guidance_scale=2.0, num_inference_steps=20, image_size=(224, 400), fix_seed_within_batch=False,
-                bbox_max_length=None)          # configs/test_config.yaml + configs/runner/default.yaml:54-61
+                bbox_max_length=None, validation_seed_global=False)          # configs/test_config.yaml + configs/runner/default.yaml:54-61
 
 
 def _parse(v: str):
@@ -79,6 +80,8 @@ def resolve_run_config(ckpt_dir: str, cli_overrides: Sequence[str]) -> Dict:
             run["seed"] = _parse(v)
         elif k == "fix_seed_within_batch":
             run["fix_seed_within_batch"] = bool(_parse(v))
+        elif k == "runner.validation_seed_global":
+            run["validation_seed_global"] = bool(_parse(v))
         elif k == "runner.validation_times":
             run["validation_times"] = int(v)
         elif k == "runner.bbox_max_length":
@@ -161,9 +164,34 @@ def rank_batches(n_batches: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_batches, world))
 
 
-def rank_seed(seed, rank: int, world: int):
-    """val_set_gen.py:83-87: `cfg.seed + accelerator.process_index`; one process: the seed itself (tools/test.py)."""
-    return None if seed is None else (int(seed) + rank if world > 1 else int(seed))
+def rank_seed(seed, rank: int, world: int, seed_global: bool = False):
+    """The seed a rank's generator starts from.  Default (runner.validation_seed_global false, configs/runner/default.yaml): run_one_batch_pipe
+    seeds `torch.manual_seed(cfg.seed)` per batch on EVERY rank, no rank offset (magicdrive/misc/test_utils.py:233-238) — a scene's initial
+    latents do not depend on the world size or on the rank its batch lands on.  validation_seed_global: ONE generator per rank, seeded
+    `cfg.seed + accelerator.process_index` before the loop (perception/data_prepare/val_set_gen.py:83-87)."""
+    if seed is None:
+        return None
+    return int(seed) + rank if seed_global else int(seed)
+
+
+def new_local_seed(global_generator) -> int:
+    """magicdrive/misc/test_utils.py:184-188."""
+    return int(torch.randint(0x7ffffffffffffff0, [1], generator=global_generator).item())
+
+
+def batch_generator(seed, bs: int, fix_seed_within_batch: bool, global_generator=None):
+    """The `generator` argument of one batch's pipe() calls, as run_one_batch_pipe builds it (test_utils.py:221-238).  The reference's
+    `torch.manual_seed(s)` re-seeds and returns THE default generator, so its per-scene list holds one object `bs` times — seeded with the
+    last local seed drawn when a global generator is given — and its state carries over the validation_times loop; reproduced with one
+    private generator."""
+    if seed is None:
+        return None
+    if global_generator is not None:
+        local = [new_local_seed(global_generator) for _ in range(bs if fix_seed_within_batch else 1)][-1]
+        g = torch.Generator().manual_seed(local)
+    else:
+        g = torch.Generator().manual_seed(int(seed))
+    return [g] * bs if fix_seed_within_batch else g
 
 
 def save_views(out_dir: str, scene: int, gen: int, views) -> List[str]:
@@ -241,7 +269,8 @@ def main(argv=None):
     if rank == 0:
         os.makedirs(a.out, exist_ok=True)
     DD.barrier()
-    seed = rank_seed(run["seed"], rank, world)
+    seed = rank_seed(run["seed"], rank, world, run["validation_seed_global"])
+    global_gen = torch.Generator().manual_seed(seed) if (run["validation_seed_global"] and seed is not None) else None   # carried across batches
     batches = list(iter_batches_index(len(data), a.batch_size))
     mine = set(rank_batches(len(batches), rank, world))
     n_rounds = (len(batches) + world - 1) // world                  # every rank takes part in every per-batch exchange (a collective)
@@ -261,23 +290,23 @@ def main(argv=None):
                     raise SystemExit(f"{a.sd15} has no text_encoder/: pass --prompt-embeds to sample with zero embeddings")
                 D = pipe.unet.cfg["cross_attention_dim"]
                 kw.update(prompt=None, prompt_embeds=torch.zeros(bs, 77, D), negative_prompt_embeds=torch.zeros(bs, 77, D))
-            # Seeding as the reference entry point does it (tools/test.py passes no global_generator, so run_one_batch_pipe,
-            # magicdrive/misc/test_utils.py:221-237, builds torch.manual_seed(cfg.seed) ONCE per batch, before the validation_times loop: its
-            # state carries across the iterations; with fix_seed_within_batch every scene of the batch gets that same generator object) —
-            # the same seed reproduces the reference's initial latents; under torchrun the seed is `seed + rank` (val_set_gen.py:83-87).
+            # Seeding as run_one_batch_pipe does it (magicdrive/misc/test_utils.py:221-238): the generator is built ONCE per batch, before the
+            # validation_times loop (its state carries across the iterations).  Default: manual_seed(cfg.seed) on every rank; with
+            # runner.validation_seed_global=true the rank's global generator (seed + rank, val_set_gen.py:83-87) hands out a local seed per batch.
             # --reseed-per-run (a deviation) draws a fresh seed per (batch, run).
-            base_gen = None if seed is None else torch.Generator().manual_seed(seed)
+            gen = batch_generator(seed, bs, run["fix_seed_within_batch"], global_gen)
+            base_gen = gen[0] if isinstance(gen, list) else gen
             if a.cond_on_view:
                 for ti, images in cond_on_view_runs(pipe, kw, pixel_values, run, generator=base_gen):
                     for bi, views in enumerate(images):
                         records.append(dict(scene=scene0 + bi, gen=ti, rank=rank, seed=seed)); images_out.append(views)
             else:
                 for ti in range(run["validation_times"]):
-                    g = base_gen
+                    g = gen
                     if a.reseed_per_run and base_gen is not None:
-                        g = torch.Generator().manual_seed(int(torch.randint(0x7ffffffffffffff0, [1], generator=base_gen)))
-                    gen = None if g is None else ([g] * bs if run["fix_seed_within_batch"] else g)
-                    images = pipe(generator=gen, **kw).images                      # List[List[PIL]]: scene x view
+                        g1 = torch.Generator().manual_seed(new_local_seed(base_gen))
+                        g = [g1] * bs if run["fix_seed_within_batch"] else g1
+                    images = pipe(generator=g, **kw).images                      # List[List[PIL]]: scene x view
                     for bi, views in enumerate(images):
                         records.append(dict(scene=scene0 + bi, gen=ti, rank=rank, seed=seed)); images_out.append(views)
             n_local += bs
