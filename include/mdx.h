@@ -42,7 +42,7 @@ extern "C" {
 #define MDX_ELAUNCH (-2)     /* hip launch / runtime error */
 #define MDX_EUNSUPPORTED (-3)
 
-#define MDX_ABI_VERSION 8
+#define MDX_ABI_VERSION 9
 
 /* ---- epilogue flags shared by GEMM / conv ------------------------------- */
 #define MDX_EPI_NONE 0
@@ -95,6 +95,22 @@ typedef struct MdxGemmDesc {
     double ln_eps;
     const float* ln_csum;
     void* ln_scratch;
+    /* Row statistics out of the PRODUCER's epilogue (ABI 9).  The LayerNorms of a transformer block normalise tensors that a
+     * C x C projection has just written (proj_in -> norm1, attn1.to_out + residual -> norm2, attn2.to_out + residual -> norm4 / norm3,
+     * connector(attn4.to_out) + residual -> norm3: attention.py:123-200, blocks.py:190-222).  rowstat_out != NULL: besides C the GEMM writes
+     *     rowstat_out[(p * M + m) * 2 + {0, 1}] = (sum, sum of squares) of the STORED values C[m][n] (rounded to the 16-bit type, residual added)
+     * over the columns n of part p, for rowstat_parts parts that together cover [0, N); parts a route does not need are written as zeros, so a
+     * consumer simply adds all parts.  Fixed summation order (deterministic).  Plain epilogue, one batch, 16-bit C, no Vt; rowstat_parts >= 1.
+     * The K = 320 weight-stationary kernel emits them from its store phase (one part per 128-column tile); every other route runs a small
+     * statistics kernel over C behind the GEMM (part 0 = the whole row).
+     * ln_stats != NULL (with ln_eps > 0): the fused LayerNorm takes mean / rstd of row m from these sums — written by the producer of A through
+     * its rowstat_out, ln_stats_parts parts of M rows — instead of recomputing them from the rows it streams (in every N-tile's workgroup: 8x for
+     * a fused q/k/v projection).  With given statistics the GEGLU epilogue can carry the LayerNorm too (norm3 -> ff.net.0).  Routes that do not
+     * normalise in-kernel ignore ln_stats and normalise into ln_scratch as before. */
+    float* rowstat_out;
+    int64_t rowstat_parts;
+    const float* ln_stats;
+    int64_t ln_stats_parts;
 } MdxGemmDesc;
 int mdx_gemm_bf16(const MdxGemmDesc* d, void* stream);
 

@@ -137,6 +137,18 @@ __device__ __forceinline__ f32x2_t gelu_erf_f2(f32x2_t x) {
 __device__ __forceinline__ f32x2_t gelu_erf_f2(f32x2_t x) { return f32x2_t{gelu_erf_f(x.x), gelu_erf_f(x.y)}; }
 #endif
 
+// Two 16-bit products + fp32 accumulate in one instruction (v_dot2_f32_bf16 / v_dot2_f32_f16), no unpacking: a and b hold two values of the
+// build's 16-bit type each.  The products are exact in fp32.
+__device__ __forceinline__ float dot2_16(unsigned a, unsigned b, float c) {
+#if MDX_F16
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a), __builtin_bit_cast(h2_t, b), c, false);
+#else
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2_t, a), __builtin_bit_cast(b2_t, b), c, false);
+#endif
+}
+
 union Frag8 {
     uint4 u;
     bf16x8_t v;

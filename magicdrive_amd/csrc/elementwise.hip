@@ -125,16 +125,6 @@ __global__ __launch_bounds__(256) void conv_direct_kpar_kernel(CDParams p) {
 // (v_dot2c_f32_bf16 / _f16: two 16-bit products + fp32 accumulate per instruction, no unpacking) and one wave reduction per output channel.
 // Summation order per output element: lane-local over the lane's chunks, then across lanes — a permutation of the kernel above's;
 // fp32 throughout (the 16-bit products are exact in fp32).
-__device__ __forceinline__ float dot2_16(unsigned a, unsigned b, float c) {
-#if MDX_F16
-    typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
-    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, a), __builtin_bit_cast(h2_t, b), c, false);
-#else
-    typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2_t, a), __builtin_bit_cast(b2_t, b), c, false);
-#endif
-}
-
 template <int NCHK, int PIX>
 __global__ __launch_bounds__(256) void conv_direct_kpar_ws_kernel(CDParams p) {
     constexpr int NOUT = 4;

@@ -33,6 +33,8 @@ int launch_gemm_ws(const GCParams& p, hipStream_t st);                          
 bool ws_supported(const GCParams& p);
 bool ws_fuses_layernorm(const GCParams& p);
 int launch_layernorm_plain(const bf16_t* X, bf16_t* Y, int M, int C, long ldx, long ldy, float eps, hipStream_t st);   // norm.hip
+int launch_rowstat(const bf16_t* X, int M, int C, long ldx, float* stat, int parts, hipStream_t st);                      // norm.hip
+bool ws_emits_rowstat(const GCParams& p);                                                                                  // gemm_ws.hip
 int launch_gemm_xl(const GCParams& p, bool conv, int bn, hipStream_t st);       // gemm_xl.hip: 256 x {256,160} LDS-DMA quadrant-phase tiles
 bool xl_supported(const GCParams& p, bool conv, int bn);
 
@@ -351,6 +353,21 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
         p.wide = wide_on && !p.c_f32 && (nout % 8) == 0 && (p.ldc % 8) == 0 && (p.sC % 8) == 0 && (((uintptr_t)p.C) & 15) == 0 &&
                  (!p.R || ((p.ldr % 8) == 0 && (p.sR % 8) == 0 && (((uintptr_t)p.R) & 15) == 0));
     }
+    if (!opt(OPT_LN_STATS)) { p.rowstat = nullptr; p.rowstat_parts = 0; p.ln_stats = nullptr; p.ln_stats_parts = 0; }   // A/B: the round-5 data flow
+    if (p.rowstat) {
+        // Row statistics of C for the LayerNorm that reads it next (MdxGemmDesc.rowstat_out): the K = 320 weight-stationary kernel emits them
+        // from its store phase; every other route gets them from a small kernel over the finished C (part 0 = whole rows, the rest zeros).
+        if (conv || p.batch > 1 || p.epi != 0 || p.c_f32 || p.Vt || p.rowstat_parts < 1) return set_error(MDX_EINVAL, "rowstat_out: plain 2-D GEMM with 16-bit C only");
+        const int ws_mode_ = (int)opt(OPT_GEMM_WS);
+        const bool ws_route = ws_mode_ > 0 && p.splitk <= 1 && ws_supported(p) && (ws_mode_ >= 2 || p.M >= 8192) &&
+                              !((int)opt(OPT_XL_K320) && (int)opt(OPT_GEMM_XL) > 0) && (int)opt(OPT_GEMM_XL) < 2;
+        if (!(ws_route && ws_emits_rowstat(p) && opt(OPT_LN_FUSE))) {
+            GCParams q = p;
+            q.rowstat = nullptr; q.rowstat_parts = 0;
+            if (int rc = launch_gemm_conv(q, conv, st)) return rc;
+            return launch_rowstat((const bf16_t*)p.C, p.M, p.N, p.ldc, p.rowstat, p.rowstat_parts, st);
+        }
+    }
     if (geglu && (p.N % 64) != 0) return set_error(MDX_EINVAL, "GEGLU needs packed N %% 64 == 0 (N=%d)", p.N);
     constexpr int impl = 0;
     // K = 320 projections with many rows: weights in registers, activations streamed (gemm_ws.hip).  MDX_GEMM_WS: 0 off, 1 when
@@ -397,7 +414,7 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
         if (!(ws_taken && ws_fuses_layernorm(p) && opt(OPT_LN_FUSE))) {
             if (!p.ln_scratch) return set_error(MDX_EINVAL, "fused LayerNorm: this shape is not normalised in-kernel and no ln_scratch was given");
             if (int rc = launch_layernorm_plain(p.A, p.ln_scratch, p.M, p.K, p.lda, p.lda, p.ln_eps, st)) return rc;
-            p.A = p.ln_scratch; p.ln_eps = 0.f; p.ln_csum = nullptr;
+            p.A = p.ln_scratch; p.ln_eps = 0.f; p.ln_csum = nullptr; p.ln_stats = nullptr; p.ln_stats_parts = 0;
         }
     }
     if (xl_mode >= 2 && p.splitk <= 1 && p.batch <= 1 && !(p.K == 320 && !conv && !xl_k320)) {
@@ -534,16 +551,28 @@ extern "C" int mdx_gemm_bf16(const MdxGemmDesc* d, void* stream) {
         if (!d->ln_csum || p.batch > 1 || d->splitk > 1 || d->c_is_f32 || d->temb || ((uintptr_t)d->ln_scratch & 15))
             return set_error(MDX_EINVAL, "mdx_gemm_bf16: fused LayerNorm needs ln_csum, one batch, no split-K / fp32 C / temb, 16-byte aligned ln_scratch");
         p.ln_eps = (float)d->ln_eps; p.ln_csum = d->ln_csum; p.ln_scratch = (bf16_t*)d->ln_scratch;
+        if (d->ln_stats) {
+            if (d->ln_stats_parts < 1 || ((uintptr_t)d->ln_stats & 7)) return set_error(MDX_EINVAL, "mdx_gemm_bf16: ln_stats needs ln_stats_parts >= 1 and 8-byte alignment");
+            p.ln_stats = d->ln_stats; p.ln_stats_parts = (int)d->ln_stats_parts;
+        }
+    } else if (d->ln_stats) {
+        return set_error(MDX_EINVAL, "mdx_gemm_bf16: ln_stats without ln_eps");
+    }
+    if (d->rowstat_out) {
+        if (d->rowstat_parts < 1 || ((uintptr_t)d->rowstat_out & 7) || d->Vt || d->epilogue || d->c_is_f32 || p.batch > 1)
+            return set_error(MDX_EINVAL, "mdx_gemm_bf16: rowstat_out needs rowstat_parts >= 1, 8-byte alignment, a plain epilogue, 16-bit C, one batch, no Vt");
+        p.rowstat = d->rowstat_out; p.rowstat_parts = (int)d->rowstat_parts;
     }
     if (d->Vt) {   // fused q/k/v projection with a transposed V output: weight-stationary kernel only
         p.Vt = (bf16_t*)d->Vt; p.vt_from = (int)d->vt_from; p.vt_T = (int)d->vt_T; p.vt_ld = d->vt_ld; p.vt_stride = d->vt_stride;
         if (!ws_supported(p) || d->epilogue || d->R || (d->vt_from % 128) || d->vt_from <= 0 || d->vt_from >= d->N || d->vt_T <= 0 ||
             (d->vt_T % 8) || (d->M % d->vt_T) || (d->vt_ld % 8) || (d->vt_stride % 8) || ((uintptr_t)d->Vt & 15))
             return set_error(MDX_EINVAL, "mdx_gemm_bf16: transposed V output needs K=320, plain epilogue, no residual, vt_from %% 128 == 0, vt_T %% 8 == 0, aligned Vt");
+        if (!opt(OPT_LN_STATS)) { p.ln_stats = nullptr; p.ln_stats_parts = 0; }
         if (p.ln_eps > 0.f && !opt(OPT_LN_FUSE)) {            // A/B switch: normalised copy first, then the plain fused q/k/v launch pair
             if (!p.ln_scratch) return set_error(MDX_EINVAL, "fused LayerNorm: LN_FUSE=0 needs ln_scratch");
             if (int rc2 = launch_layernorm_plain(p.A, p.ln_scratch, p.M, p.K, p.lda, p.lda, p.ln_eps, (hipStream_t)stream)) return rc2;
-            p.A = p.ln_scratch; p.ln_eps = 0.f; p.ln_csum = nullptr;
+            p.A = p.ln_scratch; p.ln_eps = 0.f; p.ln_csum = nullptr; p.ln_stats = nullptr; p.ln_stats_parts = 0;
         }
         { GCParams q = p; const long nout = d->vt_from;      // wide-path check of the C part
           q.wide = (nout % 8) == 0 && (p.ldc % 8) == 0 && (((uintptr_t)p.C) & 15) == 0;

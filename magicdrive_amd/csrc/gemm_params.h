@@ -38,6 +38,11 @@ struct GCParams {
     // the affine part, ln_csum[n] = sum_k W[n][k].  gemm_ws.hip computes the row statistics from the slabs it streams and applies
     // C = rstd_m (acc - mean_m csum_n) + bias_n; every other route normalises into ln_scratch first (launch_gemm_conv).
     const float* ln_csum; float ln_eps; bf16_t* ln_scratch;
+    // Row statistics (MdxGemmDesc.rowstat_out / ln_stats, ABI 9): rowstat [rowstat_parts][M][2] = (sum, sum of squares) of the stored C rows per column
+    // part, emitted by the store phase of gemm_ws.hip's plain kernel (one part per 128-column tile) or by rowstat_kernel behind any other route;
+    // ln_stats [ln_stats_parts][M][2]: the same sums of the A rows, from which the fused LayerNorm takes mean / rstd instead of recomputing them.
+    float* rowstat; int rowstat_parts;
+    const float* ln_stats; int ln_stats_parts;
     int dbg;                      // debug knobs of gemm_pp.hip (MDX_PP_DBG): 1 skip LDS stores, 2 skip global loads, 4 skip MFMAs
 };
 

@@ -71,9 +71,16 @@ __device__ __forceinline__ void ws_lds_barrier() {
 // them), 15 us the extra fragment read, 35 us the epilogue — against the 240-400 us LayerNorm pass it replaces; to_q: +105 us.  For
 // the GEGLU (20 N-tiles, a VALU-heavy epilogue already) the same scheme cost +485 us per launch, more than the pass: not built
 // (the engine keeps layernorm_kernel in front of ff.net.0; profiles/README.md round 3).
-template <bool GEGLU, int ST, bool VT, bool LN>
+// LN = 2 (round 6, MdxGemmDesc.ln_stats): mean / rstd come from the (sum, sum of squares) that the PRODUCER of A wrote from its store phase
+// (RS below), summed over its column parts — no sums in the slab loop, and with that the GEGLU epilogue can carry norm3 as well.  The partial sums
+// of a tile's 128 rows are fetched by hand-counted loads right behind the barrier of the tile's first slab (older than that slab's refill pieces, so
+// the next slab's `vmcnt` wait covers them) and published in LDS before the barrier of the third slab.
+// RS (MdxGemmDesc.rowstat_out): the wide store phase of the plain kernel also writes, per stored row segment of its 128-column tile, the sum and the
+// sum of squares of the values it stores (16 lanes share a row: a DPP row rotation tree), part = the N-tile — what the LayerNorm behind it needs.
+template <bool GEGLU, int ST, bool VT, int LN, bool RS>
 __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
-    static_assert(!(GEGLU && LN), "fused LayerNorm: plain and V^T epilogues only");
+    static_assert(!(GEGLU && LN == 1), "in-kernel LayerNorm statistics: plain and V^T epilogues only");
+    static_assert(!(RS && (GEGLU || VT)), "row statistics: plain store phase only");
 
     constexpr int BM = 128, BN = 128, BK = 64, KS = 20, NSLAB = 5;
     constexpr int BNO = GEGLU ? BN / 2 : BN;
@@ -218,6 +225,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
     int q = 0;                                                   // slab counter (ring stage = q % ST)
     float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;            // LN: sums of x / x^2 of row 32 wave + frow over this lane's half of the k chunks
     const float ln_eps = p.ln_eps;
+    constexpr int LNS_MAXP = 4;                                  // LN == 2: column parts of the producer's row statistics (3 for N = 320 out of this kernel)
+    unsigned long long lns[LNS_MAXP] = {0, 0, 0, 0};             // raw (sum, sum of squares) pairs of row m0 + (tid & 127), in flight over one slab
     for (int t = 0; t < ntiles; ++t) {
         const int m0 = (walker + t * nwalk) * BM;
 #pragma unroll
@@ -228,9 +237,36 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
             // lgkmcnt waits) before any wave refills that stage.
             __builtin_amdgcn_sched_barrier(0);
             ws_wait_vmcnt<(ST - 2) * PPW>();
+            if constexpr (LN == 2) {
+                if (s == 1) {                                    // the partial sums fetched behind slab 0's barrier have landed (in-order return)
+#pragma unroll
+                    for (int k = 0; k < LNS_MAXP; ++k) asm volatile("" : "+v"(lns[k]));
+                    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < LNS_MAXP; ++k) {
+                        const float keep = k < p.ln_stats_parts ? 1.f : 0.f;
+                        t1 = __builtin_fmaf(__uint_as_float((unsigned)(lns[k] & 0xffffffffull)), keep, t1);
+                        t2 = __builtin_fmaf(__uint_as_float((unsigned)(lns[k] >> 32)), keep, t2);
+                    }
+                    const float mean = t1 * (1.0f / 320.0f);
+                    const float var = fmaxf(__builtin_fmaf(-mean, mean, t2 * (1.0f / 320.0f)), 0.f);
+                    const float rs = rsqrtf(var + ln_eps);
+                    if (tid < 128) Ls[tid] = make_float2(rs, -mean * rs);      // read after >= 3 more barriers (the epilogue)
+                }
+            }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (LN == 2) {
+                if (s == 0) {                                    // every wave is past the previous tile's epilogue (it read that tile's Ls)
+                    const long row = min(m0 + (tid & 127), p.M - 1);
+#pragma unroll
+                    for (int k = 0; k < LNS_MAXP; ++k) {
+                        const float* sp = p.ln_stats + ((long)min(k, p.ln_stats_parts - 1) * p.M + row) * 2;
+                        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(lns[k]) : "v"(sp) : "memory");
+                    }
+                }
+            }
 #pragma unroll
             for (int j = 0; j < PPW; ++j) WS_ISSUE_PIECE(j)      // refill of the stage freed by this iteration's barrier
             WS_ADVANCE()
@@ -242,26 +278,26 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
             Frag8 sf[2];
             const unsigned char* sr = as + wave * (32 * 128);
 #if defined(MDX_WS_LN_ABLATE) && (MDX_WS_LN_ABLATE & 2)              // ... and the read too (one per tile keeps the code shape)
-            if constexpr (LN) { if (s == 0) sf[0].u = *(const uint4*)(sr + (x0 << 4)); }
+            if constexpr (LN == 1) { if (s == 0) sf[0].u = *(const uint4*)(sr + (x0 << 4)); }
 #else
-            if constexpr (LN) sf[0].u = *(const uint4*)(sr + (x0 << 4));
+            if constexpr (LN == 1) sf[0].u = *(const uint4*)(sr + (x0 << 4));
 #endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[0][i].u = *(const uint4*)(as + i * 32 * 128 + (x0 << 4));
-            if constexpr (LN) __builtin_amdgcn_sched_barrier(0); else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            if constexpr (LN == 1) __builtin_amdgcn_sched_barrier(0); else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 if (ks + 1 < 4) {
                     const int co = (x0 ^ ((ks + 1) << 1)) << 4;
 #if defined(MDX_WS_LN_ABLATE) && (MDX_WS_LN_ABLATE & 2)
-                    if constexpr (LN) sf[(ks + 1) & 1].u = sf[ks & 1].u;
+                    if constexpr (LN == 1) sf[(ks + 1) & 1].u = sf[ks & 1].u;
 #else
-                    if constexpr (LN) sf[(ks + 1) & 1].u = *(const uint4*)(sr + co);
+                    if constexpr (LN == 1) sf[(ks + 1) & 1].u = *(const uint4*)(sr + co);
 #endif
 #pragma unroll
                     for (int i = 0; i < 4; ++i) af[(ks + 1) & 1][i].u = *(const uint4*)(as + i * 32 * 128 + co);
                 }
-                if constexpr (LN) {
+                if constexpr (LN == 1) {
                     // {1 MFMA, the sums of 2 of the fragment's 8 values (6 VALU)} x 4, each group fenced: the VALU work issues in the shadow of
                     // the MFMA in front of it (sched_group_barrier pipelines of this shape were only partly honoured: half of the VALU ended up
                     // in one block behind the slab's last MFMA)
@@ -303,11 +339,11 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
             }
             // LN: the sums must be formed in THIS slab: left alone, LLVM sinks the whole add chain to the end of the tile and keeps all 20
             // fragments of the tile alive until then (80 VGPRs -> 70 spilled registers, reloaded behind s_waitcnt vmcnt(0) inside the ring)
-            if constexpr (LN) asm volatile("" : "+v"(s1a), "+v"(s1b), "+v"(s2a), "+v"(s2b));
+            if constexpr (LN == 1) asm volatile("" : "+v"(s1a), "+v"(s1b), "+v"(s2a), "+v"(s2b));
         }
         // ---- epilogue of tile t: staging is separate from the ring, which keeps streaming ----
         if (no_epi) continue;                                    // ablation: main loop only
-        if constexpr (LN) {
+        if constexpr (LN == 1) {
             float s1 = s1a + s1b, s2 = s2a + s2b;
             s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);          // the other half of the k chunks
             const float mean = s1 * (1.0f / 320.0f);
@@ -329,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
                     for (int g = 0; g < 4; ++g) {
                         const int tl = i * 32 + 8 * g + 4 * half - pass * ROWS_PASS;       // token inside the pass
                         float o[4];
-                        if constexpr (LN) {
+                        if constexpr (LN != 0) {
                             const float4 sa = *(const float4*)(Ls + i * 32 + 8 * g + 4 * half), sb = *(const float4*)(Ls + i * 32 + 8 * g + 4 * half + 2);
                             o[0] = __builtin_fmaf(sa.x, acc[i][4 * g], __builtin_fmaf(sa.y, csch, bch));
                             o[1] = __builtin_fmaf(sa.z, acc[i][4 * g + 1], __builtin_fmaf(sa.w, csch, bch));
@@ -368,13 +404,34 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
                 if (GEGLU) {
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
-                        const float bvv[4] = {bA[g].x, bA[g].y, bA[g].z, bA[g].w};
-                        const float bgg[4] = {bA[2 + g].x, bA[2 + g].y, bA[2 + g].z, bA[2 + g].w};
+                        float bvv[4] = {bA[g].x, bA[g].y, bA[g].z, bA[g].w};
+                        float bgg[4] = {bA[2 + g].x, bA[2 + g].y, bA[2 + g].z, bA[2 + g].w};
                         float o[4];
+                        float cvv[4] = {0.f, 0.f, 0.f, 0.f}, cgg[4] = {0.f, 0.f, 0.f, 0.f};
+                        float2 st = make_float2(1.f, 0.f);
+                        if constexpr (LN != 0) {                     // norm3 folded in: rstd_m acc + (-mean_m rstd_m) csum_n + bias_n on value AND gate columns
+                            st = Ls[i * 32 + frow];
+                            const int cb = (wave >> 1) * 64 + 16 * (wave & 1) + 8 * g + 4 * half;      // raw (packed) column of the value; its gate sits 32 further
+                            const float4 c_v = *(const float4*)(Lc + cb), c_g = *(const float4*)(Lc + cb + 32);
+                            const float4 b_v = *(const float4*)(Lb + cb), b_g = *(const float4*)(Lb + cb + 32);
+                            cvv[0] = c_v.x; cvv[1] = c_v.y; cvv[2] = c_v.z; cvv[3] = c_v.w;
+                            cgg[0] = c_g.x; cgg[1] = c_g.y; cgg[2] = c_g.z; cgg[3] = c_g.w;
+                            bvv[0] = b_v.x; bvv[1] = b_v.y; bvv[2] = b_v.z; bvv[3] = b_v.w;
+                            bgg[0] = b_g.x; bgg[1] = b_g.y; bgg[2] = b_g.z; bgg[3] = b_g.w;
+                        }
 #pragma unroll
                         for (int e = 0; e < 4; e += 2) {             // pairs: the GELU runs on packed fp32 (common.h: gelu_erf_f2)
-                            const float x0 = acc[i][4 * g + e] + bvv[e], x1 = acc[i][4 * g + e + 1] + bvv[e + 1];
-                            const f32x2_t gt = {acc[i][8 + 4 * g + e] + bgg[e], acc[i][8 + 4 * g + e + 1] + bgg[e + 1]};
+                            float x0, x1;
+                            f32x2_t gt;
+                            if constexpr (LN != 0) {
+                                x0 = __builtin_fmaf(st.x, acc[i][4 * g + e], __builtin_fmaf(st.y, cvv[e], bvv[e]));
+                                x1 = __builtin_fmaf(st.x, acc[i][4 * g + e + 1], __builtin_fmaf(st.y, cvv[e + 1], bvv[e + 1]));
+                                gt.x = __builtin_fmaf(st.x, acc[i][8 + 4 * g + e], __builtin_fmaf(st.y, cgg[e], bgg[e]));
+                                gt.y = __builtin_fmaf(st.x, acc[i][8 + 4 * g + e + 1], __builtin_fmaf(st.y, cgg[e + 1], bgg[e + 1]));
+                            } else {
+                                x0 = acc[i][4 * g + e] + bvv[e]; x1 = acc[i][4 * g + e + 1] + bvv[e + 1];
+                                gt.x = acc[i][8 + 4 * g + e] + bgg[e]; gt.y = acc[i][8 + 4 * g + e + 1] + bgg[e + 1];
+                            }
                             const f32x2_t ge = no_gelu ? gt : gelu_erf_f2(gt);
                             o[e] = x0 * ge.x; o[e + 1] = x1 * ge.y;
                         }
@@ -385,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         uint2 ov;
-                        if constexpr (LN) {
+                        if constexpr (LN != 0) {
                             const float2 st = Ls[i * 32 + frow];                                     // (rstd, -mean rstd) of this lane's row
                             const float4 cs = *(const float4*)(Lc + ocol + 8 * g + 4 * half), bb = *(const float4*)(Lb + ocol + 8 * g + 4 * half);
                             ov.x = pack2bf(__builtin_fmaf(st.x, acc[i][4 * g], __builtin_fmaf(st.y, cs.x, bb.x)),
@@ -426,12 +483,32 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GCParams p) {
                 }
 #pragma unroll
                 for (int u = 0; u < IT; ++u) {
-                    if (!ok[u]) continue;
+                    if (!RS && !ok[u]) continue;
                     const int idx = tid + u * 256;
                     const int row = idx / CPR, c8 = (idx - row * CPR) * 8;
                     uint4 v = *(const uint4*)(Cs + row * CSTR + c8);
                     if (Rg) { v.x = add2bf(v.x, rv[u].x); v.y = add2bf(v.y, rv[u].y); v.z = add2bf(v.z, rv[u].z); v.w = add2bf(v.w, rv[u].w); }
-                    *(uint4*)(Cg + (long)(mp + row) * p.ldc + n0o + c8) = v;
+                    if (ok[u]) *(uint4*)(Cg + (long)(mp + row) * p.ldc + n0o + c8) = v;
+                    if constexpr (RS) {
+                        // (sum, sum of squares) of the 8 values this lane stores; the 16 lanes of a row segment (CPR = 16: lanes 16 k .. 16 k + 15 of the
+                        // wave) are combined by a DPP row-rotation tree — every lane takes part (no early exit above), fixed order: deterministic
+                        static_assert(CPR == 16, "row statistics: one 16-lane DPP row per stored row segment");
+                        // packed dot products (dot2_16: two 16-bit products + fp32 accumulate per instruction): sum = x . (1, 1), squares = x . x —
+                        // 8 instructions per 8 values (unpack + add + fma: 32; measured +48 us on a 350 us launch at 576 views, r6b A/B log)
+                        const unsigned km = ok[u] ? 0xffffffffu : 0u;
+                        const unsigned one2 = MDX_ONE16 | (MDX_ONE16 << 16);
+                        const unsigned w0 = v.x & km, w1 = v.y & km, w2 = v.z & km, w3 = v.w & km;
+                        float q1 = dot2_16(w0, one2, 0.f), q2 = dot2_16(w0, w0, 0.f);
+                        q1 = dot2_16(w1, one2, q1); q2 = dot2_16(w1, w1, q2);
+                        q1 = dot2_16(w2, one2, q1); q2 = dot2_16(w2, w2, q2);
+                        q1 = dot2_16(w3, one2, q1); q2 = dot2_16(w3, w3, q2);
+                        // row_ror:n (dpp_ctrl 0x120 + n): lane l of a 16-lane row reads lane (l + n) % 16 of its row
+#define WS_ROR_ADD(x, n) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + (n), 0xf, 0xf, true))
+                        WS_ROR_ADD(q1, 8); WS_ROR_ADD(q2, 8); WS_ROR_ADD(q1, 4); WS_ROR_ADD(q2, 4);
+                        WS_ROR_ADD(q1, 2); WS_ROR_ADD(q2, 2); WS_ROR_ADD(q1, 1); WS_ROR_ADD(q2, 1);
+#undef WS_ROR_ADD
+                        if ((tid & 15) == 0 && mp + row < p.M) *(float2*)(p.rowstat + ((long)tn * p.M + mp + row) * 2) = make_float2(q1, q2);
+                    }
                 }
             } else {
                 constexpr int CPR = BNO / 4, IT = ROWS_PASS * CPR / 256;     // 8
@@ -472,12 +549,12 @@ bool ws_supported(const GCParams& p) {
            (p.epi != 1 || (p.N % 64) == 0);
 }
 
-template <bool GEGLU, bool VT, bool LN>
+template <bool GEGLU, bool VT, int LN, bool RS>
 static int launch_ws_one(const GCParams& p, hipStream_t st) {
     constexpr int ST = 3;
     const size_t smem = (size_t)ST * 128 * 64 * 2 + (size_t)128 * (64 + 8) * 2 +   // ring + staging (also holds 64 x 136 and the transposed 128 x 72)
                         (LN ? 128 * sizeof(float2) + 256 * sizeof(float) : 0);      // + the tile's row statistics, W's column sums, bias
-    auto kern = gemm_ws_kernel<GEGLU, ST, VT, LN>;
+    auto kern = gemm_ws_kernel<GEGLU, ST, VT, LN, RS>;
     if (int rc = ensure_dyn_smem((const void*)kern, smem, "ws")) return rc;
     GCParams q = p;
     q.mt = (p.M + 127) / 128; q.nt = (p.N + 127) / 128;
@@ -491,28 +568,51 @@ static int launch_ws_one(const GCParams& p, hipStream_t st) {
     const int dbg = (int)opt(OPT_WS_DBG);
     q.dbg = dbg;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nwalk * q.nt)), dim3(256), smem, st, q);
-    return check_launch(GEGLU ? "gemm_ws_kernel<geglu>" : LN ? (VT ? "gemm_ws_kernel<vT,ln>" : "gemm_ws_kernel<plain,ln>")
-                                                             : (VT ? "gemm_ws_kernel<vT>" : "gemm_ws_kernel<plain>"));
+    return check_launch(GEGLU ? (LN ? "gemm_ws_kernel<geglu,lns>" : "gemm_ws_kernel<geglu>")
+                              : LN == 2 ? (VT ? "gemm_ws_kernel<vT,lns>" : "gemm_ws_kernel<plain,lns>")
+                              : LN == 1 ? (VT ? "gemm_ws_kernel<vT,ln>" : "gemm_ws_kernel<plain,ln>")
+                                        : (VT ? "gemm_ws_kernel<vT>" : RS ? "gemm_ws_kernel<plain,rs>" : "gemm_ws_kernel<plain>"));
 }
 
-// Whether launch_gemm_ws normalises the A rows itself when p.ln_eps > 0 (else the caller must have done it: launch_gemm_conv).
-bool ws_fuses_layernorm(const GCParams& p) { return p.epi == 0 && p.ln_csum != nullptr; }
+// Whether launch_gemm_ws normalises the A rows itself when p.ln_eps > 0 (else the caller must have done it: launch_gemm_conv): plain / V^T epilogues
+// with statistics from the streamed rows or from the producer; GEGLU only with the producer's statistics (MdxGemmDesc.ln_stats).
+bool ws_fuses_layernorm(const GCParams& p) {
+    if (!p.ln_csum || (p.ln_stats && p.ln_stats_parts > 4)) return false;
+    return p.epi == 0 || (p.epi == 1 && p.ln_stats != nullptr);
+}
+// Whether the plain kernel's store phase can emit the row statistics of C (MdxGemmDesc.rowstat_out): 16-byte row walk, one part per 128-column tile.
+bool ws_emits_rowstat(const GCParams& p) {
+    return p.rowstat && p.epi == 0 && !p.Vt && p.wide && !p.c_f32 && p.ln_eps <= 0.f && (p.N + 127) / 128 <= p.rowstat_parts;
+}
 
 int launch_gemm_ws(const GCParams& p, hipStream_t st) {
     if ((long)p.M * p.lda * 2 >= 0x7FFF0000L) return set_error(MDX_EINVAL, "gemm_ws: A exceeds the 2 GiB buffer window");
     const bool ln = p.ln_eps > 0.f;
-    if (ln && !ws_fuses_layernorm(p)) return set_error(MDX_EINVAL, "gemm_ws: fused LayerNorm needs a plain epilogue and ln_csum");
-    if (p.epi == 1) return launch_ws_one<true, false, false>(p, st);
-    if (!p.Vt) return ln ? launch_ws_one<false, false, true>(p, st) : launch_ws_one<false, false, false>(p, st);
+    if (ln && !ws_fuses_layernorm(p)) return set_error(MDX_EINVAL, "gemm_ws: fused LayerNorm needs ln_csum and a plain epilogue (GEGLU: also ln_stats)");
+    const bool lns = ln && p.ln_stats != nullptr;
+    if (p.rowstat) {
+        if (!ws_emits_rowstat(p)) return set_error(MDX_EINVAL, "gemm_ws: rowstat_out needs the plain wide store phase and one part per 128-column tile");
+        // parts beyond the N-tiles stay zero: clear them here (a tiny memset node; the common N = 320 case has exactly 3 parts and skips it)
+        const int ntile = (p.N + 127) / 128;
+        if (p.rowstat_parts > ntile)
+            if (hipMemsetAsync(p.rowstat + (long)ntile * p.M * 2, 0, (size_t)(p.rowstat_parts - ntile) * p.M * 2 * sizeof(float), st) != hipSuccess)
+                return set_error(MDX_ELAUNCH, "gemm_ws: rowstat memset");
+        return launch_ws_one<false, false, 0, true>(p, st);
+    }
+    if (p.epi == 1) return lns ? launch_ws_one<true, false, 2, false>(p, st) : launch_ws_one<true, false, 0, false>(p, st);
+    auto plain = [&](const GCParams& c) {
+        return lns ? launch_ws_one<false, false, 2, false>(c, st) : ln ? launch_ws_one<false, false, 1, false>(c, st) : launch_ws_one<false, false, 0, false>(c, st);
+    };
+    if (!p.Vt) return plain(p);
     // fused q/k/v: the C columns [0, vt_from) and the transposed V columns [vt_from, N) are two launches over two row ranges of W
     GCParams c = p;
     c.N = p.vt_from; c.Vt = nullptr;
-    int rc = ln ? launch_ws_one<false, false, true>(c, st) : launch_ws_one<false, false, false>(c, st);
+    int rc = plain(c);
     if (rc != MDX_OK) return rc;
     GCParams v = p;
     v.W = p.W + (long)p.vt_from * p.ldw; v.N = p.N - p.vt_from; v.bias = p.bias ? p.bias + p.vt_from : nullptr; v.R = nullptr; v.C = nullptr;
     v.ln_csum = p.ln_csum ? p.ln_csum + p.vt_from : nullptr;
-    return ln ? launch_ws_one<false, true, true>(v, st) : launch_ws_one<false, true, false>(v, st);
+    return lns ? launch_ws_one<false, true, 2, false>(v, st) : ln ? launch_ws_one<false, true, 1, false>(v, st) : launch_ws_one<false, true, 0, false>(v, st);
 }
 
 }  // namespace mdx

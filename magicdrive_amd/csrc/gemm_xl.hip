@@ -1174,6 +1174,8 @@ static int launch_xl(const GCParams& p, hipStream_t st) {
         // only when every XCD gets >= 8 M-groups: M-groups are dealt out whole, and with few of them the XCD that draws one more runs
         // an extra round of tiles (measured: the 4x7-level convs, 84 M-tiles x 5 = 17 groups, went from 0.49 to 0.72 ms)
         raster_shape(q.mt, q.nt, &q.gm, &q.gn);
+        if (const int fgm = (int)opt(OPT_XL_GM)) q.gm = fgm < q.mt ? fgm : q.mt;        // sweeps (tools/xlone.py --raster)
+        if (const int fgn = (int)opt(OPT_XL_GN)) q.gn = fgn < q.nt ? fgn : q.nt;
         const long nb = raster_blocks(q.mt, q.nt, q.gm, q.gn);
         if ((q.mt + q.gm - 1) / q.gm >= 64 && nb < 0x7fffffffL) { q.swz = 2; nblk_raster = (unsigned)nb; }
     }

@@ -547,6 +547,36 @@ int launch_layernorm_plain(const bf16_t* X, bf16_t* Y, int M, int C, long ldx, l
     p.X = X; p.Y = Y; p.gamma = nullptr; p.beta = nullptr; p.M = M; p.C = C; p.ldx = ldx; p.ldy = ldy; p.eps = eps;
     return launch_layernorm<false>(p, st);
 }
+
+// Row statistics of a finished C for GEMM routes that do not emit them from their store phase (MdxGemmDesc.rowstat_out, gemm_conv.hip:
+// launch_gemm_conv): one wave per row, 16-byte loads from clamped addresses, part 0 = (sum, sum of squares) of the whole row in a fixed
+// order (lane-strided chunks, then the wave tree), parts 1.. = zeros.  A narrow row (C % 8 != 0) takes the element loop.
+__global__ __launch_bounds__(256) void rowstat_kernel(const bf16_t* X, int M, int C, long ldx, float* stat, int parts) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bf16_t* xr = X + (long)row * ldx;
+    float s1 = 0.f, s2 = 0.f;
+    if ((C & 7) == 0 && (ldx & 7) == 0 && (((uintptr_t)X) & 15) == 0) {
+        for (int c8 = lane; c8 < C / 8; c8 += 64) {
+            Frag8 f; f.u = *(const uint4*)(xr + c8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float x = bf2f(f.h[e]); s1 += x; s2 = __builtin_fmaf(x, x, s2); }
+        }
+    } else {
+        for (int c = lane; c < C; c += 64) { const float x = bf2f(xr[c]); s1 += x; s2 = __builtin_fmaf(x, x, s2); }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) {
+        *(float2*)(stat + (long)row * 2) = make_float2(s1, s2);
+        for (int k = 1; k < parts; ++k) *(float2*)(stat + ((long)k * M + row) * 2) = make_float2(0.f, 0.f);
+    }
+}
+int launch_rowstat(const bf16_t* X, int M, int C, long ldx, float* stat, int parts, hipStream_t st) {
+    if (M <= 0) return MDX_OK;
+    hipLaunchKernelGGL(rowstat_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, X, M, C, ldx, stat, parts);
+    return check_launch("rowstat_kernel");
+}
 }  // namespace mdx
 
 extern "C" int mdx_layernorm_bf16(const MdxLayerNormDesc* d, void* stream) {

@@ -54,10 +54,13 @@ namespace mdx {
     X(GN_TWO_STAGE, 1, "streaming two-stage GroupNorm for maps >= 32768 elements") \
     X(XL_PERSIST, 1, "256x256 XL GEMMs (plain / GEGLU, optional residual) on the persistent kernel gemm_xlp_kernel") \
     X(XL_RASTER, 2, "XL tile order: 0 row-major, 1 XCD-strided M-tiles, 2 XCD-blocked (M-group x N-group panels per XCD)") \
+    X(XL_GM, 0, "XL_RASTER 2: force the M-tiles per panel (0 = cost model, xl_layout.h: raster_shape)") \
+    X(XL_GN, 0, "XL_RASTER 2: force the N-tiles per panel (0 = cost model)") \
     X(STREAMS, 2, "host side (pipeline): HIP streams a pipe() call spreads its scene chunks over (chunks of >= 16 scenes, one plan + hipGraph each)") \
     X(PLAN_CACHE, 6, "host side (pipeline): sampler plans (captured graphs + buffers) kept per pipeline (LRU); a multi-stream call pins one plan per chunk") \
     X(CHECK_TIMESTEPS, 0, "host side (schedulers): 1 = a device-resident timestep that is not in the scheduler's list raises (one sync per step) instead of poisoning the sample with NaN") \
-    X(LN_FUSE, 1, "MdxGemmDesc.ln_eps: 1 = gemm_ws.hip normalises the rows in-kernel, 0 = always normalise into ln_scratch first (A/B)")
+    X(LN_FUSE, 1, "MdxGemmDesc.ln_eps: 1 = gemm_ws.hip normalises the rows in-kernel, 0 = always normalise into ln_scratch first (A/B)") \
+    X(LN_STATS, 1, "MdxGemmDesc.rowstat_out / ln_stats: 1 = row statistics travel from the producer's store phase to the fused LayerNorm, 0 = round-5 behaviour (nothing emitted, in-kernel sums, GEGLU through ln_scratch) (A/B)")
 
 enum Opt : int {
 #define MDX_OPT_ENUM(key, dflt, doc) OPT_##key,

@@ -103,6 +103,17 @@ class PackedNet:
         b = self._get("geglub", [wkey, bkey], lambda w, b: PK.pack_geglu(w, b, self.dtype)[1])
         return w, b
 
+    def ln_geglu(self, wkey, bkey, ln_pre: str):
+        """GEGLU projection that consumes LayerNorm `ln_pre` with the affine part folded in and the rows in packed [32 value | 32 gate] order
+        (PackedNet.ln_lin + PackedNet.geglu): W' = pack(W diag(gamma)), b' = pack(b + W beta), csum = row sums of the rounded W'.  Only taken
+        when the row statistics come from the producer (MdxGemmDesc.ln_stats)."""
+        keys = [wkey, bkey, ln_pre + "weight", ln_pre + "bias"]
+        fold = lambda w, b, g, be: PK.pack_geglu(w * g.reshape(-1)[None, :], b.reshape(-1) + w @ be.reshape(-1), self.dtype)
+        w = self._get("lngegluw", keys, lambda w, b, g, be: fold(w, b, g, be)[0])
+        bb = self._get("lngeglub", keys, lambda w, b, g, be: fold(w, b, g, be)[1])
+        cs = self._get("lngeglucs", keys, lambda w, b, g, be: fold(w, b, g, be)[0].float().sum(1).contiguous())
+        return w, bb, cs
+
     def folded_affine(self, w2key, b2key, w1key, b1key, b1_scale: float = 1.0):
         """y = W2 (W1 x + s b1) + b2  ->  (W2 W1) x + (W2 s b1 + b2), folded in fp32."""
         keys = [w2key, b2key, w1key, b1key]
@@ -344,7 +355,7 @@ class Builder:
         return C == 320 and T % 8 == 0 and B * T >= 8192
 
     def self_like_attention(self, net, pre, n: torch.Tensor, B, T, C, heads, cross_view: bool, name, ln_pre: Optional[str] = None,
-                            ln_scratch: Optional[torch.Tensor] = None) -> torch.Tensor:
+                            ln_scratch: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
         """q,k fused projection + V^T projection + fused attention over the same token set (attn1) or over the
         two neighbour views (attn4).  n: normalised tokens [B*T, C] — or, with ln_pre (only when fuses_qkv), the RAW tokens: LayerNorm
         `ln_pre` is then applied inside the projection (ops.Gemm.ln_eps)."""
@@ -358,7 +369,7 @@ class Builder:
             qk = self.pool.get((B * T, 2 * C))
             if ln_pre is not None:
                 w, b, cs = net.ln_lin(qkv_keys, ln_pre, (qs, 1.0, 1.0))
-                self.emit(O.Gemm(n, w, qk, bias=b, Vt=vt, vt_from=2 * C, vt_T=T, ln_eps=1e-5, ln_csum=cs, ln_scratch=ln_scratch,
+                self.emit(O.Gemm(n, w, qk, bias=b, Vt=vt, vt_from=2 * C, vt_T=T, ln_eps=1e-5, ln_csum=cs, ln_scratch=ln_scratch, ln_stats=ln_stats,
                                  ws=self.ws, name=name + ".ln+qkv"))
             else:
                 self.emit(O.Gemm(n, net.cat_lin(qkv_keys, (qs, 1.0, 1.0)), qk, Vt=vt, vt_from=2 * C, vt_T=T, ws=self.ws, name=name + ".qkv"))
@@ -375,28 +386,49 @@ class Builder:
         self.pool.put(vt)
         return ao
 
-    def transformer_block(self, net, pre, h: torch.Tensor, B, T, C, heads, ctx_kv, name) -> torch.Tensor:
-        """BasicTransformerBlock / BasicMultiviewTransformerBlock.forward (magicdrive/networks/blocks.py:144-238)."""
+    ROWSTAT_PARTS = 3          # column parts of a producer's row statistics (gemm_ws.hip: one per 128-column tile of N = 320; other routes fill part 0)
+    # norm3 -> ff.net.0 folded into the GEGLU epilogue (PackedNet.ln_geglu, gemm_ws_kernel<geglu,lns>): built, tested, measured and NOT the default —
+    # the two extra fused multiply-adds per value and gate on 2560 raw columns cost the (VALU-bound) GEGLU epilogue +1.9 ms per step over its 7
+    # level-0 launches, against 1.3 ms for the 7 LayerNorm passes they replace (576 views, profiles/r06_ln_stats_ab.log).
+    FOLD_NORM3 = False
+
+    def rowstat(self, M: int) -> torch.Tensor:
+        """fp32 [parts, M, 2] buffer for the (sum, sum of squares) a projection's store phase leaves for the LayerNorm behind it."""
+        return self.pool.get((self.ROWSTAT_PARTS, M, 2), F32)
+
+    def transformer_block(self, net, pre, h: torch.Tensor, B, T, C, heads, ctx_kv, name, h_stats: Optional[torch.Tensor] = None,
+                          out_stats: bool = False):
+        """BasicTransformerBlock / BasicMultiviewTransformerBlock.forward (magicdrive/networks/blocks.py:144-238).
+        `h_stats`: row statistics of h from its producer (proj_in or the previous block), given exactly when the LayerNorms of this block are
+        folded (fuse_ln); out_stats: also return the row statistics of the block's output (a further block's norm1 reads it): (h, stats)."""
         # LayerNorm -> projection pairs whose GEMM has K = 320 and takes the weight-stationary route normalise inside the GEMM (gemm_ws.hip reads
-        # the whole row anyway): norm1 -> q/k/v, norm2 -> to_q, norm4 -> cross-view q/k/v.  The scratch buffer is only written by routes that cannot
-        # fuse (small M, forced routes).  norm3 -> GEGLU keeps its own pass: each of its 20 N-tiles would repeat the row sums, measured slower
-        # than the pass it saves (gemm_ws.hip).
+        # the whole row anyway): norm1 -> q/k/v, norm2 -> to_q, norm4 -> cross-view q/k/v, and (round 6) norm3 -> GEGLU.  The mean / rstd of a row
+        # come from the (sum, sum of squares) that the PRODUCER of the tensor wrote from its store phase (MdxGemmDesc.rowstat_out -> ln_stats:
+        # proj_in, attn1.to_out + residual, attn2.to_out + residual, connector(attn4.to_out) + residual are all C x C projections of the same
+        # kernel family) instead of being recomputed from the streamed rows in every N-tile's workgroup (round 3: 8x for a fused q/k/v launch pair,
+        # +150 us per pair; for the 20 N-tiles of the GEGLU more than the LayerNorm pass it would have saved).  The scratch buffer is only written by
+        # routes that cannot fuse (small M, forced routes).
         fuse_ln = self.fuses_qkv(B, T, C)
+        assert (h_stats is not None) == fuse_ln
+        M = B * T
         # 1. self-attention
         if fuse_ln:
             n1 = self.pool.get(tuple(h.shape))
-            ao = self.self_like_attention(net, pre + "attn1.", h, B, T, C, heads, False, name + ".attn1", ln_pre=pre + "norm1.", ln_scratch=n1)
+            ao = self.self_like_attention(net, pre + "attn1.", h, B, T, C, heads, False, name + ".attn1", ln_pre=pre + "norm1.", ln_scratch=n1, ln_stats=h_stats)
+            self.pool.put(h_stats)
         else:
             n1 = self.layernorm(net, pre + "norm1.", h, name + ".norm1")
             ao = self.self_like_attention(net, pre + "attn1.", n1, B, T, C, heads, False, name + ".attn1")
         self.pool.put(n1)
-        h1 = self.gemm(ao, net.lin(pre + "attn1.to_out.0.weight"), C, bias=net.vec(pre + "attn1.to_out.0.bias"), R=h, name=name + ".attn1.out")
+        s1 = self.rowstat(M) if fuse_ln else None
+        h1 = self.gemm(ao, net.lin(pre + "attn1.to_out.0.weight"), C, bias=net.vec(pre + "attn1.to_out.0.bias"), R=h, rowstat=s1, name=name + ".attn1.out")
         self.pool.put(ao); self.pool.put(h)
         # 2. context cross-attention with prologue-computed K / V^T
         if fuse_ln:
             n2 = self.pool.get(tuple(h1.shape))
             w, b, cs = net.ln_lin([pre + "attn2.to_q.weight"], pre + "norm2.", (q_prescale(C // heads),))
-            q2 = self.gemm(h1, w, C, bias=b, ln_eps=1e-5, ln_csum=cs, ln_scratch=n2, name=name + ".attn2.ln+q")
+            q2 = self.gemm(h1, w, C, bias=b, ln_eps=1e-5, ln_csum=cs, ln_scratch=n2, ln_stats=s1, name=name + ".attn2.ln+q")
+            self.pool.put(s1)
         else:
             n2 = self.layernorm(net, pre + "norm2.", h1, name + ".norm2")
             q2 = self.gemm(n2, net.lin(pre + "attn2.to_q.weight", q_prescale(C // heads)), C, name=name + ".attn2.q")
@@ -405,13 +437,18 @@ class Builder:
         ao2 = self.pool.get((B * T, C))
         self.emit(O.Attn(q2.view(B, T, C), Kc, Vtc, ao2.view(B, T, C), heads=heads, Tk=S, scale=(C // heads) ** -0.5, q_prescaled=True, name=name + ".attn2"))
         self.pool.put(q2)
-        h2 = self.gemm(ao2, net.lin(pre + "attn2.to_out.0.weight"), C, bias=net.vec(pre + "attn2.to_out.0.bias"), R=h1, name=name + ".attn2.out")
+        has4 = net.has(pre + "attn4.to_q.weight")
+        fold3 = fuse_ln and self.FOLD_NORM3
+        s2 = self.rowstat(M) if (fuse_ln and (has4 or fold3)) else None       # read by norm4 (multiview blocks) or, folded, by norm3 (ControlNet blocks)
+        h2 = self.gemm(ao2, net.lin(pre + "attn2.to_out.0.weight"), C, bias=net.vec(pre + "attn2.to_out.0.bias"), R=h1, rowstat=s2, name=name + ".attn2.out")
         self.pool.put(ao2); self.pool.put(h1)
         # 2b. cross-view attention: out = W_o (o_left + o_right) + 2 b_o ; connector ; residual (blocks.py:190-222)
-        if net.has(pre + "attn4.to_q.weight"):
+        s3 = s2
+        if has4:
             if fuse_ln:
                 n4 = self.pool.get(tuple(h2.shape))
-                ao4 = self.self_like_attention(net, pre + "attn4.", h2, B, T, C, heads, True, name + ".attn4", ln_pre=pre + "norm4.", ln_scratch=n4)
+                ao4 = self.self_like_attention(net, pre + "attn4.", h2, B, T, C, heads, True, name + ".attn4", ln_pre=pre + "norm4.", ln_scratch=n4, ln_stats=s2)
+                self.pool.put(s2)
             else:
                 n4 = self.layernorm(net, pre + "norm4.", h2, name + ".norm4")
                 ao4 = self.self_like_attention(net, pre + "attn4.", n4, B, T, C, heads, True, name + ".attn4")
@@ -424,28 +461,40 @@ class Builder:
             else:                                                                 # gated: tanh(alpha) per channel (blocks.py:24-32, 84-85); none: identity (:86-88)
                 wf, bf_ = net.gated_affine(pre + "attn4.to_out.0.weight", pre + "attn4.to_out.0.bias",
                                            pre + "connector.alpha" if net.has(pre + "connector.alpha") else None, bo_scale)
-            h3 = self.gemm(ao4, wf, C, bias=bf_, R=h2, name=name + ".attn4.out+connector")
+            s3 = self.rowstat(M) if fold3 else None
+            h3 = self.gemm(ao4, wf, C, bias=bf_, R=h2, rowstat=s3, name=name + ".attn4.out+connector")
             self.pool.put(ao4); self.pool.put(h2)
         else:
             h3 = h2
         # 3. GEGLU feed-forward
-        n3 = self.layernorm(net, pre + "norm3.", h3, name + ".norm3")
-        wg, bg = net.geglu(pre + "ff.net.0.proj.weight", pre + "ff.net.0.proj.bias")
-        g = self.gemm(n3, wg, 4 * C, bias=bg, epilogue=L.EPI_GEGLU, name=name + ".ff.geglu")
+        if fold3:
+            n3 = self.pool.get(tuple(h3.shape))
+            wg, bg, csg = net.ln_geglu(pre + "ff.net.0.proj.weight", pre + "ff.net.0.proj.bias", pre + "norm3.")
+            g = self.gemm(h3, wg, 4 * C, bias=bg, epilogue=L.EPI_GEGLU, ln_eps=1e-5, ln_csum=csg, ln_scratch=n3, ln_stats=s3, name=name + ".ff.ln+geglu")
+            self.pool.put(s3)
+        else:
+            n3 = self.layernorm(net, pre + "norm3.", h3, name + ".norm3")
+            wg, bg = net.geglu(pre + "ff.net.0.proj.weight", pre + "ff.net.0.proj.bias")
+            g = self.gemm(n3, wg, 4 * C, bias=bg, epilogue=L.EPI_GEGLU, name=name + ".ff.geglu")
         self.pool.put(n3)
-        h4 = self.gemm(g, net.lin(pre + "ff.net.2.weight"), C, bias=net.vec(pre + "ff.net.2.bias"), R=h3, name=name + ".ff.out")
+        s4 = self.rowstat(M) if (fuse_ln and out_stats) else None
+        h4 = self.gemm(g, net.lin(pre + "ff.net.2.weight"), C, bias=net.vec(pre + "ff.net.2.bias"), R=h3, rowstat=s4, name=name + ".ff.out")
         self.pool.put(g); self.pool.put(h3)
-        return h4
+        return (h4, s4) if out_stats else h4
 
     def transformer2d(self, net, pre, x: Act, heads, ctx_kv, name, out=None) -> Act:
         """Transformer2DModel.forward (transformer_2d.py:276-315): GN(eps 1e-6) -> 1x1 -> block -> 1x1 -> + input.  `out` as in resnet."""
         B, T, C = x.B, x.H * x.W, x.C
         gn = self.groupnorm(net, pre + "norm.", x, 1e-6, False, name + ".norm")
-        h = self.gemm(gn.tok, net.lin(pre + "proj_in.weight"), C, bias=net.vec(pre + "proj_in.bias"), name=name + ".proj_in")
+        fuse_ln = self.fuses_qkv(B, T, C)
+        hs = self.rowstat(B * T) if fuse_ln else None                    # row statistics of proj_in's output for the first block's norm1
+        h = self.gemm(gn.tok, net.lin(pre + "proj_in.weight"), C, bias=net.vec(pre + "proj_in.bias"), rowstat=hs, name=name + ".proj_in")
         self.free(gn)
         i = 0
         while net.has(f"{pre}transformer_blocks.{i}.norm1.weight"):
-            h = self.transformer_block(net, f"{pre}transformer_blocks.{i}.", h, B, T, C, heads, ctx_kv, f"{name}.tb{i}")
+            more = net.has(f"{pre}transformer_blocks.{i + 1}.norm1.weight")       # a further block's norm1 reads this block's ff.out + residual
+            r = self.transformer_block(net, f"{pre}transformer_blocks.{i}.", h, B, T, C, heads, ctx_kv, f"{name}.tb{i}", h_stats=hs, out_stats=more)
+            h, hs = r if more else (r, None)
             i += 1
         if out is None:
             out = self.new(x.B, x.H, x.W, C)

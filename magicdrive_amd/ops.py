@@ -73,6 +73,10 @@ class Gemm:
     ln_eps: float = 0.0
     ln_csum: Optional[torch.Tensor] = None
     ln_scratch: Optional[torch.Tensor] = None
+    # row statistics (include/mdx.h: MdxGemmDesc.rowstat_out / ln_stats): fp32 [parts, M, 2] = (sum, sum of squares) of the stored C rows per column part,
+    # written by the producer of a LayerNorm's input and read by the GEMM that carries that LayerNorm (ln_eps > 0)
+    rowstat: Optional[torch.Tensor] = None
+    ln_stats: Optional[torch.Tensor] = None
     opcode = L.OP_GEMM
 
     def lower(self):
@@ -135,6 +139,18 @@ class Gemm:
             _chk(self.ln_scratch is None or (self.ln_scratch.dtype == A.dtype and self.ln_scratch.is_contiguous() and self.ln_scratch.numel() >= M * lda),
                  f"gemm {self.name}: ln_scratch must be a contiguous [M, lda] buffer of the operand type")
             d.ln_eps, d.ln_csum, d.ln_scratch = float(self.ln_eps), _p(self.ln_csum), _p(self.ln_scratch)
+            if self.ln_stats is not None:
+                st = self.ln_stats
+                _chk(st.dtype == F32 and st.dim() == 3 and st.is_contiguous() and st.shape[1] == M and st.shape[2] == 2, f"gemm {self.name}: ln_stats must be fp32 [parts, M, 2]")
+                d.ln_stats, d.ln_stats_parts = _p(st), st.shape[0]
+        else:
+            _chk(self.ln_stats is None, f"gemm {self.name}: ln_stats without ln_eps")
+        if self.rowstat is not None:
+            rs = self.rowstat
+            _chk(rs.dtype == F32 and rs.dim() == 3 and rs.is_contiguous() and rs.shape[1] == M and rs.shape[2] == 2 and rs.shape[0] >= 1,
+                 f"gemm {self.name}: rowstat must be fp32 [parts, M, 2]")
+            _chk(batch == 1 and self.epilogue == L.EPI_NONE and self.Vt is None and Cm.dtype in H16, f"gemm {self.name}: rowstat needs a plain 2-D GEMM with 16-bit C")
+            d.rowstat_out, d.rowstat_parts = _p(rs), rs.shape[0]
         return self.opcode, d
 
 

@@ -30,8 +30,14 @@ def _temb_rows(op, n_rows_b, width, col0=0):
 def run_gemm(op: O.Gemm):
     A, W, C = op.A.float(), op.W.float(), op.C
     if op.ln_eps > 0:                         # fused LayerNorm, exactly as include/mdx.h states it: rstd (A W'^T - mean csum) + bias
-        mean = A.mean(-1, keepdim=True)
-        rstd = (A.var(-1, unbiased=False, keepdim=True) + op.ln_eps).rsqrt()
+        if op.ln_stats is not None:           # statistics handed over by the producer of A (MdxGemmDesc.ln_stats): sum / sum of squares per column part
+            s = op.ln_stats.float().sum(0)    # [M, 2]
+            K = A.shape[-1]
+            mean = (s[:, 0] / K)[:, None]
+            rstd = ((s[:, 1] / K - mean[:, 0] ** 2).clamp_min(0) + op.ln_eps).rsqrt()[:, None]
+        else:
+            mean = A.mean(-1, keepdim=True)
+            rstd = (A.var(-1, unbiased=False, keepdim=True) + op.ln_eps).rsqrt()
         raw = rstd * (A @ W.transpose(-1, -2) - mean * op.ln_csum.float())
     else:
         raw = A @ W.transpose(-1, -2)
@@ -56,6 +62,11 @@ def run_gemm(op: O.Gemm):
     if op.R is not None:
         raw = raw + op.R.float()
     C.copy_(raw.to(C.dtype))
+    if op.rowstat is not None:                # MdxGemmDesc.rowstat_out: sums of the STORED values; any split into parts is allowed, unused parts are zero
+        cs = C.float()
+        op.rowstat.zero_()
+        op.rowstat[0, :, 0] = cs.sum(-1)
+        op.rowstat[0, :, 1] = (cs * cs).sum(-1)
 
 
 def run_conv(op: O.Conv):

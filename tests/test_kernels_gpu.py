@@ -191,9 +191,142 @@ def test_gemm_fused_layernorm_qkv_transposed_v(dev, Bv, T):
     close(Vt, ref[:, 2 * Cc:].reshape(Bv, T, Cc).transpose(1, 2), name="ln + fused V^T")
 
 
+def rowstat_ref(Cmat, parts_cols):
+    """(sum, sum of squares) of the STORED rows per column part, fp64 on the host."""
+    cf = Cmat.double().cpu()
+    return torch.stack([torch.stack([cf[:, a:b].sum(1), (cf[:, a:b] ** 2).sum(1)], -1) for a, b in parts_cols])
+
+
+@pytest.mark.parametrize("M,N,res,parts,route", [(8400, 320, True, 3, "ws"), (9001, 320, False, 4, "ws"), (8333, 328, True, 3, "ws"), (16384, 640, True, 5, "ws"),
+                                                 (2100, 320, True, 3, "small"), (8400, 320, True, 3, "no_ws"), (8400, 320, False, 2, "few_parts")])
+def test_gemm_row_statistics_out(dev, M, N, res, parts, route):
+    """MdxGemmDesc.rowstat_out (ABI 9): the projection that writes a LayerNorm's input also leaves (sum, sum of squares) of every STORED row —
+    rounded, residual added — per 128-column tile of the weight-stationary kernel's store phase (a DPP row-rotation tree over the 16 lanes of
+    a row segment), unused parts zero; every other route (small M, kernel off, fewer parts than tiles) runs rowstat_kernel over the finished C
+    (part 0 = whole row).  Against fp64 sums of the stored values; bit-identical across runs (fixed summation order)."""
+    K = 320
+    A = rnd(M, K, seed=1); W = rnd(N, K, scale=K ** -0.5, seed=2); b = rnd(N, seed=3, dtype=torch.float32)
+    R = (rnd(M, N, seed=4).float() * 2 + 3).to(BF) if res else None               # a common offset: the sums are not tiny
+    C = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+    opts = {"no_ws": {"GEMM_WS": 0}}.get(route, {})
+    outs = []
+    for _ in range(2):
+        st = torch.full((parts, M, 2), float("nan"), dtype=torch.float32, device=dev)
+        with L.options(**opts):
+            O.run_ops([O.Gemm(A, W, C, bias=b, R=R, rowstat=st, ws=ws_buf(dev))])
+            kern = (L.lib().mdx_last_kernel() or b"").decode()
+        torch.cuda.synchronize()
+        outs.append(st.clone())
+    fused = route == "ws"
+    assert (kern == "gemm_ws_kernel<plain,rs>") == fused and (fused or kern == "rowstat_kernel"), kern
+    assert torch.equal(outs[0], outs[1]), "row statistics differ between two runs"
+    ref = A.float().cpu() @ W.float().cpu().T + b.cpu()
+    if res: ref += R.float().cpu()
+    close(C, ref, name=f"gemm+rowstat {M}x{N} {route}")
+    st = outs[0].double().cpu()
+    nt = (N + 127) // 128
+    if fused:
+        want = rowstat_ref(C, [(128 * k, min(N, 128 * k + 128)) for k in range(nt)])
+        assert (st[nt:] == 0).all(), "parts beyond the N-tiles must be zero"
+        got = st[:nt]
+    else:
+        want = rowstat_ref(C, [(0, N)])
+        assert (st[1:] == 0).all()
+        got = st[:1]
+    err = ((got - want).abs() / (want.abs() + 1.0)).max().item()
+    assert err < 2e-5, err                                              # fp32 sums of <= 128 (or N) 16-bit values
+    tot = rowstat_ref(C, [(0, N)])[0]
+    assert ((st.sum(0) - tot).abs() / (tot.abs() + 1.0)).max().item() < 2e-5        # what a consumer does: add all parts
+
+
+def _ln_stats_of(x, parts, dev):
+    """Row statistics as a producer would have left them: the row split into `parts` column ranges (the last ones may be empty / zero)."""
+    xf = x.float()
+    K = xf.shape[1]
+    st = torch.zeros(parts, xf.shape[0], 2, dtype=torch.float32, device=dev)
+    edges = [0, 128, 256, K] if parts >= 3 else [0, K]
+    for k in range(len(edges) - 1):
+        st[k, :, 0] = xf[:, edges[k]:edges[k + 1]].sum(1)
+        st[k, :, 1] = (xf[:, edges[k]:edges[k + 1]] ** 2).sum(1)
+    return st
+
+
+@pytest.mark.parametrize("M,N,res,parts", [(8400, 320, False, 3), (9001, 640, True, 3), (8333, 328, False, 4), (16384, 960, False, 1)])
+def test_gemm_fused_layernorm_given_statistics(dev, M, N, res, parts):
+    """MdxGemmDesc.ln_stats: the fused LayerNorm takes mean / rstd from the producer's (sum, sum of squares) parts — hand-counted loads behind
+    the first slab's barrier, published in LDS two barriers before the epilogue — instead of summing the streamed rows in every N-tile's
+    workgroup.  Same reference and tolerance as the in-kernel form; the scratch buffer stays untouched."""
+    K = 320
+    x = rnd(M, K, scale=1.5, seed=1).float() + 0.7
+    x[::7] += 12.0
+    x = x.to(BF)
+    W = rnd(N, K, scale=K ** -0.5, seed=2, dtype=torch.float32); gamma = 1.0 + rnd(K, scale=0.3, seed=5, dtype=torch.float32)
+    beta = rnd(K, scale=0.3, seed=6, dtype=torch.float32)
+    Wp, b, cs = ln_fold(W, gamma, beta, BF)
+    R = rnd(M, N, seed=4) if res else None
+    C = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+    scratch = torch.full((M, K), float("nan"), dtype=BF, device=dev)
+    O.run_ops([O.Gemm(x, Wp, C, bias=b, R=R, ln_eps=1e-5, ln_csum=cs, ln_scratch=scratch, ln_stats=_ln_stats_of(x, parts, dev), ws=ws_buf(dev))])
+    kern = (L.lib().mdx_last_kernel() or b"").decode()
+    torch.cuda.synchronize()
+    assert kern == "gemm_ws_kernel<plain,lns>" and torch.isnan(scratch.float()).all(), kern
+    ref = ln_ref(x, Wp, b)
+    if res: ref += R.float().cpu()
+    close(C, ref, name=f"ln(stats)+gemm {M}x{N}")
+    # a route that cannot fuse ignores the statistics and normalises into the scratch buffer: same result up to the rounding of the copy
+    with L.options(GEMM_WS=0):
+        O.run_ops([O.Gemm(x, Wp, C, bias=b, R=R, ln_eps=1e-5, ln_csum=cs, ln_scratch=scratch, ln_stats=_ln_stats_of(x, parts, dev), ws=ws_buf(dev))])
+    torch.cuda.synchronize()
+    ref2 = ln_ref(x, Wp, b, stored=True)
+    if res: ref2 += R.float().cpu()
+    close(C, ref2, name=f"ln(stats ignored)+gemm {M}x{N}")
+
+
+@pytest.mark.parametrize("Bv,T", [(6, 1400), (7, 1176)])
+def test_gemm_fused_layernorm_given_statistics_qkv(dev, Bv, T):
+    """norm1 -> to_q / to_k / to_v with the producer's statistics: the q/k launch and the transposed-V launch both read them."""
+    Cc = 320
+    M = Bv * T
+    x = (rnd(M, Cc, scale=1.3, seed=1).float() - 0.4).to(BF)
+    W = rnd(3 * Cc, Cc, scale=Cc ** -0.5, seed=2, dtype=torch.float32); gamma = 1.0 + rnd(Cc, scale=0.3, seed=5, dtype=torch.float32)
+    beta = rnd(Cc, scale=0.3, seed=6, dtype=torch.float32)
+    Wp, b, cs = ln_fold(W, gamma, beta, BF)
+    qk = torch.full((M, 2 * Cc), float("nan"), dtype=BF, device=dev)
+    Vt = torch.full((Bv, Cc, T), float("nan"), dtype=BF, device=dev)
+    O.run_ops([O.Gemm(x, Wp, qk, bias=b, Vt=Vt, vt_from=2 * Cc, vt_T=T, ln_eps=1e-5, ln_csum=cs, ln_stats=_ln_stats_of(x, 3, dev))])
+    kern = (L.lib().mdx_last_kernel() or b"").decode()
+    torch.cuda.synchronize()
+    assert kern == "gemm_ws_kernel<vT,lns>", kern
+    ref = ln_ref(x, Wp, b)
+    close(qk, ref[:, :2 * Cc], name="ln(stats) + fused qk")
+    close(Vt, ref[:, 2 * Cc:].reshape(Bv, T, Cc).transpose(1, 2), name="ln(stats) + fused V^T")
+
+
+@pytest.mark.parametrize("M,F_", [(8250, 320), (8400, 1280)])
+def test_gemm_fused_layernorm_geglu_given_statistics(dev, M, F_):
+    """norm3 -> ff.net.0 folded (round 6): with the producer's row statistics the GEGLU epilogue applies rstd (acc - mean csum) + bias to the value
+    and the gate columns; the scratch buffer stays untouched.  Without statistics the same descriptor still goes through the scratch route."""
+    K = 320
+    x = (rnd(M, K, scale=1.4, seed=1).float() + 0.5).to(BF)
+    W = rnd(2 * F_, K, scale=K ** -0.5, seed=2, dtype=torch.float32, dev="cpu"); b = rnd(2 * F_, seed=3, dtype=torch.float32, dev="cpu")
+    gamma = 1.0 + rnd(K, scale=0.3, seed=5, dtype=torch.float32, dev="cpu"); beta = rnd(K, scale=0.3, seed=6, dtype=torch.float32, dev="cpu")
+    Wf, bf_ = W * gamma[None, :], b + W @ beta
+    Wp, bp = PK.pack_geglu(Wf, bf_, BF)
+    C = torch.zeros(M, F_, dtype=BF, device=dev)
+    scratch = torch.full((M, K), float("nan"), dtype=BF, device=dev)
+    O.run_ops([O.Gemm(x, Wp.to(dev), C, bias=bp.to(dev), epilogue=L.EPI_GEGLU, ln_eps=1e-5, ln_csum=Wp.float().sum(1).to(dev), ln_scratch=scratch,
+                      ln_stats=_ln_stats_of(x, 3, dev), ws=ws_buf(dev))])
+    kern = (L.lib().mdx_last_kernel() or b"").decode()
+    torch.cuda.synchronize()
+    assert kern == "gemm_ws_kernel<geglu,lns>" and torch.isnan(scratch.float()).all(), kern
+    h, g = ln_ref(x, Wf.to(BF), bf_).chunk(2, dim=-1)
+    close(C, h * F.gelu(g), name=f"ln(stats)+geglu {M}x{F_}")
+
+
 def test_gemm_fused_layernorm_geglu_goes_through_scratch(dev):
-    """ln_eps on a GEGLU projection (norm3 -> ff.net.0) is accepted by the C-ABI but never fused (gemm_ws.hip: measured slower than the
-    LayerNorm pass): the rows are normalised into ln_scratch, then the ordinary GEGLU kernel runs on the folded weights."""
+    """ln_eps on a GEGLU projection (norm3 -> ff.net.0) WITHOUT producer statistics is accepted by the C-ABI but not fused (gemm_ws.hip: in-kernel
+    sums in 20 N-tiles measured slower than the LayerNorm pass): the rows are normalised into ln_scratch, then the ordinary GEGLU kernel runs on
+    the folded weights."""
     M, F_, K = 8250, 320, 320
     x = (rnd(M, K, scale=1.4, seed=1).float() + 0.5).to(BF)
     W = rnd(2 * F_, K, scale=K ** -0.5, seed=2, dtype=torch.float32, dev="cpu"); b = rnd(2 * F_, seed=3, dtype=torch.float32, dev="cpu")

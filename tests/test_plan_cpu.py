@@ -384,8 +384,9 @@ def test_fp16_sampler_plan_matches_golden_pipeline():
 
 @pytest.mark.parametrize("dtype,limit", [(torch.bfloat16, 6e-3), (torch.float16, 8e-4)])
 def test_fused_layernorm_block_equals_separate_layernorm(monkeypatch, dtype, limit):
-    """Level-0 transformer block (C = 320, 6 views x 1400 tokens): the emission with LayerNorm folded into the q/k/v and to_q projections
-    (engine.PackedNet.ln_lin + ops.Gemm.ln_eps: raw tokens in, W diag(gamma), W beta, column sums) against the plain LayerNorm -> Linear
+    """Level-0 transformer block (C = 320, 6 views x 1400 tokens): the emission with LayerNorm folded into the q/k/v, to_q and (round 6) GEGLU
+    projections, the row statistics handed from each producer's store phase to the consumer (ops.Gemm.rowstat -> ln_stats)
+    (engine.PackedNet.ln_lin / ln_geglu + ops.Gemm.ln_eps: raw tokens in, W diag(gamma), W beta, column sums) against the plain LayerNorm -> Linear
     emission of the same block, both through the CPU interpreter.  The two differ only in where the 16-bit rounding falls (W' vs x_hat):
     measured 4.1e-3 in bf16 (2^-9 steps), 8x less in fp16 — an algebra or packing error would show at the same size in both."""
     from magicdrive_amd import engine as E, ops as O
@@ -411,15 +412,26 @@ def test_fused_layernorm_block_equals_separate_layernorm(monkeypatch, dtype, lim
         net = PackedNet(sd, CPU, dtype)
         b = E.Builder(spec.SD15_CONFIG, CPU, B, 6, ws_mb=1, dtype=dtype)
         h = b.pool.get((B * T, C)); h.copy_(x)
-        out = b.transformer_block(net, pre, h, B, T, C, heads, {pre + "attn2.": (Kc, Vtc, S)}, "blk")
-        kinds = [type(o).__name__ + (":ln" if getattr(o, "ln_eps", 0) > 0 else "") for o in b.ops]
+        hs = None
+        if fused:       # the block's input statistics come from ITS producer (Transformer2DModel.proj_in): here an identity projection that emits them
+            hs = b.rowstat(B * T)
+            h0 = b.pool.get((B * T, C)); h0.copy_(x)
+            b.gemm(h0, torch.eye(C).to(dtype), C, out=h, rowstat=hs, name="producer")
+        out = b.transformer_block(net, pre, h, B, T, C, heads, {pre + "attn2.": (Kc, Vtc, S)}, "blk", h_stats=hs)
+        kinds = [type(o).__name__ + (":ln" if getattr(o, "ln_eps", 0) > 0 else "") + (":rs" if getattr(o, "rowstat", None) is not None else "")
+                 + (":st" if getattr(o, "ln_stats", None) is not None else "") for o in b.ops]
         plan_interp.run(b.ops)
         return out.float().clone(), kinds
     y1, k1 = run(True)
     y0, k0 = run(False)
-    assert k1.count("Gemm:ln") == 3 and k1.count("LayerNorm") == 1          # norm3 -> GEGLU keeps its own pass
-    assert k0.count("Gemm:ln") == 0 and k0.count("LayerNorm") == 4
+    # round 6: norm1 / norm2 / norm4 take their row statistics from the projection that wrote their input; norm3 -> GEGLU keeps its own pass by default
+    assert k1.count("Gemm:ln:st") == 3 and k1.count("LayerNorm") == 1 and k1.count("Gemm:rs") == 3, k1
+    assert k0.count("Gemm:ln") == 0 and k0.count("LayerNorm") == 4 and not any(":rs" in k or ":st" in k for k in k0)
     assert rel_l2(y1, y0) < limit, rel_l2(y1, y0)
+    monkeypatch.setattr(E.Builder, "FOLD_NORM3", True)       # the built-but-not-default form: norm3 folded into the GEGLU epilogue as well
+    y2, k2 = run(True)
+    assert k2.count("Gemm:ln:st") == 4 and k2.count("LayerNorm") == 0 and k2.count("Gemm:rs") == 4, k2
+    assert rel_l2(y2, y0) < limit, rel_l2(y2, y0)
 
 
 def test_forked_step_branches_share_no_buffer(tiny):

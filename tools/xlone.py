@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--bn", type=str, default="", help="comma list of XL tile widths to force one after the other (160,256,320); default: the library's choice")
+    ap.add_argument("--raster", type=str, default="", help="semicolon list of forced panel shapes 'gm,gn' of the XCD-blocked tile order (XL_GM / XL_GN), "
+                                                         "timed after the cost model's choice, e.g. '16,2;32,1;8,4'")
     a = ap.parse_args()
     dev = torch.device("cuda")
     B = a.views
@@ -84,8 +86,9 @@ def main():
             continue
         op, fl = mk()
         code, desc = op.lower()
-        for bn in bns:
-            with L.options(**({"GEMM_XL": 2, "XL_BN": bn} if bn else {})):
+        rasters = [(0, 0)] + [tuple(int(v) for v in r_.split(",")) for r_ in a.raster.split(";") if r_]
+        for bn, (gm, gn) in [(b_, r_) for b_ in bns for r_ in rasters]:
+            with L.options(**dict(({"GEMM_XL": 2, "XL_BN": bn} if bn else {}), XL_GM=gm, XL_GN=gn)):
                 try:
                     for _ in range(2):
                         L.call_op(code, desc, st)
@@ -99,7 +102,7 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / a.reps * 1e3
-            print(f"{name:26s} {('bn=%d' % bn) if bn else '':7s} {us:9.1f} us {fl / us / 1e6:8.1f} TF/s  {(L.lib().mdx_last_kernel() or b'').decode()}", flush=True)
+            print(f"{name:26s} {('bn=%d' % bn) if bn else '':7s} {('gm,gn=%d,%d' % (gm, gn)) if gm or gn else '':12s} {us:9.1f} us {fl / us / 1e6:8.1f} TF/s  {(L.lib().mdx_last_kernel() or b'').decode()}", flush=True)
         del op
         torch.cuda.empty_cache()
 
