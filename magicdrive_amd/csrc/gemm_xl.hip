@@ -57,6 +57,21 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
     constexpr int A_BYTES = BM * 128, B_BYTES = G::BNP * 128, BUF = A_BYTES + B_BYTES;
     constexpr int PA = G::PA, PB0 = G::PB0, PB1 = G::PB1;
     constexpr int UNIT_MAX = PA > PB0 ? PA : PB0;
+    // SCHED 4 (round 6, 320-wide 3x3 / stride 1 / pad 1 convs): the three HORIZONTAL taps of a (channel block, ky) share ONE A slab.  In the
+    // flattened pixel order tap kx of output pixel m reads input pixel m + (ky - 1) W + (kx - 1): the slab of tap kx = 0 shifted by kx rows.  So the
+    // A region holds 258 rows — LDS row r = input pixel m0 - 1 + r (+ the ky row shift) — loaded once per group of three K slabs (two 272-row A
+    // buffers alternating by group, the 40 KB weight slabs still alternate by slab), and the fragment reads of tap kx start kx rows further
+    // down.  The left / right image border, where the flattened neighbour is a pixel of the next image row, is a per-lane select of the fragment
+    // address: border lanes read a zero row.  Operand bytes into the CU per channel block: 3 x 34 + 9 x 40 KB instead of 9 x 72 (-29 %) — the lever
+    // the round-4/6 ablations point at (zero-filling the A pieces of kx = 1, 2 without touching the instruction stream: +6...8 %,
+    // profiles/r06_xl_a_bytes_ablation.log).  The row swizzle of this A region is row & 7 (conflict-free ds_read_b128 for row shifts 0, 1, 2;
+    // the (row >> 1) & 7 rule of the other regions pairs even / odd rows and collides 2-way under an odd shift: tests/xl_layout_check.cpp).
+    constexpr bool KXS = SCHED == 4;
+    static_assert(!KXS || (BN == 320 && CONV), "the shared-tap schedule is the 320-wide conv's");
+    constexpr int AS_ROWS = 272, AS_BYTES = AS_ROWS * 128;       // 256 + 2 halo rows (+ 6 of their piece) + 8 zero rows (the dummy pieces' target, the border select's source)
+    constexpr int ZROW_OFF = 264 * 128;
+    constexpr int B_STRIDE = KXS ? (G::BNP * 128) : (BM * 128 + G::BNP * 128);      // SCHED 4: [A buf 0 | A buf 1 | B buf 0 | B buf 1]; else [A | B] x 2
+    constexpr int B_BASE = KXS ? 2 * AS_BYTES - BM * 128 : 0;                        // (b_lds / b_rd carry the A_BYTES of the interleaved layout)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -90,6 +105,14 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
     const xl_rsrc_t rsB = xl_make_rsrc(p.W + (long)n0 * p.ldw);
     const unsigned lds0 = (unsigned)(unsigned long long)(lds_void_t*)smem;      // LDS byte address of the dynamic region
 
+    // SCHED 4 keeps its per-lane state in TWO registers (the 320-wide kernel has none to spare: 160 accumulators + 56 fragment registers):
+    //   xs_bits  bits 3 (2 h + e) + ky: LDS row of piece (h, e) exists for row shift ky - 1;  12 + ky: the halo piece's;  16 + i / 24 + i: MFMA row
+    //            tile i of this lane sits on the left / right image border
+    //   xs_vb    byte offset of this lane's 16 bytes inside ANY A piece: (lane >> 3) rows + the chunk ((lane & 7) ^ (row & 7)) — piece rows start at
+    //            multiples of 8, so the swizzle does not depend on the piece; the piece's first row is added as a scalar at issue time
+    unsigned xs_bits = 0;
+    const unsigned xs_vb = (unsigned)((long)(lane >> 3) * p.lda * 2 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4));
+    const unsigned xb_vb = (unsigned)((long)(lane >> 3) * p.ldw * 2 + (((lane & 7) ^ ((lane >> 4) & 3)) << 4));     // (row >> 1) & 7 of rows 0..7
     unsigned a_voff[2][PA];                                      // [unit A0 / A1][piece]
     unsigned a_taps[2][PA];                                      // CONV: bit t set = tap t reads inside the image (else zero)
     int a_lds[2][PA];                                            // LDS byte offset of the piece inside a buffer (wave-uniform)
@@ -103,6 +126,18 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
             const int cl = piece_lane_chunk(row0, lane);
             const int m = m0 + R;
             a_taps[h][e] = 0;
+            if constexpr (KXS) {
+                // LDS row R = input pixel q = m0 - 1 + R of the centre image row (the ky shift rides in the scalar offset): bit ky = q exists and
+                // its row y + ky - 1 is inside the image (the x position is the pixel's own: always inside)
+                const long q = (long)m0 + R - 1;
+                unsigned bits = 0;
+                if (q >= 0 && q < p.M) {
+                    const int b_ = (int)(q / hw), y_ = (int)(q - (long)b_ * hw) / Wo;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) if ((unsigned)(y_ + ky - 1) < (unsigned)p.Hi) bits |= 1u << ky;
+                }
+                xs_bits |= bits << (3 * (2 * h + e));             // (a_voff / a_taps stay unused: ONE base offset + the piece's wave-uniform row offset, XS_PIECE_A)
+            } else
             if (CONV) {
                 const int mm = min(m, p.M - 1);
                 const int b = mm / hw, rem = mm - b * hw;
@@ -139,6 +174,16 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
             }
         }
 
+    // SCHED 4: the slab's rows 256, 257 (+ 6 zero-filled rows of their piece) come from wave 7; the other waves' extra piece zero-fills rows 264-271
+    if constexpr (KXS) {
+        const int R = 256 + (lane >> 3);
+        const long q = (long)m0 + R - 1;
+        if (wave == 7 && R < 258 && q < p.M) {
+            const int b_ = (int)(q / hw), y_ = (int)(q - (long)b_ * hw) / Wo;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) if ((unsigned)(y_ + ky - 1) < (unsigned)p.Hi) xs_bits |= 1u << (12 + ky);
+        }
+    }
     // slab T -> scalar byte offsets of its k position in A and W
     const int row_bytes = (int)(p.lda * 2);
     auto a_soff = [&](int T, int& tap) -> int {
@@ -162,33 +207,79 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
     // the MFMA clusters splits their scheduling regions.
 #ifdef MDX_XL_ABLATE
     const bool do_mma = !(p.dbg & 1), do_dma = !(p.dbg & 2);
+    // round 6, the price of the 3x3 conv's nine A fetches per channel block (what a shared input halo would save): 16 = the A pieces of taps 1..8 are
+    // issued with out-of-range offsets (zero fill: same instruction stream, none of their bytes enter the CU); 32 = they are not issued at all
+    // (the hand-counted waits then cover less than they should: timing only, an optimistic bound)
+    const bool a_oob = CONV && (p.dbg & 16), a_skip = CONV && (p.dbg & 32);
+    const bool a_oob_kx = CONV && (p.dbg & 64);                   // 64 = zero fill only for kx != 0 (what sharing a row's three horizontal taps would save)
 #else
-    constexpr bool do_mma = true, do_dma = true;
+    constexpr bool do_mma = true, do_dma = true, a_oob = false, a_skip = false, a_oob_kx = false;
 #endif
     // ONE 1-KiB piece (e) of a load unit of slab T into buffer T & 1; nothing past the last slab (the waits account for it)
 #define XL_PIECE_A(h, e, T)                                                                                                       \
     if constexpr ((e) < PA) {                                                                                                     \
-        if ((T) < nt && do_dma) {                                                                                                 \
+        if ((T) < nt && do_dma && !(a_skip && ((T) % 9) != 0)) {                                                                  \
             int tap_;                                                                                                             \
             const int so_ = a_soff((T), tap_);                                                                                    \
-            const unsigned vo_ = CONV ? (((a_taps[h][(e) < PA ? (e) : 0] >> tap_) & 1u) ? a_voff[h][(e) < PA ? (e) : 0] : XL_OOB) \
-                                      : a_voff[h][(e) < PA ? (e) : 0];                                                            \
+            unsigned vo_ = CONV ? (((a_taps[h][(e) < PA ? (e) : 0] >> tap_) & 1u) ? a_voff[h][(e) < PA ? (e) : 0] : XL_OOB)       \
+                                : a_voff[h][(e) < PA ? (e) : 0];                                                                  \
+            if ((a_oob && tap_ != 0) || (a_oob_kx && (tap_ % 3) != 0)) vo_ = XL_OOB;                                              \
             xl_glds(rsA, lds0 + ((T) & 1) * BUF + a_lds[h][(e) < PA ? (e) : 0], vo_, so_);                                        \
         }                                                                                                                         \
     }
 #define XL_PIECE_B(part, e, T)                                                                                                    \
     if constexpr ((e) < ((part) ? PB1 : PB0)) {                                                                                   \
         if ((T) < nt && do_dma)                                                                                                   \
-            xl_glds_b(rsB, lds0 + ((T) & 1) * BUF + b_lds[part][(e) < UNIT_MAX ? (e) : 0], b_voff[part][(e) < UNIT_MAX ? (e) : 0],  \
-                    b_soff((T)));                                                                                                 \
+            xl_glds_b(rsB, lds0 + ((T) & 1) * B_STRIDE + B_BASE + b_lds[part][(e) < UNIT_MAX ? (e) : 0],                            \
+                      b_voff[part][(e) < UNIT_MAX ? (e) : 0], b_soff((T)));                                                       \
     }
 #define XL_ISSUE_A(h, T) { XL_PIECE_A(h, 0, T) XL_PIECE_A(h, 1, T) }
+    // SCHED 4: unit h of the shared A slab of GROUP G = (channel block, ky) into A buffer G & 1; xs_ky / xs_so = ky and scalar offset of that group
+#define XS_PIECE_A(h, e, G)                                                                                                       \
+    if ((G) < ng && do_dma) {                                                                                                     \
+        unsigned va_ = xs_vb;                                                                                                     \
+        asm volatile("" : "+v"(va_));                                                                                             \
+        const unsigned vo_ = va_ + (unsigned)((a_lds[h][e] >> 7) * row_bytes);                                                    \
+        xl_glds(rsA, lds0 + ((G) & 1) * AS_BYTES + a_lds[h][e], ((xs_bits >> (3 * (2 * (h) + (e)) + xs_ky)) & 1u) ? vo_ : XL_OOB, xs_so); \
+    }
+    // B pieces of SCHED 4 from ONE per-lane register too (N % 320 == 0: no column tail): piece rows start at multiples of 8, so only the parity of
+    // row0 / 8 enters the (row >> 1) & 7 swizzle — bit 2 of the chunk = bit 6 of the byte offset (ldw * 2 is a multiple of 128)
+#define XS_PIECE_B(part, e, T)                                                                                                    \
+    if constexpr ((e) < ((part) ? PB1 : PB0)) {                                                                                   \
+        if ((T) < nt && do_dma) {                                                                                                 \
+            const int r0_ = (b_lds[part][(e) < UNIT_MAX ? (e) : 0] - A_BYTES) >> 7;                                               \
+            unsigned vb_ = xb_vb;                                                                                                 \
+            asm volatile("" : "+v"(vb_));   /* formed HERE: as loop invariants the five offsets are hoisted and then spilled (scratch reloads + vmcnt(0) in the loop) */ \
+            const unsigned vo_ = (vb_ ^ (unsigned)(((r0_ >> 3) & 1) << 6)) + (unsigned)(r0_ * (int)(p.ldw * 2));                  \
+            xl_glds_b(rsB, lds0 + ((T) & 1) * B_STRIDE + B_BASE + b_lds[part][(e) < UNIT_MAX ? (e) : 0], vo_, b_soff((T)));        \
+        }                                                                                                                         \
+    }
+#define XS_ISSUE_B(part, T) { XS_PIECE_B(part, 0, T) XS_PIECE_B(part, 1, T) XS_PIECE_B(part, 2, T) }
+#define XS_ISSUE_A0(G) { XS_PIECE_A(0, 0, G) XS_PIECE_A(0, 1, G) }
+#define XS_ISSUE_A1X(G)                                                                                                           \
+    {                                                                                                                             \
+        XS_PIECE_A(1, 0, G) XS_PIECE_A(1, 1, G)                                                                                   \
+        unsigned va2_ = xs_vb;                                                                                                    \
+        asm volatile("" : "+v"(va2_));                                                                                            \
+        if ((G) < ng && do_dma)                                                                                                   \
+            xl_glds(rsA, lds0 + ((G) & 1) * AS_BYTES + (wave == 7 ? 256 * 128 : ZROW_OFF),                                        \
+                    ((xs_bits >> (12 + xs_ky)) & 1u) ? va2_ + (unsigned)(256 * row_bytes) : XL_OOB, xs_so);                       \
+    }
 #define XL_ISSUE_B(part, T) { XL_PIECE_B(part, 0, T) XL_PIECE_B(part, 1, T) XL_PIECE_B(part, 2, T) }
 
     // ---- fragment read offsets (bytes inside a buffer) ----
     const int fo0 = frag_off(0, lane, 0), fo1 = frag_off(0, lane, 1);     // row part = (lane & 15) * 128: tile row blocks add multiples of 2048
     const int a_rd = a_tile_row0<BN>(wm, 0) * 128;
     const int b_rd = A_BYTES + b_tile_row0<BN>(wn, 0) * 128;
+    if constexpr (KXS) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int m_ = m0 + a_tile_row0<BN>(wm, i) + (lane & 15);
+            const int ox_ = m_ % Wo;                              // (rows past M: their outputs are never stored)
+            if (ox_ == 0) xs_bits |= 1u << (16 + i);
+            if (ox_ == Wo - 1) xs_bits |= 1u << (24 + i);
+        }
+    }
 
     f32x4_t acc[TI][TJ];
 #pragma unroll
@@ -208,9 +299,25 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
             af[i][1].u = *(const uint4*)(s_ + i * 2048 + fo1);                                                                    \
         }                                                                                                                         \
     }
+    // SCHED 4: A half h of the shared slab in A buffer ab_, tap kx_ (rows shifted by kx_); lanes whose output pixel sits on the left (kx 0) / right
+    // (kx 2) image border read the zero row instead (xs_lb / xs_rb: bit i = MFMA row tile i of this lane is on that border)
+#define XS_READ_A(h, ab_)                                                                                                         \
+    {                                                                                                                             \
+        const unsigned char* s_ = smem + (ab_) * AS_BYTES;                                                                        \
+        unsigned bb_ = xs_bsel;                                                                                                   \
+        asm volatile("" : "+v"(bb_));   /* the selects are formed HERE: hoisted out of the loop they are 48 live values (seen as scratch reloads inside the slab loop) */ \
+        const int f0_ = xs_f0, f1_ = xs_f0 ^ 64;                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TIH; ++i) {                                                                         \
+            const int it_ = (h) * TIH + i;                                                                                        \
+            const bool z_ = (bb_ >> it_) & 1u;                                                                                    \
+            const int o0_ = z_ ? ZROW_OFF - it_ * 2048 : f0_, o1_ = z_ ? ZROW_OFF - it_ * 2048 : f1_;                             \
+            af[i][0].u = *(const uint4*)(s_ + o0_ + it_ * 2048);                                                                  \
+            af[i][1].u = *(const uint4*)(s_ + o1_ + it_ * 2048);                                                                  \
+        }                                                                                                                         \
+    }
 #define XL_READ_B(J0, NJ, buf_)                                                                                                   \
     {                                                                                                                             \
-        const unsigned char* s_ = smem + (buf_) * BUF + b_rd;                                                                     \
+        const unsigned char* s_ = smem + (buf_) * B_STRIDE + B_BASE + b_rd;                                                       \
         _Pragma("unroll") for (int j = (J0); j < (J0) + (NJ); ++j) {                                                              \
             bfr[j][0].u = *(const uint4*)(s_ + j * 2048 + fo0);                                                                   \
             bfr[j][1].u = *(const uint4*)(s_ + j * 2048 + fo1);                                                                   \
@@ -218,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
     }
 #define XL_READ_B_TO(D0, J0, NJ, buf_)                                                                                            \
     {                                                                                                                             \
-        const unsigned char* s_ = smem + (buf_) * BUF + b_rd;                                                                     \
+        const unsigned char* s_ = smem + (buf_) * B_STRIDE + B_BASE + b_rd;                                                       \
         _Pragma("unroll") for (int j = 0; j < (NJ); ++j) {                                                                        \
             bfr[(D0) + j][0].u = *(const uint4*)(s_ + ((J0) + j) * 2048 + fo0);                                                   \
             bfr[(D0) + j][1].u = *(const uint4*)(s_ + ((J0) + j) * 2048 + fo1);                                                   \
@@ -308,6 +415,72 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
         }
     }
     XL_STAMP(1)
+    if constexpr (KXS) {
+        // ===== schedule 4: the 256 x 320 quadrant order with ONE A slab per (channel block, ky) shared by its three kx slabs ==================
+        //   group g = (cb, ky) = slabs T = 3 g + kx; A buffer g & 1, B buffer T & 1; per slab the quadrants of the 320-wide schedule:
+        //   reads:   q0 A0,B0   q1 A1   q2 B1   q3 A0
+        //   issues:  q0 A0(g+1) [kx 0]   q1 B0(T+2)   q2 A1(g+1) + the halo piece [kx 1]   q3 B1(T+2)
+        //   A buffer (g+1) & 1 was last read by group g - 1; B0 / B1 of buffer T & 1 were read in q0 / q2 of this slab (as in the per-slab schedule).
+        //   wait in q3(T) for everything up to B1(T+1) (issued in q3(T-1)): the pieces issued during slab T follow it:
+        //     kx 0: PA + PB0 + PB1   kx 1: PB0 + PA + 1 + PB1   kx 2: PB0 + PB1 (the next group's A, issued in the two slabs before, is older)
+        //   last group: no A is issued, and its last two slabs issue no B either (as the per-slab schedule's tail)
+        const int ng = nt / 3;                                       // nt = 9 Cin / 64
+        int xs_ky = 0, xs_so = 0;                                    // ky / scalar offset of the group being ISSUED
+        auto xs_group = [&](int g_) { const int cb_ = g_ / 3; xs_ky = g_ - cb_ * 3; xs_so = xs_ky * p.Wi * row_bytes + cb_ * 128; };
+        xs_group(0);
+        XS_ISSUE_A0(0)
+        XS_ISSUE_A1X(0)
+        XS_ISSUE_B(0, 0)
+        XS_ISSUE_B(1, 0)
+        XS_ISSUE_B(0, 1)
+        XS_ISSUE_B(1, 1)
+        xl_wait_vmcnt<PB0 + PB1>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        XL_STAMP(2)
+        if (grp == 1) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ONE loop over the slabs (kx, the group and its A buffer are scalar state): as two nested loops the accumulators were loop-carried through
+        // both headers and the allocator copied all 160 of them every slab (78 v_mov_b64 per iteration in the .s)
+        int kx = 0, g = 0, ab = 0;
+        bool more = ng > 1;
+        xs_group(1);
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            // fragment offset (k32 step 0; step 1 = ^ 64) of row (lane & 15) + kx — tile row blocks are multiples of 16, they do not change
+            // row & 7 — and the border bits of this tap: left border for kx 0, right border for kx 2, none for the centre tap
+            const int r_ = (lane & 15) + kx;
+            const int xs_f0 = a_rd + r_ * 128 + (((lane >> 4) ^ (r_ & 7)) << 4);
+            const unsigned xs_bsel = kx == 0 ? (xs_bits >> 16) & 0xffu : kx == 2 ? xs_bits >> 24 : 0u;
+            XS_READ_A(0, ab)
+            XL_READ_B_TO(0, 0, TJ0, buf)
+            if (kx == 0) XS_ISSUE_A0(g + 1)
+            XL_SEG_END()
+            XL_MMA_TO(0, 0, 0, TJ0)
+            XL_MMA_END()
+            XS_READ_A(1, ab)
+            XS_ISSUE_B(0, t + 2)
+            XL_SEG_END()
+            XL_MMA_TO(1, 0, 0, TJ0)
+            XL_MMA_END()
+            XL_READ_B_TO(0, TJ0, TJ1, buf)
+            if (kx == 1) XS_ISSUE_A1X(g + 1)
+            XL_SEG_END()
+            XL_MMA_TO(1, 0, TJ0, TJ1)
+            XL_MMA_END()
+            XS_READ_A(0, ab)
+            XS_ISSUE_B(1, t + 2)
+            if (kx == 0) { if (more) xl_wait_vmcnt<PA + PB0 + PB1>(); else xl_wait_vmcnt<PB0 + PB1>(); }
+            else if (kx == 1) { if (more) xl_wait_vmcnt<PB0 + PA + 1 + PB1>(); else xl_wait_vmcnt<0>(); }
+            else { if (more) xl_wait_vmcnt<PB0 + PB1>(); else xl_wait_vmcnt<0>(); }
+            XL_SEG_END()
+            XL_MMA_TO(0, 0, TJ0, TJ1)
+            XL_MMA_END()
+            if (++kx == 3) { kx = 0; ++g; ab ^= 1; more = g + 1 < ng; xs_group(g + 1); }
+        }
+    } else
     if constexpr (BN == 320) {
         // ===== 256 x 320: quadrant order (A0,B0) (A1,B0) (A1,B1) (A0,B1) so that B0 and B1 are never live together (160 accumulators
         // leave room for one A half + 3 B tiles); A0 is read twice per slab (34 instead of 26 fragment reads: LDS port time is not the
@@ -506,6 +679,12 @@ __global__ __launch_bounds__(512, 2) void gemm_xl_kernel(GCParams p) {
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef XL_PIECE_A
+#undef XS_PIECE_A
+#undef XS_PIECE_B
+#undef XS_ISSUE_B
+#undef XS_ISSUE_A0
+#undef XS_ISSUE_A1X
+#undef XS_READ_A
 #undef XL_PIECE_B
 #undef XL_ISSUE_A
 #undef XL_ISSUE_B
@@ -1157,7 +1336,8 @@ constexpr size_t xl_smem_bytes() {
 
 template <int BN, bool CONV, int SCHED>
 static int launch_xl(const GCParams& p, hipStream_t st) {
-    constexpr size_t smem = xl_smem_bytes<BN>();
+    constexpr size_t smem_kxs = (size_t)2 * 272 * 128 + (size_t)2 * Geo<BN>::BNP * 128;      // SCHED 4: two 272-row A buffers + two weight slabs
+    constexpr size_t smem = (SCHED == 4 && smem_kxs > xl_smem_bytes<BN>()) ? smem_kxs : xl_smem_bytes<BN>();
     static_assert(smem <= 163840, "LDS budget");
     auto kern = gemm_xl_kernel<BN, CONV, SCHED>;
     if (int rc = ensure_dyn_smem((const void*)kern, smem, "xl")) return rc;
@@ -1209,7 +1389,7 @@ static int launch_xl(const GCParams& p, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), smem, st, q);
     char tag[96];
-    snprintf(tag, sizeof tag, "gemm_xl_kernel<256x%d,%s>", BN, CONV ? "conv" : "gemm");   // (the schedule is a tuning knob, not part of the name)
+    snprintf(tag, sizeof tag, "gemm_xl_kernel<256x%d,%s>", BN, CONV ? (SCHED == 4 ? "conv,kxs" : "conv") : "gemm");   // (schedules 0-3 are tuning knobs, not part of the name)
     return check_launch(tag);
 }
 
@@ -1243,7 +1423,18 @@ bool xl_supported(const GCParams& p, bool conv, int bn) {
 int launch_gemm_xl(const GCParams& p, bool conv, int bn, hipStream_t st) {
     const int sched = (int)opt(OPT_XL_SCHED);
 #define XL_GO(BN_, S_) (conv ? launch_xl<BN_, true, S_>(p, st) : launch_xl<BN_, false, S_>(p, st))
-    if (bn == 320) return XL_GO(320, 0);
+    if (bn == 320) {
+        // 3x3 / stride 1 convs: the three horizontal taps of a (channel block, ky) share one A slab (schedule 4; XL_KXSHARE = 0: per-tap slabs, A/B)
+        // Built, correct (tests/test_routes_gpu.py::test_xl_conv in a -DMDX_XL_KXS build) and 18-21 % SLOWER than one slab per tap: the border
+        // selects + per-piece offset arithmetic put ~100 more VALU instructions per slab into the load segments, which are the serial resource
+        // (profiles/r06_xl_kxshare_ab.log) — more than the -29 % operand bytes buy (+6...8 %, profiles/r06_xl_a_bytes_ablation.log).  Not in the
+        // product build; `make side SIDE=kxs FLAGS=-DMDX_XL_KXS` builds it for A/B runs.
+#ifdef MDX_XL_KXS
+        if (conv && opt(OPT_XL_KXSHARE) && p.sh == 1 && p.sw == 1 && p.Hi == p.Ho && p.Wi == p.Wo && p.Wo >= 2 && (p.K / 64) % 9 == 0 && p.N % 320 == 0)
+            return launch_xl<320, true, 4>(p, st);
+#endif
+        return XL_GO(320, 0);
+    }
     if (bn == 256) return sched == 1 ? XL_GO(256, 1) : sched == 2 ? XL_GO(256, 2) : sched == 3 ? XL_GO(256, 3) : XL_GO(256, 0);
     return sched == 1 ? XL_GO(160, 1) : sched == 2 ? XL_GO(160, 2) : sched == 3 ? XL_GO(160, 3) : XL_GO(160, 0);
 #undef XL_GO

@@ -54,6 +54,7 @@ namespace mdx {
     X(GN_TWO_STAGE, 1, "streaming two-stage GroupNorm for maps >= 32768 elements") \
     X(XL_PERSIST, 1, "256x256 XL GEMMs (plain / GEGLU, optional residual) on the persistent kernel gemm_xlp_kernel") \
     X(XL_RASTER, 2, "XL tile order: 0 row-major, 1 XCD-strided M-tiles, 2 XCD-blocked (M-group x N-group panels per XCD)") \
+    X(XL_KXSHARE, 1, "only in -DMDX_XL_KXS side builds: 320-wide XL 3x3 / stride 1 convs share one A slab in LDS between the three horizontal taps of a (channel block, ky) (schedule 4; measured slower, gemm_xl.hip: launch_gemm_xl)") \
     X(XL_GM, 0, "XL_RASTER 2: force the M-tiles per panel (0 = cost model, xl_layout.h: raster_shape)") \
     X(XL_GN, 0, "XL_RASTER 2: force the N-tiles per panel (0 = cost model)") \
     X(STREAMS, 2, "host side (pipeline): HIP streams a pipe() call spreads its scene chunks over (chunks of >= 16 scenes, one plan + hipGraph each)") \

@@ -150,10 +150,19 @@ def test_xl_conv(dev, B, H, W, Cin, Cout, stride, res, temb, expect):
     y = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=BF, device=dev)
     R = rnd(B, Ho, Wo, Cout, seed=4) if res else None
     tb = rnd(B, Cout, seed=5, dtype=torch.float32) if temb else None
-    k = run_one(O.Conv(x, PK.pack_conv_weight(w.cpu(), BF).to(dev), y, bias=b, R=R, temb=tb, temb_b_stride=Cout if temb else 0,
-                       stride=stride, pad=(1, 1), ws=ws_buf()))
-    assert k.startswith(expect) and k.endswith(",conv>"), f"routed to {k!r}, expected {expect!r}"
-    close(y, conv_ref(x, w, b, stride, (1, 1), tb, R), name=f"xl conv {B}x{H}x{W} {Cin}->{Cout}")
+    ref = conv_ref(x, w, b, stride, (1, 1), tb, R)
+    seen = set()
+    # XL_KXSHARE (round 6, only in -DMDX_XL_KXS side builds — loaded through MDX_LIB_PATH — the product build ignores the switch): 320-wide stride-1
+    # convs whose Cout is a multiple of 320 share one A slab between the three horizontal taps of a (channel block, ky) — schedule 4, kernel name
+    # "...conv,kxs>"; 0 = one slab per tap.  Both forms against the fp32 reference.
+    for share in (1, 0):
+        y.fill_(float("nan"))
+        with L.options(XL_KXSHARE=share):
+            k = run_one(O.Conv(x, PK.pack_conv_weight(w.cpu(), BF).to(dev), y, bias=b, R=R, temb=tb, temb_b_stride=Cout if temb else 0,
+                               stride=stride, pad=(1, 1), ws=ws_buf()))
+        assert k.startswith(expect) and (k.endswith(",conv>") or (share and k.endswith(",conv,kxs>"))), f"routed to {k!r}, expected {expect!r}"
+        close(y, ref, name=f"xl conv {B}x{H}x{W} {Cin}->{Cout} {k}")
+        seen.add(k)
 
 
 def test_xl320_edge_tile_reads_no_residual_past_its_buffer(dev):
