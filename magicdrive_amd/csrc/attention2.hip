@@ -789,7 +789,9 @@ int launch_attn2(const Attn2Params& p, hipStream_t st) {
     if (p.d == 40 && fold && p.nsrc == 1 && (p.Tk + A2_KV - 1) / A2_KV <= A2_NBUF &&
         (res_opt == 2 || (res_opt == 1 && p.Tq >= 512 && (long)p.B * p.H >= 1024)))
         return launch_attn2_res<5, true>(p, st);
-    if (attn3_supported(p)) return launch_attn3(p, st);          // round 5: the software-pipelined, permute-free form (attention3.hip)
+#ifdef MDX_ATTN3                                                  // tools/attn3/attention3.hip, only in `make ATTN3=1` builds (round 6: out of the product library)
+    if (attn3_supported(p)) return launch_attn3(p, st);          // round 5: the software-pipelined, permute-free form
+#endif
     if (p.d == 40) {
         // FOLD frees the registers / VALU slots of the scale-and-subtract: with it the 32-query form (<= 142 VGPRs: three waves per SIMD)
         // is the faster one for one kv source (768 views, T = 1400: self 3157 vs 3332 us, text context 640 vs 795 us; the two-source

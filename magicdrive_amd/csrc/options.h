@@ -19,7 +19,7 @@ namespace mdx {
     X(ATTN_NW8_BLOCKS, (1L << 40), "attention.hip: 8-wave workgroups from this many blocks") \
     X(ATTN_NW, 0, "force the waves per workgroup of attention.hip (0 = heuristic)") \
     X(ATTN2, 1, "attention2.hip for head dim 40") \
-    X(ATTN3, 0, "attention3.hip (permute-free P, QK of the next kv tile beside this tile's softmax) for the head-dim-40 FOLD launches: self, cross-view, joint") \
+    X(ATTN3, 0, "only in `make ATTN3=1` builds: tools/attn3/attention3.hip (permute-free P, QK of the next kv tile beside this tile's softmax) for the head-dim-40 FOLD launches: self, cross-view, joint") \
     X(ATTN3_WGS, 0, "attention3.hip: persistent workgroups per XCD (0 = automatic: two per CU)") \
     X(ATTN2_PF, 1, "attention2.hip, head dim 40 FOLD 32-query form: permute-free P (PV on 32x32x16 MFMAs, K rows permuted so that a lane's scores are its PV operand)") \
     X(ATTN2_D80, 2, "attention2.hip for head dim 80: 0 never, 1 always, 2 only the two-source cross-view form") \

@@ -287,7 +287,7 @@ def test_forced_geglu320_on_xl(dev):
 
 @pytest.mark.parametrize("mode,opts", [("attn_q32", {"ATTN2_QT": 1}), ("attn_q64", {"ATTN2_QT": 2}), ("attn_d80", {"ATTN2_D80": 1}), ("attn_d80_off", {"ATTN2_D80": 0}),
                                        ("attn_old", {"ATTN2": 0}), ("attn_nofold", {"ATTN2_FOLD": 0}), ("attn_bh_order", {"ATTN2_VIEWMAP": 0, "ATTN_SWZ": 1}),
-                                       ("attn3", {"ATTN3": 1}), ("attn3_one_wg_per_xcd", {"ATTN3": 1, "ATTN3_WGS": 1}), ("attn_nopf", {"ATTN2_PF": 0}), ("attn_nopf_q64", {"ATTN2_PF": 0, "ATTN2_QT": 2})])
+                                       ("attn_nopf", {"ATTN2_PF": 0}), ("attn_nopf_q64", {"ATTN2_PF": 0, "ATTN2_QT": 2})])
 def test_forced_attention_routes(dev, mode, opts):
     """attention2.hip's other instantiations (32- / 64-query waves; head dim 80 on / off; the per-(view, head) block order of rounds 2-3)
     and attention.hip at the same shapes, through the tests of tests/test_kernels_gpu.py (their route assertions follow the current
