@@ -225,7 +225,8 @@ class UniPCMultistepScheduler:
         ts = ts[np.sort(uniq)]
         self.timesteps = torch.from_numpy(ts)
         self.num_inference_steps = len(ts)
-        self._host_state = None                    # step(): a new timestep list starts a new history
+        self._host_state = {}                      # step(): a new timestep list starts new histories (one per (device, sample shape))
+        self._t2i = None
         return self.timesteps
 
     def scale_model_input(self, sample, timestep=None):
@@ -310,22 +311,30 @@ class UniPCMultistepScheduler:
         from . import ops as O
         if self.num_inference_steps is None:
             raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
-        t = int(timestep.reshape(-1)[0].item()) if isinstance(timestep, torch.Tensor) else int(timestep)
-        hits = (self.timesteps == t).nonzero()
-        if hits.numel() == 0:
+        t = int(timestep.reshape(-1)[0].item()) if isinstance(timestep, torch.Tensor) else int(timestep)      # (a host int costs no device sync)
+        if getattr(self, "_t2i", None) is None:
+            self._t2i = {}
+            for i_, t_ in enumerate(self.timesteps.tolist()):
+                self._t2i.setdefault(int(t_), i_)
+        if t not in self._t2i:
             raise ValueError(f"timestep {t} is not in this scheduler's timestep list")
-        idx = int(hits[0])
+        idx = self._t2i[t]
         dev = sample.device
-        st = getattr(self, "_host_state", None)
-        key = (dev, tuple(sample.shape))
-        if idx == 0 or st is None or st["key"] != key:
+        # one history per (device, sample shape): samples of different shapes (or on different devices) may share this scheduler object and interleave
+        # their steps, like diffusers' host-side class; two samples of the SAME shape on one device cannot be told apart — use one scheduler each
+        states = getattr(self, "_host_state", None)
+        if not isinstance(states, dict):
+            states = self._host_state = {}
+        key = (str(dev), tuple(sample.shape))
+        st = states.get(key)
+        if idx == 0 or st is None:
             if idx != 0:
                 raise ValueError(f"UniPC.step: timestep {t} is step {idx} of the list but no history exists for a sample of shape {tuple(sample.shape)} on {dev} "
                                  "(step() must be called for every timestep in order, starting with the first)")
             n = sample.numel()
-            st = self._host_state = dict(key=key, coef=self.coefficient_table().to(dev), next=0,
-                                         x_last=torch.zeros(n, dtype=torch.float32, device=dev), m1=torch.zeros(n, dtype=torch.float32, device=dev),
-                                         m2=torch.zeros(n, dtype=torch.float32, device=dev))
+            st = states[key] = dict(key=key, coef=self.coefficient_table().to(dev), next=0,
+                                    x_last=torch.zeros(n, dtype=torch.float32, device=dev), m1=torch.zeros(n, dtype=torch.float32, device=dev),
+                                    m2=torch.zeros(n, dtype=torch.float32, device=dev))
         if idx != st["next"]:
             raise ValueError(f"UniPC.step: expected step {st['next']} of the timestep list next, got {idx} (timestep {t}): the multistep history is sequential")
         x = sample.detach().to(torch.float32).contiguous().clone()

@@ -550,3 +550,17 @@ def test_unipc_host_step_api_reproduces_the_diffusers_kat(monkeypatch):
         s.step(sample, s.timesteps[2], sample)
     with pytest.raises(ValueError):
         s.step(sample, 12345, sample)
+    # two samples of different shapes share ONE scheduler object and interleave their steps (one history per (device, shape)),
+    # host-int timesteps; each reproduces its own sequential run
+    s.set_timesteps(6)
+    xa, xb = torch.randn(2, 4, 6, 6, generator=torch.Generator().manual_seed(1)), torch.randn(1, 4, 5, 7, generator=torch.Generator().manual_seed(2))
+    ya, yb = xa.clone(), xb.clone()
+    for t in s.timesteps.tolist():
+        ya = s.step(ya * 0.3, int(t), ya).prev_sample
+        yb = s.step(yb * -0.2, int(t), yb).prev_sample
+    for x0, y, f in ((xa, ya, 0.3), (xb, yb, -0.2)):
+        s2 = UniPCMultistepScheduler(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", solver_order=2, solver_type="bh1")
+        z = x0.clone()
+        for t in s2.set_timesteps(6):
+            z = s2.step(z * f, t, z).prev_sample
+        assert torch.equal(z, y)
