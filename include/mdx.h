@@ -42,7 +42,7 @@ extern "C" {
 #define MDX_ELAUNCH (-2)     /* hip launch / runtime error */
 #define MDX_EUNSUPPORTED (-3)
 
-#define MDX_ABI_VERSION 9
+#define MDX_ABI_VERSION 10
 
 /* ---- epilogue flags shared by GEMM / conv ------------------------------- */
 #define MDX_EPI_NONE 0
@@ -111,6 +111,14 @@ typedef struct MdxGemmDesc {
     int64_t rowstat_parts;
     const float* ln_stats;
     int64_t ln_stats_parts;
+    /* Optional second copy of W in MFMA-fragment order (ABI 10), for the W-direct persistent kernel (csrc/gemm_xd.hip: the weights go
+     * global -> registers past the LDS, the finished tile is stored under the next tile's main loop):
+     *     Wq[n / 16][k / 32][lane][8]  with lane = ((k % 32) / 8) * 16 + n % 16,  element = W[n][k + (0..7)],
+     * i.e. the 64 lanes' operands of one 16-column x 32-deep block are one contiguous KiB; N padded with zero blocks to a multiple of 256
+     * (roundup(N, 256) * K elements; magicdrive_amd/packing.py: pack_wq).  GEGLU: W (and so Wq) rows in the [32 value | 32 gate] order.
+     * The library uses it when the shape goes to the 256-wide persistent tile and K % 128 == 0, K >= 640 (plain / GEGLU epilogue, optional
+     * residual, no temb / Vt / split-K); otherwise it is ignored and W is read.  W must be given either way.  NULL: off. */
+    const void* Wq;
 } MdxGemmDesc;
 int mdx_gemm_bf16(const MdxGemmDesc* d, void* stream);
 

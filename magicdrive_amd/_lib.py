@@ -13,7 +13,7 @@ from typing import Dict, List, Tuple
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDX_LIB_PATH") or os.path.join(_HERE, "libmdx.so")      # MDX_LIB_PATH: A/B a second build (tools only)
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # opcodes (mdx.h)
 OP_GEMM, OP_CONV, OP_CONV_DIRECT, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM = 1, 2, 3, 4, 5, 6
@@ -36,7 +36,7 @@ def _f(kind, names: str):
 
 MdxGemmDesc = _struct("MdxGemmDesc", _f(P, "A W C R bias temb sel_ptr ws") + _f(I, "M N K lda ldw ldc ldr batch sA sW sC sR "
                       "temb_sel_stride temb_b_stride rows_per_b epilogue splitk c_is_f32 ws_bytes") + _f(P, "Vt") + _f(I, "vt_from vt_T vt_ld vt_stride")
-                      + _f(D, "ln_eps") + _f(P, "ln_csum ln_scratch") + _f(P, "rowstat_out") + _f(I, "rowstat_parts") + _f(P, "ln_stats") + _f(I, "ln_stats_parts"))
+                      + _f(D, "ln_eps") + _f(P, "ln_csum ln_scratch") + _f(P, "rowstat_out") + _f(I, "rowstat_parts") + _f(P, "ln_stats") + _f(I, "ln_stats_parts") + _f(P, "Wq"))
 MdxConvDesc = _struct("MdxConvDesc", _f(P, "X Wt Y R bias temb sel_ptr ws") + _f(I, "B Hi Wi Cin Ho Wo Cout kh kw sh sw ph pw "
                       "ldx ldy ldr temb_sel_stride temb_b_stride epilogue splitk ws_bytes reserved1"))
 MdxConvDirectDesc = _struct("MdxConvDirectDesc", _f(P, "X Wt Y R bias temb sel_ptr reserved_p") + _f(I, "B Hi Wi Cin Ho Wo Cout kh kw sh sw ph pw "

@@ -558,6 +558,10 @@ extern "C" int mdx_gemm_bf16(const MdxGemmDesc* d, void* stream) {
     } else if (d->ln_stats) {
         return set_error(MDX_EINVAL, "mdx_gemm_bf16: ln_stats without ln_eps");
     }
+    if (d->Wq) {
+        if ((uintptr_t)d->Wq & 15) return set_error(MDX_EINVAL, "mdx_gemm_bf16: Wq must be 16-byte aligned");
+        p.Wq = (const bf16_t*)d->Wq;
+    }
     if (d->rowstat_out) {
         if (d->rowstat_parts < 1 || ((uintptr_t)d->rowstat_out & 7) || d->Vt || d->epilogue || d->c_is_f32 || p.batch > 1)
             return set_error(MDX_EINVAL, "mdx_gemm_bf16: rowstat_out needs rowstat_parts >= 1, 8-byte alignment, a plain epilogue, 16-bit C, one batch, no Vt");

@@ -43,6 +43,8 @@ struct GCParams {
     // ln_stats [ln_stats_parts][M][2]: the same sums of the A rows, from which the fused LayerNorm takes mean / rstd instead of recomputing them.
     float* rowstat; int rowstat_parts;
     const float* ln_stats; int ln_stats_parts;
+    // W in MFMA-fragment order for the W-direct kernel (MdxGemmDesc.Wq, ABI 10; layout in gemm_xd.hip / include/mdx.h); null: not given
+    const bf16_t* Wq;
     int dbg;                      // debug knobs of gemm_pp.hip (MDX_PP_DBG): 1 skip LDS stores, 2 skip global loads, 4 skip MFMAs
 };
 

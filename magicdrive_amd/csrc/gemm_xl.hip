@@ -1334,6 +1334,9 @@ constexpr size_t xl_smem_bytes() {
     return ring > epi ? ring : epi;
 }
 
+bool xd_supported(const GCParams& q);                                          // gemm_xd.hip
+int launch_gemm_xd(const GCParams& q, int cus, hipStream_t st);
+
 template <int BN, bool CONV, int SCHED>
 static int launch_xl(const GCParams& p, hipStream_t st) {
     constexpr size_t smem_kxs = (size_t)2 * 272 * 128 + (size_t)2 * Geo<BN>::BNP * 128;      // SCHED 4: two 272-row A buffers + two weight slabs
@@ -1372,6 +1375,8 @@ static int launch_xl(const GCParams& p, hipStream_t st) {
             (long)q.M * q.lda * 2 > 0 && q.bias != (const float*)q.C) {
             const bool geglu = q.epi == 1, has_r = q.R != nullptr;
             if (geglu && has_r) goto not_persistent;
+            // W-direct form (gemm_xd.hip): the caller supplied the weights in fragment order and K is a whole number of unit pairs
+            if (opt(OPT_XD) && xd_supported(q)) return launch_gemm_xd(q, cus, st);
             {
                 auto launch_p = [&](auto kp) -> int {
                     if (int rc = ensure_dyn_smem((const void*)kp, smem, "xlp")) return rc;

@@ -53,6 +53,7 @@ namespace mdx {
     X(GN_FINALIZE_CHUNKS, 16, "two-stage GroupNorm: with more chunks per image than this the chunk partials are combined once by gn_finalize_kernel (0 = always in the apply pass)") \
     X(GN_TWO_STAGE, 1, "streaming two-stage GroupNorm for maps >= 32768 elements") \
     X(XL_PERSIST, 1, "256x256 XL GEMMs (plain / GEGLU, optional residual) on the persistent kernel gemm_xlp_kernel") \
+    X(XD, 0, "W-direct persistent GEMM (gemm_xd.hip: weights global -> registers, finished tile stored under the next tile's main loop) for the 256x256 XL GEMMs whose descriptor carries Wq (K % 128 == 0, K >= 640); bit-identical to gemm_xlp_kernel, measured 0.89-1.04x of it (profiles/r06_xd_ab.log): off by default") \
     X(XL_RASTER, 2, "XL tile order: 0 row-major, 1 XCD-strided M-tiles, 2 XCD-blocked (M-group x N-group panels per XCD)") \
     X(XL_KXSHARE, 1, "only in -DMDX_XL_KXS side builds: 320-wide XL 3x3 / stride 1 convs share one A slab in LDS between the three horizontal taps of a (channel block, ky) (schedule 4; measured slower, gemm_xl.hip: launch_gemm_xl)") \
     X(XL_GM, 0, "XL_RASTER 2: force the M-tiles per panel (0 = cost model, xl_layout.h: raster_shape)") \

@@ -315,8 +315,26 @@ class Builder:
         self.emit(O.LayerNorm(x, y, net.vec(pre + "weight"), net.vec(pre + "bias"), 1e-5, name=name))
         return y
 
+    @staticmethod
+    def wq_of(W: torch.Tensor, M: int, epilogue: int) -> Optional[torch.Tensor]:
+        """The fragment-ordered copy of a linear weight (packing.pack_wq) for the W-direct persistent GEMM (csrc/gemm_xd.hip), made once per
+        weight tensor and kept on it; None when the route is switched off (option XD, the default: measured on par with the LDS-both persistent kernel), for shapes that kernel does not take (K % 128, K < 640) or launches too small for the persistent tile
+        walk (fewer than two 256 x 256 tiles per CU: the library would not route them there)."""
+        if W.dim() != 2 or not W.is_contiguous() or epilogue not in (L.EPI_NONE, L.EPI_GEGLU) or not L.get_option("XD"):
+            return None
+        N, K = W.shape
+        if K % 128 or K < 640 or N % 16 or ((M + 255) // 256) * ((N + 255) // 256) < 512:
+            return None
+        wq = getattr(W, "_mdx_wq", None)
+        if wq is None:
+            wq = PK.pack_wq(W)
+            W._mdx_wq = wq
+        return wq
+
     def gemm(self, A, W, N_out, bias=None, R=None, epilogue=L.EPI_NONE, name="", out=None, **kw) -> torch.Tensor:
         C = out if out is not None else self.pool.get((A.shape[0], N_out))
+        if "Wq" not in kw and not any(kw.get(k) is not None for k in ("Vt", "temb", "rowstat")) and not kw.get("ln_eps"):
+            kw["Wq"] = self.wq_of(W, A.shape[0], epilogue)
         self.emit(O.Gemm(A, W, C, bias=bias, R=R, epilogue=epilogue, ws=self.ws, name=name, **kw))
         return C
 

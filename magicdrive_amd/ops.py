@@ -77,6 +77,8 @@ class Gemm:
     # written by the producer of a LayerNorm's input and read by the GEMM that carries that LayerNorm (ln_eps > 0)
     rowstat: Optional[torch.Tensor] = None
     ln_stats: Optional[torch.Tensor] = None
+    # W once more in MFMA-fragment order (packing.pack_wq; include/mdx.h: MdxGemmDesc.Wq): the W-direct persistent kernel reads this copy
+    Wq: Optional[torch.Tensor] = None
     opcode = L.OP_GEMM
 
     def lower(self):
@@ -151,6 +153,10 @@ class Gemm:
                  f"gemm {self.name}: rowstat must be fp32 [parts, M, 2]")
             _chk(batch == 1 and self.epilogue == L.EPI_NONE and self.Vt is None and Cm.dtype in H16, f"gemm {self.name}: rowstat needs a plain 2-D GEMM with 16-bit C")
             d.rowstat_out, d.rowstat_parts = _p(rs), rs.shape[0]
+        if self.Wq is not None:
+            _chk(batch == 1 and self.Wq.dtype == W.dtype and self.Wq.is_contiguous() and self.Wq.numel() == (N + 255) // 256 * 256 * K and K % 32 == 0,
+                 f"gemm {self.name}: Wq must be packing.pack_wq(W)")
+            d.Wq = _p(self.Wq)
         return self.opcode, d
 
 

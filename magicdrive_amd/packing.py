@@ -36,6 +36,17 @@ def pack_geglu(w: torch.Tensor, b: torch.Tensor, dtype=torch.bfloat16):
     return wp.contiguous().to(dtype), bp.contiguous().to(torch.float32)
 
 
+def pack_wq(w: torch.Tensor) -> torch.Tensor:
+    """Row-major linear weight [N, K] (16-bit, K % 32 == 0) -> MFMA-fragment order for the W-direct GEMM (include/mdx.h: MdxGemmDesc.Wq,
+    csrc/gemm_xd.hip):  Wq[n // 16][k // 32][((k % 32) // 8) * 16 + n % 16][k % 8], N padded with zero rows to a multiple of 256.
+    A pure permutation: one contiguous KiB per 16-column x 32-deep block."""
+    n, k = w.shape
+    assert k % 32 == 0, f"pack_wq: K={k} must be a multiple of 32"
+    npad = round_up(n, 256)
+    wp = w if npad == n else torch.cat([w, torch.zeros(npad - n, k, dtype=w.dtype, device=w.device)], 0)
+    return wp.reshape(npad // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(npad, k)
+
+
 def nearest_index(n_in: int, n_out: int) -> torch.Tensor:
     """Source index of F.interpolate(mode='nearest', size=n_out): min(floor(dst * (in/out)), in-1) in fp32."""
     scale = np.float32(n_in) / np.float32(n_out)

@@ -329,6 +329,79 @@ def test_persistent_xl_gemm_bench_shapes(dev, M, N, K, res):
     assert torch.equal(outs[1], outs[0]), "persistent and per-tile kernels must agree bit for bit"
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# gemm_xd.hip — the W-direct persistent GEMM (option XD, off by default; MdxGemmDesc.Wq)
+@pytest.mark.parametrize("M,N,K,epi,res,bias,ldx", [
+    (130000, 1280, 640, 0, False, True, 0),          # qk at level 1 (ten units per tile: every unit of a tile drains the previous one)
+    (201600 - 37, 640, 640, 0, True, True, 64),      # to_out + residual: ragged M, 2.5 N-tiles (column tail dropped by the descriptor), C a column slice of a wider buffer
+    (70000, 5120, 640, 1, False, True, 0),           # GEGLU at level 1
+    (52416, 1280, 1280, 0, True, False, 0),          # level 2 + residual, no bias (zero-record bias descriptor)
+    (130000, 1296, 768, 0, False, True, 0),          # twelve units: one generic pair behind the ten drain units, 16-column tail tile
+    (52416, 1280, 5120, 0, True, True, 0),           # ff.out at level 2: 80 units
+])
+def test_xd_gemm_matches_persistent_xl_bit_for_bit(dev, M, N, K, epi, res, bias, ldx):
+    """Same descriptor with XD = 1 (gemm_xd_kernel) and XD = 0 (gemm_xlp_kernel): identical arithmetic per element, so the outputs must be
+    EQUAL (incl. the untouched columns of a wider C buffer), and both are within the bf16 tolerance of the fp32 reference.  The XD launch is
+    repeated: its register loads are hand-counted asynchronous operations, and the one bug this kernel had (register copies of in-flight
+    loads at the tile loop's back-edge, see tests/test_xd_isa.py) showed in one launch out of ten."""
+    A = rnd(M, K, scale=0.5, seed=1); W = rnd(N, K, scale=0.05, seed=2)
+    bv = torch.randn(N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    if epi == 1:
+        W, bv = PK.pack_geglu(W.float(), bv, BF)
+    No = N // 2 if epi == 1 else N
+    Cbuf = torch.zeros(M, No + ldx, dtype=BF, device="cuda")
+    R = rnd(M, No, seed=4) if res else None
+    Wq = PK.pack_wq(W)
+    op = O.Gemm(A, W, Cbuf[:, :No], bias=bv if bias else None, R=R, epilogue=epi, ws=ws_buf(), Wq=Wq)
+    outs = {}
+    for xd in (0, 1):
+        with L.options(XD=xd):
+            Cbuf.fill_(7.0)
+            k = run_one(op)
+            assert k.startswith("gemm_xd_kernel" if xd else "gemm_xlp_kernel"), k
+            outs[xd] = Cbuf.clone()
+    assert torch.equal(outs[1], outs[0]), f"{(outs[1] != outs[0]).sum().item()} elements differ"
+    with L.options(XD=1):
+        for it in range(12):
+            Cbuf.fill_(7.0)
+            run_one(op)
+            assert torch.equal(Cbuf, outs[0]), f"launch {it}: {(Cbuf != outs[0]).sum().item()} elements differ"
+    idx = torch.randint(0, M, (1024,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    idx[:8] = torch.arange(M - 8, M, device="cuda")
+    ref = A[idx].float() @ W.float().t()
+    if bias:
+        ref = ref + bv[None, :]
+    if epi == 1:
+        r4 = ref.reshape(-1, N // 64, 2, 32)
+        ref = (r4[:, :, 0] * F.gelu(r4[:, :, 1])).reshape(-1, No)
+    ref = ref.to(BF).float()
+    if res:
+        ref = ref + R[idx].float()
+    close(outs[1][idx, :No], ref, name=f"xd_gemm_{M}x{N}x{K}")
+    if ldx:
+        assert bool((outs[1][:, No:] == 7.0).all())
+
+
+def test_xd_fp16_build(dev):
+    """The fp16 build of the W-direct kernel (v_mfma_f32_16x16x32_f16) against its own LDS-both persistent kernel."""
+    H = torch.float16
+    M, N, K = 70000, 1280, 640
+    A = rnd(M, K, scale=0.5, seed=1, dtype=H); W = rnd(N, K, scale=0.05, seed=2, dtype=H)
+    R = rnd(M, N, seed=4, dtype=H)
+    C = torch.zeros(M, N, dtype=H, device="cuda")
+    op = O.Gemm(A, W, C, R=R, ws=ws_buf(), Wq=PK.pack_wq(W))
+    outs = {}
+    for xd in (0, 1):
+        with L.options(XD=xd):
+            C.zero_()
+            O.run_ops([op])
+            k = (L.lib().mdx_last_kernel() or b"").decode()
+            torch.cuda.synchronize()
+            assert k.startswith("gemm_xd_kernel" if xd else "gemm_xlp_kernel"), k
+            outs[xd] = C.clone()
+    assert torch.equal(outs[1], outs[0])
+
+
 def test_set_option_rejects_unknown_key():
     with pytest.raises(L.MdxError):
         L.set_option("NO_SUCH_SWITCH", 1)
