@@ -46,7 +46,7 @@ namespace mdx {
 using namespace mdx_xl;
 
 #ifndef XD_ABL
-#define XD_ABL 0     // timing-only ablations (wrong results): 1 no stores, 2 no conversion, 4 no barrier, 8 no weight loads, 16 no activation DMA, 32 no residual loads, 64 no A fragment reads
+#define XD_ABL 0     // timing-only ablations (wrong results): 1 no stores, 2 no conversion, 4 no barrier, 8 no weight loads, 16 no activation DMA, 32 no residual loads, 128 every store into ONE 1-KiB window (no write traffic past the L2)
 #endif
 #if MDX_F16
 #define XD_MFMA_NAME "v_mfma_f32_16x16x32_f16"
@@ -256,8 +256,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (!(XD_ABL & 4)) __builtin_amdgcn_s_barrier();
         }
         asm volatile("" ::: "memory");
-        if (XD_ABL & 64) {}
-        else if constexpr (q < 7) read_af((q + 1) & 1, stg, ((q + 1) >> 2) ? a_rd1 : a_rd0, (q + 1) & 3);
+        if constexpr (q < 7) read_af((q + 1) & 1, stg, ((q + 1) >> 2) ? a_rd1 : a_rd0, (q + 1) & 3);
         else read_af(0, stage_of(1), a_rd0, 0);
         xd_u4_t sv = xd_u4_t{0u, 0u, 0u, 0u};
         if constexpr (ST) sv = take(std::integral_constant<int, ST ? cst : 0>{});
@@ -276,7 +275,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if constexpr (BL) xd_gload_imm<(BL ? q - 4 : 0) * 64>(bq[BL ? q - 4 : 0], rsB, b_voff);
                 if constexpr (ST) {
                     if constexpr (HAS_R) sv = add_r(sv, rr[q >> 1]);
-                    if (!(XD_ABL & 1)) xd_gstore(sv, rsC, seg_voff(cst, false), 0);
+                    if (!(XD_ABL & 1)) xd_gstore(sv, rsC, (XD_ABL & 128) ? (unsigned)(lane * 16) : seg_voff(cst, false), 0);
                 }
             }
         }
@@ -386,7 +385,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // and its residual loads return zeros (they still count, so the wait arithmetic is the same for every tile).  No control-flow join sits
     // between an asynchronous load and the wait that covers it except the two loop back-edges, see below.
 #ifdef XD_TIMING
-    unsigned long long tm_loop = 0, tm_conv = 0, tm_tiles = 0;
+    unsigned long long tm_loop = 0, tm_conv = 0, tm_tiles = 0, tm_u04 = 0, tm_u58 = 0;
     const unsigned long long tm_begin = __builtin_amdgcn_s_memtime();
 #endif
     for (;;) {
@@ -403,10 +402,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         unit(I0{}, std::integral_constant<int, 2>{}, BT{}, 2);
         unit(I1{}, std::integral_constant<int, 3>{}, BT{}, 3);
         unit(I0{}, std::integral_constant<int, 4>{}, BT{}, 4);
+#ifdef XD_TIMING
+        const unsigned long long tm_m1 = __builtin_amdgcn_s_memtime();
+#endif
         unit(I1{}, std::integral_constant<int, 5>{}, BT{}, 5);
         unit(I0{}, std::integral_constant<int, 6>{}, BT{}, 6);
         unit(I1{}, std::integral_constant<int, 7>{}, BT{}, 7);
         unit(I0{}, std::integral_constant<int, 8>{}, BT{}, 8);
+#ifdef XD_TIMING
+        const unsigned long long tm_m2 = __builtin_amdgcn_s_memtime();
+        tm_u04 += tm_m1 - tm_a; tm_u58 += tm_m2 - tm_m1;
+#endif
         unit(I1{}, std::integral_constant<int, 9>{}, BT{}, 9);
         for (int t = 10; t < T; t += 2) {
             unit(I0{}, std::integral_constant<int, GEN>{}, BF_{}, t);
@@ -439,8 +445,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 #ifdef XD_TIMING
     if (p.timing && tid == 0) {                                   // cycles (s_memtime) per workgroup: main loops, conversions, tiles, all
-        p.timing[blockIdx.x * 4 + 0] = tm_loop; p.timing[blockIdx.x * 4 + 1] = tm_conv; p.timing[blockIdx.x * 4 + 2] = tm_tiles;
-        p.timing[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime() - tm_begin;
+        p.timing[blockIdx.x * 8 + 0] = tm_loop; p.timing[blockIdx.x * 8 + 1] = tm_conv; p.timing[blockIdx.x * 8 + 2] = tm_tiles;
+        p.timing[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memtime() - tm_begin;
+        p.timing[blockIdx.x * 8 + 4] = tm_u04; p.timing[blockIdx.x * 8 + 5] = tm_u58;
     }
 #endif
     // ---- the last tile's segments: nothing left to hide them under ----
@@ -484,7 +491,7 @@ bool xd_supported(const GCParams& q) {
 int launch_gemm_xd(const GCParams& q0, int cus, hipStream_t st) {
     GCParams q = q0;
 #ifdef XD_TIMING
-    q.timing = (q0.ws && q0.ws_bytes >= (long)cus * 32) ? (unsigned long long*)q0.ws : nullptr;
+    q.timing = (q0.ws && q0.ws_bytes >= (long)cus * 64) ? (unsigned long long*)q0.ws : nullptr;
 #endif
     const bool geglu = q.epi == 1, has_r = q.R != nullptr;
     constexpr size_t ring = 3 * 256 * 128;

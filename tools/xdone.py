@@ -93,10 +93,10 @@ def main():
             with L.options(XD=1):
                 L.call_op(code, desc, st, dtype=L.DTYPE_F16 if a.f16 else L.DTYPE_BF16)
             torch.cuda.synchronize()
-            tt = ws.view(torch.int64)[:256 * 4].reshape(256, 4).double()
+            tt = ws.view(torch.int64)[:256 * 8].reshape(256, 8).double()
             tiles = tt[:, 2].clamp_min(1)
             print(f"   timing (s_memtime ticks, mean over workgroups): per tile main loop {(tt[:, 0] / tiles).mean():.0f}, conversion {(tt[:, 1] / tiles).mean():.0f}; "
-                  f"tiles per workgroup {tt[:, 2].mean():.1f}; whole kernel {tt[:, 3].mean():.0f} (max {tt[:, 3].max():.0f}); units per tile {K // 64}")
+                  f"units 0-4 (incl. the tile's set-up) {(tt[:, 4] / tiles).mean():.0f}, units 5-8 {(tt[:, 5] / tiles).mean():.0f}; tiles per workgroup {tt[:, 2].mean():.1f}; whole kernel {tt[:, 3].mean():.0f} (max {tt[:, 3].max():.0f}); units per tile {K // 64}")
         if a.stress:
             op = O.Gemm(A, W, C, bias=bv if bias else None, R=R, epilogue=epi, ws=ws, Wq=Wq)
             code, desc = op.lower()
