@@ -25,6 +25,20 @@
 //          behind it the next unit's stage is complete for every wave and the stage two ahead is free.
 // XdSched computes the three counts from the table of optional operations per (unit of the tile, quarter).
 //
+// Rules this file follows about the registers its asm loads fill (weight fragments, residual segments, bias) — to hipcc they are ordinary values,
+// defined at the asm statement; the data arrives later (tests/test_xd_isa.py checks the compiled ISA, DESIGN.md section 6 has the story):
+//   * no control-flow join between an asm load and the wait that covers it, except the two loop back-edges: ONE straight-line tile body (the first
+//     tile drains a zero-record pending tile), and before the tile loop's back-edge everything is waited for and every such value re-defined
+//     behind the wait — a phi there is resolved by v_mov copies, and a copy of a register whose load is in flight copies stale bits;
+//   * asm-loaded registers are consumed through an in-place re-definition behind their wait, never through a by-value copy;
+//   * the accumulators are pinned to their AGPRs until the row block that converts them (otherwise the allocator copies all 256 to VGPRs behind the
+//     last MFMA, spills long-lived offsets, and their scratch reloads wait vmcnt(0) inside the counted pipeline);
+//   * wave-uniform per-unit offsets are made opaque where they are used, so that they are not hoisted out of the tile loop into ~100 SGPRs.
+// Measured (profiles/r06_xd_ab.log): bit-identical to gemm_xlp_kernel, 0.89-1.04x its speed — the stores are issued for free between the MFMAs, but
+// their write traffic slows the loop's loads by what the separate epilogue used to cost.  Option XD, off by default.
+// Side builds: -DXD_TIMING (per-workgroup s_memtime sums into the op workspace: tools/xdone.py --timing), -DXD_ABL=bits (timing-only ablations),
+// -DXD_STQ=1 (store quarters {0,3,4,7}), -DXD_STPOL=1/2/3 (nt / sc1 / sc0 sc1 stores).
+//
 // Packed weights: Wq[n / 16][k / 32][lane][8] with lane = ((k % 32) / 8) * 16 + n % 16 — the 64 lanes' A operands of one 16 x 32 MFMA block are one
 // contiguous KiB; columns padded with zero blocks to a multiple of 256 (packing.pack_wq).  GEGLU: rows in the [32 value | 32 gate] order of
 // packing.pack_geglu, so tiles j = 0, 1 of a wave are values and j = 2, 3 their gates.

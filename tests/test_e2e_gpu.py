@@ -542,6 +542,19 @@ def test_guard_sweep_sampler_plans(dev):
     _guard_sweep(["--cases", "text,cfg,unipc_gv", "--sizes", "5,24,31,33,96", "--full", "3,12", "--steps", "2"], 1100)
 
 
+def test_xd_route_inside_the_sampler(dev):
+    """Option XD = 1 end to end (it is off by default): the engine packs the fragment-ordered weight copies (engine.Builder.wq_of) and the level-1 / 2 projections of plans with
+    >= 512 tiles run on gemm_xd_kernel.  Same check as the sweep above — a scene of a 20- / 33-scene call (text-only) and of a 12-scene CFG call must reproduce its 1-scene call, whose
+    GEMMs are far too small for that route — in a child process with MDX_XD=1 pre-setting the option table, every plan buffer closing a device segment of its own."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MDX_XD="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "batch_sweep.py"), "--sizes", "20,33", "--full", "12", "--steps", "2", "--guard", "--expect-wq"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    print(r.stdout[-2000:])
+    assert r.returncode == 0 and '"wq_copies"' in r.stdout, (r.returncode, r.stdout[-1200:], r.stderr[-2500:])
+
+
 def test_guard_sweep_hires_fp16_vae(dev):
     """The same net under the plans the sweep above does not build: configs[3] (432x768, ...Plus map encoder, CFG) at 2 scenes, the fp16 build of
     every kernel (7 scenes: ragged tiles), and the VAE decode / encode plans."""
