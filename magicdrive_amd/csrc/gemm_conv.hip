@@ -435,8 +435,30 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
         BN = 128;
         if (!geglu && (p.N <= 64 || (p.N % 128 != 0 && p.N <= 192))) BN = 64;
         BM = p.M >= 2048 ? 128 : 64;
+        // Small grids (round 6; the reference's own operating point is 1-4 scenes per call, where every launch of the step program lands here): with fewer
+        // workgroups than the chip has room for, the SMALLER tile is the faster one — four 64 x 64 workgroups share a CU (37 KB of LDS each) where two
+        // 128 x 128 ones fit, and a 4-wave workgroup alone on its CU has nothing to run beside its load phase.  Measured over every GEMM / conv shape
+        // of the 1-, 2- and 4-scene step programs under forced tiles (tools/tile_sweep.py, profiles/r06_tile_sweep.log): plain GEMMs are fastest on
+        // 64 x 64 up to ~1400 such tiles (9.5 vs 14.7 us at M 2100, N = K = 640; 18.7 vs 28.4 us at M 2184, N = K = 1280); implicit-GEMM convs up to
+        // ~40 k (tile, slab) units of work, beyond that on 128 x 128 — never on the 64 x 128 tile rounds 1-5 gave every M < 2048; GEGLU (needs 128
+        // columns) on 128 rows from M = 512.  Same k order in every tile: results do not depend on the choice (split-K aside).
+        if (opt(OPT_GEMM_SMALL_TILES) && p.batch <= 1) {
+            const long t64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+            if (geglu) {
+                BM = p.M >= 512 ? 128 : 64;
+            } else if (!conv) {
+                if (t64 <= 1408) BM = BN = 64;
+            } else if (t64 * (long)((p.K + 63) / 64) <= 40000) {
+                BM = BN = 64;
+            } else if (BN == 128) {
+                BM = 128;
+            }
+        }
         const int big = (int)opt(OPT_GEMM_BM256);
         if (big && BN == 128 && p.M >= big) BM = 256;
+        const int fbm = (int)opt(OPT_GEMM_BM), fbn = (int)opt(OPT_GEMM_BN);
+        if (fbm == 64 || fbm == 128) BM = fbm;
+        if ((fbn == 64 && !geglu) || fbn == 128) BN = fbn;
     }
     long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * (p.batch > 1 ? p.batch : 1);
     int splitk = 1;

@@ -30,6 +30,9 @@ namespace mdx {
     X(CONV_OUT_WS, 1, "direct conv with Cout <= 4 and a long K (conv_out): weight-stationary K-parallel kernel (weights in registers, 16 pixels per wave)") \
     X(GEMM_SWZ, 1, "XCD-aware tile order of the generic / conv3x3 kernels") \
     X(C3_DBG, 0, "conv3x3 ablation bits (wrong results)") \
+    X(GEMM_SMALL_TILES, 1, "generic tile choice for small grids (1-4 scenes per call): 64 x 64 for plain GEMMs up to 1408 such tiles and for convs up to 40 k (tile, slab) units, 128 x 128 for larger convs with M < 2048, 128-row GEGLU from M = 512; 0 = the rounds 1-5 rule (128 rows from M = 2048, else 64 x 128)") \
+    X(GEMM_BM, 0, "force the generic tile's rows (64 / 128; 0 = heuristic)") \
+    X(GEMM_BN, 0, "force the generic tile's columns (64 / 128; 0 = heuristic)") \
     X(GEMM_PIPE, 1, "software-pipelined fragment reads in the generic 128x128x64 tile") \
     X(EPI_WIDE, 1, "16-byte epilogue accesses when alignment allows") \
     X(GEMM_WS, 1, "gemm_ws.hip: 0 off, 1 when M >= 8192, 2 whenever supported") \

@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from magicdrive_amd import synthetic  # noqa: E402
 from magicdrive_amd.networks import spec  # noqa: E402
-ap = argparse.ArgumentParser(); ap.add_argument("--scenes", type=int, default=1); ap.add_argument("--steps", type=int, default=50); ap.add_argument("--fork-max", type=int, default=-1, help="pipe.fork_max_scenes (0 = never fork; default: the pipeline's)"); ap.add_argument("--no-ops", action="store_true")
+ap = argparse.ArgumentParser(); ap.add_argument("--scenes", type=int, default=1); ap.add_argument("--steps", type=int, default=50); ap.add_argument("--fork-max", type=int, default=-1, help="pipe.fork_max_scenes (0 = never fork; default: the pipeline's)"); ap.add_argument("--no-ops", action="store_true"); ap.add_argument("--rows-json", default="", help="write every launch of the step program (name, kernel, median / best ms, GFLOP) to this file")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = spec.SD15_CONFIG
@@ -29,6 +29,10 @@ if a.no_ops:
 plan = next(iter(pipe._plans.values()))
 fam, kern, rows = bench.per_op_profile(plan, reps=3)
 tot = sum(v["ms"] for v in kern.values())
+if a.rows_json:
+    import json
+    with open(a.rows_json, "w") as f:
+        json.dump(rows, f)
 print(f"step program op by op: {tot:.2f} ms, {len(rows)} launches")
 for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:16]:
     print(f"  {k:52s} {v['ms']:7.3f} ms {v['launches']:4d} launches {1e3 * v['ms'] / v['launches']:7.1f} us avg")
