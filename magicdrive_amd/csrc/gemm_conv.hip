@@ -27,8 +27,6 @@
 namespace mdx {
 
 
-int launch_conv3x3(const GCParams& p, hipStream_t st);                          // conv3x3.hip: 3x3/s1/p1 conv, A slab shared by 3 taps
-bool conv3x3_supported(const GCParams& p);
 int launch_gemm_ws(const GCParams& p, hipStream_t st);                          // gemm_ws.hip: weight-stationary K = 320 GEMM
 bool ws_supported(const GCParams& p);
 bool ws_fuses_layernorm(const GCParams& p);
@@ -199,7 +197,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 1) void gemm_con
         if constexpr (PIPE && TM == 2 && TN == 2) {
             // Fragment reads run one k-step ahead of the MFMAs (second register set), pinned between them with
             // sched_group_barrier: left alone every ds_read sits right before its first use and each k-step exposes an LDS
-            // round trip (conv3x3.hip measured +7 % from this alone).
+            // round trip (round 2 measured +7 % from this alone).
             Frag8 af[2][TM], bfr[2][TN];
 #define GC_READ(set, ks_)                                                                                             \
             {                                                                                                         \
@@ -340,10 +338,11 @@ static int launch_one(const GCParams& p, hipStream_t st) {
 //   gemm_ws.hip   K = 320 projections / GEGLU with M >= 8192 (level 0 of the UNet): weights in registers, activations streamed
 //   gemm_xl.hip   every conv with Cin % 64 == 0 and every GEMM with K % 64 == 0 that yields >= xl_min_tiles 256-row tiles
 //                 (>= ~8 scenes per GPU at level 0, >= ~32 at the 7x13 level): 256 x {160, 256, 320} LDS-DMA tiles
-//   conv3x3.hip   3x3 / s1 / p1 convs with M >= 4096 that XL declined (1-7 scenes per GPU: too few 256-row tiles to fill 256 CUs)
-//   this file     everything else: 128 / 64-row register-staged tiles, split-K for the 7x13 / 4x7 levels at small batches
+//   this file     everything else: 128 / 64-row register-staged tiles (64 x 64 for small grids), split-K for the 7x13 / 4x7 levels at small batches
 // (round 3 removed gemm_dma.hip — an LDS-DMA ring that never beat register staging — and gemm_pp.hip, whose 256 x 256 ping-pong tile
-// was superseded by gemm_xl.hip at every batch where it used to be chosen.)
+// was superseded by gemm_xl.hip at every batch where it used to be chosen; round 6 removed conv3x3.hip — one A slab shared by the three
+// horizontal taps on a 128 x 128 tile — which by then only 1- and 2-scene calls reached and which ran 8-12 % behind the generic tile
+// there: 56 vs 50 us for the level-0 320 -> 320 conv at one scene, profiles/r06_lat1_small_grids.log.)
 int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MDX_OK;
     const bool geglu = p.epi == 1;
@@ -489,11 +488,6 @@ int launch_gemm_conv(GCParams p, bool conv, hipStream_t st) {
         if (try_xl(bn_xl)) return launch_gemm_xl(p, conv, bn_xl, st);
     }
     if (impl == 0 && ws_first) return launch_gemm_ws(p, st);       // MDX_XL_K320 was set but the XL kernel declined the shape
-    // 3x3 / stride 1 / pad 1 convs with enough rows for 128-row tiles: conv3x3.hip.  MDX_CONV3: 0 off, 1 when M >= 4096 (default).
-    const int c3_mode = (int)opt(OPT_CONV3);
-    if (impl == 0 && conv && c3_mode > 0 && splitk == 1 && conv3x3_supported(p) && p.M >= 4096 && (p.N % 4) == 0) {
-        return launch_conv3x3(p, st);                                              // (small grids were given split-K above)
-    }
     int rc;
     {
         const int bk = (int)opt(OPT_GEMM_BK);

@@ -437,7 +437,11 @@ extern "C" int mdx_groupnorm_bf16(const MdxGroupNormDesc* d, void* stream) {
     const int two_stage = (int)opt(OPT_GN_TWO_STAGE);
     const long elems = (long)p.HW * p.C;
     const int nt_ws = (p.C % 8 == 0) ? ((p.C / 8) > GN2_NT ? GN2_NT : gn2_rows(p.C / 8) * (p.C / 8)) : 0;
-    if (two_stage && d->ws && elems >= 32768 && p.C % 8 == 0 && p.C <= GN2_MAXC && p.G <= nt_ws && p.ldx % 8 == 0 && p.ldy % 8 == 0 &&
+    // Small tensors (round 6: 1-4 scenes per call) stay on the one-workgroup-per-(image, group) kernel below: ONE launch of ~8-20 us instead of two of
+    // ~10 us each, whatever the size; from ~4 M elements on the two streaming passes win (tools/lat1.py rows with GN_TWO_STAGE = 0 / 1 at 1, 2 and 4
+    // scenes, profiles/r06_lat1_small_grids.log: 6 x 350 x 640: 12.5 vs 18.8 us; 12 x 1400 x 320: 29.4 vs 24.1 us).
+    const bool small = (long)p.B * elems <= opt(OPT_GN_ONE_KERNEL_ELEMS);
+    if (two_stage && !small && d->ws && elems >= 32768 && p.C % 8 == 0 && p.C <= GN2_MAXC && p.G <= nt_ws && p.ldx % 8 == 0 && p.ldy % 8 == 0 &&
         ((uintptr_t)p.X & 15) == 0 && ((uintptr_t)p.Y & 15) == 0) {
         GN2Params q;
         q.X = p.X; q.Y = p.Y; q.gamma = p.gamma; q.beta = p.beta; q.part = (float*)d->ws;

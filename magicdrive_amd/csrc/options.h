@@ -28,8 +28,7 @@ namespace mdx {
     X(ATTN2_VIEWMAP, 1, "attention2.hip block order: 1 = all heads and query blocks of a view on one XCD (a row's 128-byte lines are shared by the heads), 0 = per (view, head)") \
     X(ATTN2_QT, 0, "32-query tiles per wave in attention2.hip: 0 = automatic (2; 1 for one-source FOLD launches), 1 / 2 = force") \
     X(CONV_OUT_WS, 1, "direct conv with Cout <= 4 and a long K (conv_out): weight-stationary K-parallel kernel (weights in registers, 16 pixels per wave)") \
-    X(GEMM_SWZ, 1, "XCD-aware tile order of the generic / conv3x3 kernels") \
-    X(C3_DBG, 0, "conv3x3 ablation bits (wrong results)") \
+    X(GEMM_SWZ, 1, "XCD-aware tile order of the generic kernel") \
     X(GEMM_SMALL_TILES, 1, "generic tile choice for small grids (1-4 scenes per call): 64 x 64 for plain GEMMs up to 1408 such tiles and for convs up to 40 k (tile, slab) units, 128 x 128 for larger convs with M < 2048, 128-row GEGLU from M = 512; 0 = the rounds 1-5 rule (128 rows from M = 2048, else 64 x 128)") \
     X(GEMM_BM, 0, "force the generic tile's rows (64 / 128; 0 = heuristic)") \
     X(GEMM_BN, 0, "force the generic tile's columns (64 / 128; 0 = heuristic)") \
@@ -43,7 +42,6 @@ namespace mdx {
     X(XL_GEGLU320, 0, "K = 320 GEGLU on the 256-wide XL tile instead of gemm_ws.hip") \
     X(GEMM_BM256, 0, "generic 256x128 8-wave tile from M >= value (0 = never)") \
     X(GEMM_TIMING, 0, "s_memtime stamps of the generic kernel into the op workspace") \
-    X(CONV3, 1, "conv3x3.hip for 3x3/s1/p1 convs with M >= 4096 that XL declined") \
     X(GEMM_BK, 64, "generic tile slab depth (64 or 32)") \
     X(GEMM_FLATTEN, 1, "batched shared-A GEMM as ONE col_split XL launch") \
     X(CONV_CIMAJOR, 1, "channel-block-major K order of implicit-GEMM convs") \
@@ -54,6 +52,7 @@ namespace mdx {
     X(XL_SCHED, 0, "XL main-loop schedule variant 0..3 (0 = four quadrant phases)") \
     X(GN_REVERSE, 1, "two-stage GroupNorm: statistics pass reads the tensor back to front (Infinity-Cache reuse between producer / passes)") \
     X(GN_FINALIZE_CHUNKS, 16, "two-stage GroupNorm: with more chunks per image than this the chunk partials are combined once by gn_finalize_kernel (0 = always in the apply pass)") \
+    X(GN_ONE_KERNEL_ELEMS, (4L << 20), "GroupNorm tensors of at most this many elements (all images) take the one-launch kernel (one workgroup per (image, group)) instead of the two streaming passes") \
     X(GN_TWO_STAGE, 1, "streaming two-stage GroupNorm for maps >= 32768 elements") \
     X(XL_PERSIST, 1, "256x256 XL GEMMs (plain / GEGLU, optional residual) on the persistent kernel gemm_xlp_kernel") \
     X(XD, 0, "W-direct persistent GEMM (gemm_xd.hip: weights global -> registers, finished tile stored under the next tile's main loop) for the 256x256 XL GEMMs whose descriptor carries Wq (K % 128 == 0, K >= 640); bit-identical to gemm_xlp_kernel, measured 0.89-1.04x of it (profiles/r06_xd_ab.log): off by default") \

@@ -59,7 +59,7 @@ def test_fp16_gemm_conv_norm_kernels(dev):
         assert TR.geglu_case(26400, 1280, 320) == "gemm_ws_kernel<geglu>"
         TR.test_flattened_batched_vt(dev, 60, 350, 640)
         with L.options(GEMM_XL=0):
-            TR.conv_case(16, 28, 50, 320, 320, expect="conv3x3_kernel")
+            TR.conv_case(16, 28, 50, 320, 320, expect="gemm_conv_kernel<128,128,64")
             TR.gemm_case(8736, 1280, 1280, res=True, expect="gemm_conv_kernel<128,128,64")
         TK.test_gemm_geglu_large_gates(dev, 8400, 1280, 320)               # the clamped polynomial erf against the fp16 table
         TK.test_gemm_geglu_large_gates(dev, 2100, 2560, 640)

@@ -433,7 +433,7 @@ def test_gemm_batched_vt(dev, Bt, T, Cc):
     (1, 41, 40, 16, 32, 3, (2, 2), (2, 1), False, False),        # map-encoder style asymmetric pad
     (1, 22, 20, 96, 256, 3, (2, 1), (2, 1), False, False),
     (2, 14, 25, 640, 640, 1, (1, 1), (0, 0), True, False),       # 1x1
-    (4, 28, 50, 320, 320, 3, (1, 1), (1, 1), True, True),        # M >= 4096: conv3x3.hip (3 taps share one A slab)
+    (4, 28, 50, 320, 320, 3, (1, 1), (1, 1), True, True),        # M >= 4096
     (13, 14, 25, 640, 192, 3, (1, 1), (1, 1), False, True),      # tiles straddle images (350 px each), ragged M and N
     (48, 7, 13, 128, 320, 3, (1, 1), (1, 1), True, False),       # 91-pixel images: a 128-row tile covers 2-3 of them
 ])
@@ -598,9 +598,22 @@ def test_groupnorm(dev, B, HW, Cc, G, silu, eps):
     gam = rnd(Cc, seed=2, dtype=torch.float32); bet = rnd(Cc, seed=3, dtype=torch.float32)
     y = torch.zeros_like(x)
     O.run_ops([O.GroupNorm(x, y, gam, bet, groups=G, eps=eps, silu=silu)])
-    y2 = torch.zeros_like(x)      # with a workspace: the two-stage coalesced path for big maps
-    O.run_ops([O.GroupNorm(x, y2, gam, bet, groups=G, eps=eps, silu=silu, ws=ws_buf(dev, 4))])
+    k1 = (L.lib().mdx_last_kernel() or b"").decode()
+    y2 = torch.zeros_like(x)      # with a workspace: the two-stage coalesced path for big maps (GN_ONE_KERNEL_ELEMS = 0: also for these few-image cases,
+    with L.options(GN_ONE_KERNEL_ELEMS=0):   # which the round-6 rule keeps on the one-launch kernel up to 4 M elements)
+        O.run_ops([O.GroupNorm(x, y2, gam, bet, groups=G, eps=eps, silu=silu, ws=ws_buf(dev, 4))])
+        k2 = (L.lib().mdx_last_kernel() or b"").decode()
     torch.cuda.synchronize()
+    assert k1 == "groupnorm_kernel" and (k2 == "gn_stats_kernel+gn_apply_kernel") == (HW * Cc >= 32768), (k1, k2)
+    if B * HW * Cc > (4 << 20) or HW * Cc < 32768:      # default rule with a workspace: one launch up to 4 M elements, the streaming passes above
+        y3 = torch.zeros_like(x)
+        O.run_ops([O.GroupNorm(x, y3, gam, bet, groups=G, eps=eps, silu=silu, ws=ws_buf(dev, 4))])
+        k3 = (L.lib().mdx_last_kernel() or b"").decode()
+        assert k3 == k2 and torch.equal(y3, y2), (k3, k2)
+    else:
+        y3 = torch.zeros_like(x)
+        O.run_ops([O.GroupNorm(x, y3, gam, bet, groups=G, eps=eps, silu=silu, ws=ws_buf(dev, 4))])
+        assert (L.lib().mdx_last_kernel() or b"").decode() == "groupnorm_kernel" and torch.equal(y3, y)
     ref = F.group_norm(x.float().cpu().transpose(1, 2), G, gam.cpu(), bet.cpu(), eps)
     if silu: ref = F.silu(ref)
     close(y, ref.transpose(1, 2), name="groupnorm")

@@ -211,7 +211,7 @@ def test_flattened_batched_vt(dev, Bt, T, Cc):
 
 # ---------------------------------------------------------------------------------------------------------------------------
 # Forced routes, in-process: the routing switches are library options (csrc/options.h, mdx_set_option): every XL tile width on small
-# ragged shapes (GEMM_XL=2: whenever supported), the other main loops (generic tile, conv3x3, gemm_ws) with the XL kernel switched
+# ragged shapes (GEMM_XL=2: whenever supported), the other main loops (generic tile, gemm_ws) with the XL kernel switched
 # off at the shapes the round-1 review listed, and the attention kernels' other instantiations.
 def gemm_case(M, N, K, bias=True, res=False, epi=0, expect=None):
     dev = torch.device("cuda")
@@ -269,15 +269,22 @@ def test_forced_no_xl(dev):
         gemm_case(8736, 1280, 1280, res=True, expect="gemm_conv_kernel<128,128,64")
         geglu_case(8736, 5120, 1280, expect="gemm_conv_kernel<128,128,64")
         gemm_case(4500, 2560, 1280, res=True, expect="gemm_conv_kernel<128,128,64")          # ragged M
-        conv_case(96, 7, 13, 1280, 1280, expect="conv3x3_kernel")                             # 8736 rows, tiles span 3-4 images
-        conv_case(24, 14, 25, 1920, 1280, res=False, expect="conv3x3_kernel")
-        conv_case(16, 28, 50, 320, 320, expect="conv3x3_kernel")
-        conv_case(600, 4, 7, 320, 320, expect="conv3x3_kernel")                               # 4x7 images
-        conv_case(22, 28, 28, 640, 640, expect="conv3x3_kernel")                              # 28-px rows straddling 128-row tiles
+        conv_case(96, 7, 13, 1280, 1280, expect="gemm_conv_kernel<128,128,64")               # 8736 rows, tiles span 3-4 images
+        conv_case(24, 14, 25, 1920, 1280, res=False, expect="gemm_conv_kernel<128,128,64")
+        conv_case(16, 28, 50, 320, 320, expect="gemm_conv_kernel<128,128,64")
+        conv_case(600, 4, 7, 320, 320, expect="gemm_conv_kernel<128,128,64")                  # 4x7 images
+        conv_case(22, 28, 28, 640, 640, expect="gemm_conv_kernel<128,128,64")                 # 28-px rows straddling 128-row tiles
         gemm_case(537600, 320, 320, res=True, expect="gemm_ws_kernel<plain>")                 # bench row count
         geglu_case(26400, 1280, 320, expect="gemm_ws_kernel<geglu>")                          # K = 320 GEGLU on the weight-stationary kernel
-        with L.options(CONV3=0):
-            conv_case(16, 28, 50, 320, 320, expect="gemm_conv_kernel<128,128,64")             # the generic implicit-GEMM conv
+        # small grids (round 6: GEMM_SMALL_TILES): 64 x 64 tiles for plain GEMMs / small convs, 128 x 128 for larger convs below 2048 rows, and the
+        # rounds 1-5 rule (128 rows from M = 2048, else 64 x 128) with the option off
+        gemm_case(2100, 640, 640, res=True, expect="gemm_conv_kernel<64,64,64")
+        conv_case(6, 28, 50, 320, 320, expect="gemm_conv_kernel<64,64,64")
+        conv_case(6, 7, 13, 2560, 1280, expect="gemm_conv_kernel<128,128,64")                 # 128 x 128 tiles (+ automatic split-K)
+        with L.options(GEMM_SMALL_TILES=0):
+            gemm_case(2100, 640, 640, res=True, expect="gemm_conv_kernel<128,128,64")
+            gemm_case(546, 1280, 1280, res=True, expect="gemm_conv_kernel<64,128,64")
+            conv_case(6, 7, 13, 2560, 1280, expect="gemm_conv_kernel<64,128,64")
 
 
 def test_forced_geglu320_on_xl(dev):

@@ -45,7 +45,7 @@ tot_def = tot_best = 0.0
 for key, ops in sorted(shapes.items(), key=lambda kv: (kv[0][0], -kv[0][1], kv[0][2], kv[0][3])):
     op = ops[0]
     t0, k0 = timeit(op)
-    if not (k0.startswith("gemm_conv_kernel") or k0.startswith("splitk_reduce") or k0.startswith("conv3x3")):
+    if not (k0.startswith("gemm_conv_kernel") or k0.startswith("splitk_reduce")):
         continue
     res = []
     if not a.default_only:
@@ -53,7 +53,7 @@ for key, ops in sorted(shapes.items(), key=lambda kv: (kv[0][0], -kv[0][1], kv[0
             if sk > 1 and key[3] / sk < 256: continue
             if key[5] == 1 and bn == 64: continue
             try:
-                with L.options(GEMM_BM=bm, GEMM_BN=bn, CONV3=0):
+                with L.options(GEMM_BM=bm, GEMM_BN=bn):
                     t, k = timeit(dataclasses.replace(op, splitk=sk))
             except Exception:
                 continue
