@@ -382,6 +382,14 @@ def main():
         fdt = DD.max_over_ranks(time.perf_counter() - t1, dev)
         assert torch.isfinite(fout).all()
         full_cond = {"scenes_per_s": nb * world / fdt, "scenes_per_gpu": nb, "seconds_per_call": fdt}
+        # ... and the reference's own call (tools/test.py, validation_batch_size 1): ONE scene with camera + boxes + map and CFG = 12 views per pass
+        fkw1 = dict(fkw, image=fkw["image"][:1], camera_param=fkw["camera_param"][:1], latents=fkw["latents"][:1], prompt_embeds=fkw["prompt_embeds"][:1],
+                    negative_prompt_embeds=fkw["negative_prompt_embeds"][:1], bev_controlnet_kwargs={"bboxes_3d_data": {k: v[:1] for k, v in fbox.items()}})
+        pipe(**fkw1); torch.cuda.synchronize()
+        ts2 = []
+        for _ in range(3):
+            t6 = time.perf_counter(); pipe(**fkw1); torch.cuda.synchronize(); ts2.append(time.perf_counter() - t6)
+        full_cond["latency_1scene_s"] = min(ts2)
 
     hires = None
     if args.hires_scenes > 0 and side:
@@ -462,6 +470,7 @@ def main():
                                                        "mfma_frac": round(vae_tf / (vae_dev_ms * 1e-3) / MFMA_BF16_PEAK_TFLOPS, 4),
                                                        "what": "AutoencoderKL.decode of one 6-view scene (SD-1.5 VAE, 224x400): op program on the sampler's kernels"},
                    "scenes_per_s_incl_vae_decode": None if vae_ms is None else round(1.0 / (world / scenes_per_s + vae_ms * 1e-3) * world, 4),
+                   "latency_1scene_full_cond_cfg_s": None if full_cond is None else round(full_cond["latency_1scene_s"], 4),
                    "full_cond_scenes_per_s": None if full_cond is None else round(full_cond["scenes_per_s"], 4),
                    "full_cond": None if full_cond is None else
                    {"workload": "configs[2]: 6-view 224x400, camera + 32 boxes + BEV map, CFG 2.0, same sampler", "scenes_per_gpu": full_cond["scenes_per_gpu"],
