@@ -286,24 +286,85 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 1) void gemm_con
 }
 
 // Sum the split-K slabs and apply the epilogue.  One thread per (m, 4 raw columns).
+// Round 6: every load of a thread is issued before the first is consumed — the epilogue operands (bias, temb row, residual) at the top, the slabs four at a
+// time through addresses clamped to the last slab.  As first written (one float4 per loop iteration, bias / temb / residual loaded where they are used, each
+// behind its own branch) the kernel was a chain of splitk + ~6 serial memory round trips: 8-12 us for a launch that moves a few hundred KB, and a 1-scene step
+// runs ~100 of them.  The slabs are still added in ascending z (one select per slab for the clamped ones): bit-identical sums.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GCParams p) {
     const int n4 = p.N / 4;
     long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)p.M * n4) return;
     int m = (int)(idx / n4);
     int nb = (int)(idx - (long)m * n4) * 4;
-    if (p.epi == 1 && (nb & 63) >= 32) return;  // gate columns are consumed by their value thread
-    float v[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0};
-    for (int z = 0; z < p.splitk; ++z) {
-        const float* w = p.ws + ((long)z * p.M + m) * p.N + nb;
-        float4 a = *(const float4*)w;
-        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
-        if (p.epi == 1) {
-            float4 b = *(const float4*)(w + 32);
-            g[0] += b.x; g[1] += b.y; g[2] += b.z; g[3] += b.w;
+    const bool geglu = p.epi == 1;
+    if (geglu && (nb & 63) >= 32) return;  // gate columns are consumed by their value thread
+    // ---- epilogue operands: all requested here ----
+    const int sel = (p.temb && p.sel) ? *p.sel : 0;
+    float bv[4] = {0, 0, 0, 0}, bg[4] = {0, 0, 0, 0}, tv[4] = {0, 0, 0, 0};
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bv[j] = p.bias[nb + j]; if (geglu) bg[j] = p.bias[nb + 32 + j]; }
+    }
+    if (p.temb && !geglu) {
+        const float* tb = p.temb + (long)sel * p.temb_sel_stride + (long)(m / p.rows_per_b) * p.temb_b_stride;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tv[j] = tb[nb + j];
+    }
+    const int ncol = geglu ? (nb >> 6) * 32 + (nb & 63) : nb;
+    float rf[4] = {0, 0, 0, 0};
+    if (p.R) {
+        if (p.c_f32) {
+            const float4 r4 = *(const float4*)((const float*)p.R + (long)m * p.ldr + ncol);
+            rf[0] = r4.x; rf[1] = r4.y; rf[2] = r4.z; rf[3] = r4.w;
+        } else {
+            const uint2 rv = *(const uint2*)((const bf16_t*)p.R + (long)m * p.ldr + ncol);
+            rf[0] = bf2f((bf16_t)(rv.x & 0xffff)); rf[1] = bf2f((bf16_t)(rv.x >> 16));
+            rf[2] = bf2f((bf16_t)(rv.y & 0xffff)); rf[3] = bf2f((bf16_t)(rv.y >> 16));
         }
     }
-    epilogue_store(p, 0, m, nb, v, g);
+    // ---- the slabs, four requests in flight ----
+    float v[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0};
+    const float* w0 = p.ws + (long)m * p.N + nb;
+    const long zs = (long)p.M * p.N;
+    const int last = p.splitk - 1;
+    for (int z0 = 0; z0 < p.splitk; z0 += 4) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* w = w0 + (long)min(z0 + i, last) * zs;
+            a[i] = *(const float4*)w;
+            if (geglu) b[i] = *(const float4*)(w + 32);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = z0 + i <= last;
+            v[0] = ok ? v[0] + a[i].x : v[0]; v[1] = ok ? v[1] + a[i].y : v[1]; v[2] = ok ? v[2] + a[i].z : v[2]; v[3] = ok ? v[3] + a[i].w : v[3];
+            if (geglu) { g[0] = ok ? g[0] + b[i].x : g[0]; g[1] = ok ? g[1] + b[i].y : g[1]; g[2] = ok ? g[2] + b[i].z : g[2]; g[3] = ok ? g[3] + b[i].w : g[3]; }
+        }
+    }
+    // ---- epilogue: the arithmetic of epilogue_store (gemm_params.h), operand for operand ----
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (geglu) {
+            float h = v[j], gt = g[j];
+            if (p.bias) { h += bv[j]; gt += bg[j]; }
+            o[j] = h * gelu_erf_f(gt);
+        } else {
+            float x = v[j];
+            if (p.bias) x += bv[j];
+            if (p.temb) x += tv[j];
+            if (p.epi == 2) x = silu_f(x);
+            o[j] = x;
+        }
+        if (p.R) o[j] += rf[j];
+    }
+    if (p.c_f32) {
+        *(float4*)((float*)p.C + (long)m * p.ldc + ncol) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+        uint2 ov; ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]);
+        *(uint2*)((bf16_t*)p.C + (long)m * p.ldc + ncol) = ov;
+    }
 }
 
 template <int BM, int BN, int BK, int WM, int WN, bool CONV, bool PIPE>

@@ -19,6 +19,7 @@ struct GNParams {
 };
 
 constexpr int GN_THREADS = 1024;
+constexpr int GN_MAX_CPG = 2560;     // channels per group the one-launch kernel keeps gamma / beta for in LDS (mdx_groupnorm_bf16 rejects more)
 
 // block-wide sum of two values at once (16 waves)
 __device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
@@ -68,60 +69,80 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_kernel(GNParams p) {
 
     // Loads are issued GN_U at a time before any is consumed (the loop is latency-, not bandwidth-bound:
     // a group's slab sits in L2), and a group that fits in GN_U vectors per thread is read only ONCE.
+    // Round 6 (this kernel is what 1-4 scene calls run, 88 launches per step): (pixel, channel vector) of a thread's vectors advance incrementally —
+    // vector i + 1024 is q pixels and r vectors further, (q, r) = divmod(1024, vpp) — instead of one 32-bit division by a run-time divisor per
+    // vector and pass (~30 VALU operations each, 14 per thread at level 0: ~3 us of a 12 us kernel with 4 waves per SIMD), and the group's
+    // gamma / beta wait in LDS (fetched beside the data, behind the reduction's barriers) instead of being a second global round trip in pass 2.
     constexpr int GN_U = (VEC == 8) ? 4 : 8;          // <= 32 live values per thread (1024-thread WG: 128 VGPR budget)
+    __shared__ float gb[2][GN_MAX_CPG];               // (a global or a "flat" load of gamma / beta in pass 2 waits on vmcnt(0), i.e. on the PREVIOUS vector's store: the
+    for (int c = threadIdx.x; c < cpg; c += GN_THREADS) { gb[0][c] = p.gamma[g * cpg + c]; gb[1][c] = p.beta[g * cpg + c]; }   // stores ran one round trip at a time)
     const float pivot = bf2f(xb[0]);
     float s1 = 0.f, s2 = 0.f;
     float v[GN_U][VEC];
     const bool single = nvec <= GN_U * GN_THREADS;
-    for (int base = threadIdx.x; base < nvec; base += GN_U * GN_THREADS) {
+    const int stepq = GN_THREADS / vpp, stepr = GN_THREADS - stepq * vpp;        // vector i + 1024 = pixel + stepq, vector-in-pixel + stepr (mod vpp)
+    const int bigq = (GN_U * GN_THREADS) / vpp, bigr = GN_U * GN_THREADS - bigq * vpp;
+    const int px0 = (int)threadIdx.x / vpp, r0 = (int)threadIdx.x - px0 * vpp;    // ONE division per thread
+    {
+        int pxb = px0, rb = r0;
+        for (int base = threadIdx.x; base < nvec; base += GN_U * GN_THREADS) {
+            int px = pxb, r = rb;
 #pragma unroll
-        for (int u = 0; u < GN_U; ++u) {
-            const int i = base + u * GN_THREADS;
-            if (i < nvec) {
-                int px = i / vpp;
-                load(px, (i - px * vpp) * VEC, v[u]);
-            } else {
+            for (int u = 0; u < GN_U; ++u) {
+                // unconditional loads (a vector past the end re-reads vector 0 and is replaced by the pivot): behind a per-lane branch every load got
+                // its own `s_waitcnt vmcnt(0)` inside the branch — the batch of GN_U loads was GN_U serial round trips (18 vs 10 us at level 0)
+                const int i = base + u * GN_THREADS;
+                const bool ok = i < nvec;
+                load(ok ? px : 0, ok ? r * VEC : 0, v[u]);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) v[u][e] = pivot;
+                for (int e = 0; e < VEC; ++e) v[u][e] = ok ? v[u][e] : pivot;
+                px += stepq; r += stepr;
+                if (r >= vpp) { r -= vpp; ++px; }
             }
+#pragma unroll
+            for (int u = 0; u < GN_U; ++u)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { float dlt = v[u][e] - pivot; s1 += dlt; s2 += dlt * dlt; }
+            pxb += bigq; rb += bigr;
+            if (rb >= vpp) { rb -= vpp; ++pxb; }
         }
-#pragma unroll
-        for (int u = 0; u < GN_U; ++u)
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) { float dlt = v[u][e] - pivot; s1 += dlt; s2 += dlt * dlt; }
     }
-    block_sum2(s1, s2, red);
+    block_sum2(s1, s2, red);                          // (its barriers also publish gb)
     const float n = (float)p.HW * (float)cpg;
     const float md = s1 / n;                          // mean of (x - pivot)
     const float mean = pivot + md;
     const float var = fmaxf(s2 / n - md * md, 0.f);
     const float rstd = rsqrtf(var + p.eps);
+    int pxb = px0, rb = r0;
     for (int base = threadIdx.x; base < nvec; base += GN_U * GN_THREADS) {
         if (!single) {
+            int px = pxb, r = rb;
 #pragma unroll
             for (int u = 0; u < GN_U; ++u) {
                 const int i = base + u * GN_THREADS;
-                if (i < nvec) {
-                    int px = i / vpp;
-                    load(px, (i - px * vpp) * VEC, v[u]);
-                }
+                const bool ok = i < nvec;
+                load(ok ? px : 0, ok ? r * VEC : 0, v[u]);
+                px += stepq; r += stepr;
+                if (r >= vpp) { r -= vpp; ++px; }
             }
         }
+        int px = pxb, r = rb;
 #pragma unroll
         for (int u = 0; u < GN_U; ++u) {
             const int i = base + u * GN_THREADS;
+            const int cpx = px, cv = r * VEC;
+            px += stepq; r += stepr;
+            if (r >= vpp) { r -= vpp; ++px; }
             if (i >= nvec) continue;
-            const int px = i / vpp;
-            const int cv = (i - px * vpp) * VEC;
-            const int c0 = g * cpg + cv;
             float o[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                float y = (v[u][e] - mean) * rstd * p.gamma[c0 + e] + p.beta[c0 + e];
+                const float ga = gb[0][cv + e], be = gb[1][cv + e];
+                float y = (v[u][e] - mean) * rstd * ga + be;
                 if (p.silu) y = silu_f(y);
                 o[e] = y;
             }
-            bf16_t* dptr = yb + px * ldy + cv;
+            bf16_t* dptr = yb + cpx * ldy + cv;
             if constexpr (VEC == 8) {
                 uint4 u4; u4.x = pack2bf(o[0], o[1]); u4.y = pack2bf(o[2], o[3]); u4.z = pack2bf(o[4], o[5]); u4.w = pack2bf(o[6], o[7]);
                 *(uint4*)dptr = u4;
@@ -134,6 +155,8 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm_kernel(GNParams p) {
                 *dptr = f2bf(o[0]);
             }
         }
+        pxb += bigq; rb += bigr;
+        if (rb >= vpp) { rb -= vpp; ++pxb; }
     }
 }
 
@@ -426,6 +449,7 @@ extern "C" int mdx_groupnorm_bf16(const MdxGroupNormDesc* d, void* stream) {
     if (!d || !d->X || !d->Y || !d->gamma || !d->beta) return set_error(MDX_EINVAL, "mdx_groupnorm_bf16: null operand");
     if (d->G <= 0 || d->C % d->G) return set_error(MDX_EINVAL, "groupnorm: C=%ld not divisible by G=%ld", (long)d->C, (long)d->G);
     if (d->B <= 0 || d->HW <= 0) return MDX_OK;
+    if (d->C / d->G > GN_MAX_CPG) return set_error(MDX_EUNSUPPORTED, "groupnorm: %ld channels per group (at most %d)", (long)(d->C / d->G), GN_MAX_CPG);
     GNParams p;
     p.X = (const bf16_t*)d->X; p.Y = (bf16_t*)d->Y; p.gamma = d->gamma; p.beta = d->beta;
     p.B = (int)d->B; p.HW = (int)d->HW; p.C = (int)d->C; p.G = (int)d->G; p.ldx = d->ldx; p.ldy = d->ldy;
