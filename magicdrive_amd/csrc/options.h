@@ -37,7 +37,7 @@ namespace mdx {
     X(GEMM_WS, 1, "gemm_ws.hip: 0 off, 1 when M >= 8192, 2 whenever supported") \
     X(GEMM_XL, 1, "gemm_xl.hip: 0 off, 1 cost model, 2 whenever supported") \
     X(XL_K320, 0, "let XL take the K = 320 projections from gemm_ws.hip") \
-    X(XL_MIN_TILES, 160, "fewest 256-row tiles an XL launch must have") \
+    X(XL_MIN_TILES, 64, "fewest 256-row tiles an XL launch must have (round 6: 64; 160 until then — 2...8 scenes per call are 2-6 % faster with the lower bound, 12+ scenes and 1 scene do not care: profiles/r06_lat1_small_grids.log)") \
     X(XL_BN, 0, "force an XL tile width (160 / 256 / 320; 0 = cost model)") \
     X(XL_GEGLU320, 0, "K = 320 GEGLU on the 256-wide XL tile instead of gemm_ws.hip") \
     X(GEMM_BM256, 0, "generic 256x128 8-wave tile from M >= value (0 = never)") \
