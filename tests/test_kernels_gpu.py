@@ -365,6 +365,46 @@ def test_gemm_forced_splitk_matches(dev):
     close(C1, ref, name="splitk=1"); close(C2, ref, name="splitk=6")
 
 
+@pytest.mark.parametrize("sk", [2, 3, 5, 8, 13])
+@pytest.mark.parametrize("kind", ["plain", "temb_res", "silu", "geglu"])
+def test_splitk_reduce_epilogues(dev, sk, kind):
+    """splitk_reduce_kernel (round 6: every load requested before the first is consumed, slabs four in flight through clamped addresses) with each epilogue it
+    applies, at slab counts on both sides of a multiple of four — against the fp32 reference, bit-identical to a second run, and within rounding of the
+    one-pass (splitk = 1) launch, whose reduction order differs only in where the k range is cut."""
+    M, K = 168, 2560
+    A = rnd(M, K, seed=1)
+    ws = ws_buf(dev)
+    if kind == "geglu":
+        F_ = 640
+        W = rnd(2 * F_, K, scale=K ** -0.5, seed=2, dtype=torch.float32, dev="cpu"); b = rnd(2 * F_, seed=3, dtype=torch.float32, dev="cpu")
+        Wp, bp = PK.pack_geglu(W, b, BF)
+        mk = lambda C, s_: O.Gemm(A, Wp.to(dev), C, bias=bp.to(dev), epilogue=L.EPI_GEGLU, splitk=s_, ws=ws)
+        h, g = (A.float().cpu() @ W.to(BF).float().T + b).chunk(2, dim=-1)
+        ref = h * F.gelu(g); N = F_
+    else:
+        N = 648                                                     # N % 8 != 0: the narrow-store layout of the fp32 slabs' consumer
+        W = rnd(N, K, scale=K ** -0.5, seed=2); b = rnd(N, seed=3, dtype=torch.float32)
+        R = rnd(M, N, seed=4) if kind == "temb_res" else None
+        tb = rnd(3, 6, N, seed=5, dtype=torch.float32) if kind == "temb_res" else None      # [step][image][N]; rows_per_b = 28
+        sel = torch.tensor([2], dtype=torch.int32, device=dev) if kind == "temb_res" else None
+        epi = 2 if kind == "silu" else 0
+        mk = lambda C, s_: O.Gemm(A, W, C, bias=b, R=R, temb=tb, sel=sel, temb_sel_stride=6 * N if tb is not None else 0, temb_b_stride=N if tb is not None else 0,
+                                  rows_per_b=28, epilogue=epi, splitk=s_, ws=ws)
+        ref = A.float().cpu() @ W.float().cpu().T + b.cpu()
+        if tb is not None: ref = ref + tb[2].cpu().repeat_interleave(28, dim=0)
+        if epi == 2: ref = F.silu(ref)
+        if R is not None: ref = ref + R.float().cpu()
+    outs = []
+    for s_ in (sk, sk, 1):
+        C = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+        O.run_ops([mk(C, s_)])
+        torch.cuda.synchronize()
+        outs.append(C)
+    close(outs[0], ref, name=f"split-K {sk} {kind}")
+    assert torch.equal(outs[0], outs[1]), "split-K reduce is not deterministic"
+    assert rel_l2(outs[0], outs[2]) < 4e-3, rel_l2(outs[0], outs[2])
+
+
 def test_gemm_strided_views_and_temb(dev):
     # A and C are column slices of wider buffers; temb row chosen by a device-side selector
     M, N, K = 2 * 350, 640, 320
