@@ -3,7 +3,7 @@
 import os, sys
 os.environ["MDX_GEMM_TIMING"] = "1"
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from magicdrive_amd import _lib as L, ops as O
 BF = torch.bfloat16
